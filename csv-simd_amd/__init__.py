@@ -1,0 +1,356 @@
+"""csv-simd_amd — Python host side of the MI355X stage-1 CSV structural indexer.
+
+Thin ctypes binding over the C ABI in ``include/csvsimd.h`` (``csrc/libcsvsimd_hip.so``, built
+in-tree by ``__graft_entry__.build()`` / ``make -C csv-simd_amd/csrc``).  Names follow the
+reference crate: ``read`` (src/reader.rs:150), ``create`` (src/lib.rs:61), ``Tape`` /
+``boundaries`` / ``chunks`` (src/tape.rs), ``seek_record`` / ``seek_field``
+(src/record_source.rs:70-140), ``StructureError`` (src/error.rs:7-21).
+
+There is no CPU fallback: every compute call needs a HIP device and raises ``StructureError``
+(or ``OSError`` if the shared library has not been built) otherwise.  The directory name holds a
+hyphen, so import it with ``__graft_entry__.load_package()`` (module name ``csv_simd_amd``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcsvsimd_hip.so")
+TILE_BYTES = 128 * 1024
+
+OK = 0
+ERR_IO, ERR_MISSING_VALUE, ERR_INVALID_STATE, ERR_INVALID_CSV_FORMAT = -1, -2, -3, -4
+ERR_INVALID_ARG, ERR_TAPE_CAPACITY, ERR_HIP, ERR_NO_DEVICE, ERR_INTERNAL = -9, -11, -12, -13, -14
+NEWLINE_LF, NEWLINE_CRLF = 0, 1
+
+
+class StructureError(RuntimeError):
+    """Mirror of reference ``StructureError`` (src/error.rs:7-21) plus the ABI's own codes."""
+
+    def __init__(self, code: int, detail: str = ""):
+        self.code = code
+        msg = lib().csvsimd_strerror(code).decode()
+        if code == ERR_HIP or detail:
+            msg += ": " + (detail or lib().csvsimd_last_error().decode())
+        super().__init__(f"[{code}] {msg}")
+
+
+class ShardResult(C.Structure):
+    _fields_ = [
+        ("count", C.c_uint64),
+        ("count_enter_outside", C.c_uint64),
+        ("count_enter_inside", C.c_uint64),
+        ("quote_parity", C.c_uint32),
+        ("in_quote_out", C.c_uint32),
+        ("error", C.c_uint32),
+        ("reserved0", C.c_uint32),
+        ("written", C.c_uint64),
+        ("reserved1", C.c_uint64 * 2),
+    ]
+
+
+class Stitch(C.Structure):
+    _fields_ = [
+        ("in_quote_in", C.c_uint32),
+        ("in_quote_final", C.c_uint32),
+        ("count", C.c_uint64),
+        ("tape_index_base", C.c_uint64),
+        ("total_entries", C.c_uint64),
+    ]
+
+
+class _Boundary(C.Structure):
+    _fields_ = [("start", C.c_uint64), ("len", C.c_uint64)]
+
+
+class _Chunk(C.Structure):
+    _fields_ = [("id", C.c_uint8), ("start", C.c_uint64), ("end", C.c_uint64), ("record_cnt", C.c_uint32)]
+
+
+# every symbol include/csvsimd.h declares: (restype, argtypes)
+_u64p = C.POINTER(C.c_uint64)
+_PROTOTYPES = {
+    "csvsimd_strerror": (C.c_char_p, [C.c_int]),
+    "csvsimd_last_error": (C.c_char_p, []),
+    "csvsimd_device_count": (C.c_int, []),
+    "csvsimd_abi_version": (C.c_uint32, []),
+    "csvsimd_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "csvsimd_ctx_destroy": (None, [C.c_void_p]),
+    "csvsimd_ctx_reserve": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "csvsimd_stage1_index_device_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32,
+                                                    C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "csvsimd_stage1_index_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32,
+                                              C.c_void_p, C.c_uint64, C.POINTER(ShardResult), C.c_void_p]),
+    "csvsimd_stage1_bound": (C.c_int, [C.c_uint64, _u64p]),
+    "csvsimd_stage1_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, _u64p,
+                                       C.POINTER(C.c_uint32)]),
+    "csvsimd_stitch_shards": (C.c_int, [C.POINTER(ShardResult), C.c_uint32, C.c_uint32, C.c_uint32,
+                                        C.POINTER(Stitch)]),
+    "csvsimd_tape_create": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "csvsimd_tape_destroy": (None, [C.c_void_p]),
+    "csvsimd_tape_field_cnt": (C.c_uint32, [C.c_void_p]),
+    "csvsimd_tape_record_cnt": (C.c_uint32, [C.c_void_p]),
+    "csvsimd_tape_record_jump_size": (C.c_uint64, [C.c_void_p]),
+    "csvsimd_tape_record_offset": (C.c_uint32, [C.c_void_p]),
+    "csvsimd_tape_new_line": (C.c_int, [C.c_void_p]),
+    "csvsimd_tape_header_name": (C.c_int64, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint64]),
+    "csvsimd_tape_seek_record": (C.c_int, [C.c_void_p, C.c_uint32, _u64p, _u64p, C.POINTER(C.c_int)]),
+    "csvsimd_tape_seek_field": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, _u64p, _u64p, C.POINTER(C.c_int)]),
+    "csvsimd_boundaries": (C.c_int, [C.c_uint32, C.c_uint8, C.POINTER(_Boundary), C.POINTER(C.c_uint32)]),
+    "csvsimd_tape_chunks": (C.c_int, [C.c_void_p, C.c_uint8, C.POINTER(_Chunk), C.POINTER(C.c_uint32)]),
+    "csvsimd_create": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]),
+    "csvsimd_tape_index": (_u64p, [C.c_void_p, _u64p]),
+    "csvsimd_tape_bytes": (C.POINTER(C.c_uint8), [C.c_void_p, _u64p]),
+    "csvsimd_synth_fill_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
+                                            C.c_uint64, C.c_uint32, C.c_void_p]),
+    "csvsimd_tape_checksum_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "csvsimd_selftest_device": (C.c_int, [C.c_int]),
+    "csvsimd_stage1_time_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                             C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+}
+EXPORTED_SYMBOLS = tuple(_PROTOTYPES)
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Loads libcsvsimd_hip.so (fails loudly if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OSError(f"{LIB_PATH} is missing: run __graft_entry__.build() (no CPU fallback exists)")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOTYPES.items():
+            fn = getattr(handle, name)  # AttributeError = the ABI lost a symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def _check(rc: int) -> None:
+    if rc != OK:
+        raise StructureError(rc)
+
+
+def device_count() -> int:
+    return lib().csvsimd_device_count()
+
+
+def selftest(device: int = 0) -> None:
+    _check(lib().csvsimd_selftest_device(device))
+
+
+class Context:
+    """One per (thread, device): owns the look-back scratch (csvsimd_ctx)."""
+
+    def __init__(self, device: int = 0):
+        h = C.c_void_p()
+        _check(lib().csvsimd_ctx_create(device, C.byref(h)))
+        self._h = h
+        self.device = device
+
+    def reserve(self, max_len: int) -> None:
+        _check(lib().csvsimd_ctx_reserve(self._h, max_len))
+
+    def close(self) -> None:
+        if self._h:
+            lib().csvsimd_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- stage 1 on device-resident bytes (pointers are raw device addresses) ----------------
+    def stage1_index_device(self, dbuf: int, length: int, base_off: int = 0, in_quote_in: int = 0,
+                            dtape: int = 0, tape_cap: int = 0, stream: int = 0,
+                            allow_overflow: bool = False) -> ShardResult:
+        r = ShardResult()
+        rc = lib().csvsimd_stage1_index_device(self._h, dbuf, length, base_off, in_quote_in, dtape or None,
+                                               tape_cap, C.byref(r), stream or None)
+        if rc == ERR_TAPE_CAPACITY and allow_overflow:
+            return r
+        _check(rc)
+        return r
+
+    def stage1_index_device_async(self, dbuf: int, length: int, base_off: int, in_quote_in: int, dtape: int,
+                                  tape_cap: int, d_result: int, stream: int = 0) -> None:
+        _check(lib().csvsimd_stage1_index_device_async(self._h, dbuf, length, base_off, in_quote_in,
+                                                       dtape or None, tape_cap, d_result, stream or None))
+
+    def stage1_time_device(self, dbuf: int, length: int, dtape: int, tape_cap: int, d_result: int,
+                           stream: int = 0, warmup: int = 2, iters: int = 10) -> float:
+        ms = C.c_float()
+        _check(lib().csvsimd_stage1_time_device(self._h, dbuf, length, dtape or None, tape_cap, d_result,
+                                                stream or None, warmup, iters, C.byref(ms)))
+        return float(ms.value)
+
+    # ---- reader::read(&Mmap) -> StructureIndex (src/reader.rs:150) ---------------------------
+    def read(self, data) -> np.ndarray:
+        """Host bytes -> index (uint64 array, [0] == 0 sentinel). Two passes: count, then fill."""
+        a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        n = C.c_uint64()
+        ptr = a.ctypes.data if a.size else None
+        _check(lib().csvsimd_stage1_index(self._h, ptr, a.size, None, 0, C.byref(n), None))
+        out = np.empty(n.value, dtype=np.uint64)
+        _check(lib().csvsimd_stage1_index(self._h, ptr, a.size, out.ctypes.data, out.size, C.byref(n), None))
+        return out[: n.value]
+
+    def read_into(self, data: np.ndarray, tape: np.ndarray) -> Tuple[int, int, int]:
+        """Raw csvsimd_stage1_index: returns (rc, tape_len, in_quote_out)."""
+        n, q = C.c_uint64(), C.c_uint32()
+        rc = lib().csvsimd_stage1_index(self._h, data.ctypes.data if data.size else None, data.size,
+                                        tape.ctypes.data if tape is not None and tape.size else None,
+                                        tape.size if tape is not None else 0, C.byref(n), C.byref(q))
+        return rc, n.value, q.value
+
+    # ---- csv_simd::create(filename) -> Tape (src/lib.rs:61-74) ---------------------------------
+    def create(self, filename: str) -> "Tape":
+        h = C.c_void_p()
+        _check(lib().csvsimd_create(self._h, os.fsencode(filename), C.byref(h)))
+        return Tape(h)
+
+
+def stage1_bound(length: int) -> int:
+    n = C.c_uint64()
+    _check(lib().csvsimd_stage1_bound(length, C.byref(n)))
+    return n.value
+
+
+def stitch_shards(results: Sequence[ShardResult], rank: int, file_in_quote_in: int = 0) -> Stitch:
+    arr = (ShardResult * len(results))(*results)
+    out = Stitch()
+    _check(lib().csvsimd_stitch_shards(arr, len(results), rank, file_in_quote_in, C.byref(out)))
+    return out
+
+
+def boundaries(task_size: int, job_count: int) -> Optional[List[Tuple[int, int]]]:
+    """reference ``boundaries`` (src/tape.rs:385-428): list of (start, len) or None."""
+    out = (_Boundary * max(job_count, 1))()
+    n = C.c_uint32()
+    rc = lib().csvsimd_boundaries(task_size, job_count, out, C.byref(n))
+    if rc == ERR_INVALID_STATE:
+        return None
+    _check(rc)
+    return [(out[i].start, out[i].len) for i in range(n.value)]
+
+
+class Tape:
+    """reference ``Tape`` (src/tape.rs:74-153) + ``RecordSource`` (src/record_source.rs)."""
+
+    def __init__(self, handle: C.c_void_p, keepalive=None):
+        self._h = handle
+        self._keep = keepalive
+
+    @classmethod
+    def from_index(cls, data: np.ndarray, index: np.ndarray) -> "Tape":
+        """TapeCore::create + Tape::from_core on a finished index (borrows both arrays)."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        index = np.ascontiguousarray(index, dtype=np.uint64)
+        h = C.c_void_p()
+        _check(lib().csvsimd_tape_create(data.ctypes.data, data.size, index.ctypes.data, index.size, C.byref(h)))
+        return cls(h, keepalive=(data, index))
+
+    def close(self) -> None:
+        if self._h:
+            lib().csvsimd_tape_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def field_cnt(self) -> int:
+        return lib().csvsimd_tape_field_cnt(self._h)
+
+    @property
+    def record_cnt(self) -> int:
+        return lib().csvsimd_tape_record_cnt(self._h)
+
+    @property
+    def record_jump_size(self) -> int:
+        return lib().csvsimd_tape_record_jump_size(self._h)
+
+    @property
+    def record_offset(self) -> int:
+        return lib().csvsimd_tape_record_offset(self._h)
+
+    @property
+    def new_line(self) -> str:
+        return "CRLF" if lib().csvsimd_tape_new_line(self._h) == NEWLINE_CRLF else "LF"
+
+    def header(self) -> List[str]:
+        names = []
+        for i in range(self.field_cnt):
+            n = lib().csvsimd_tape_header_name(self._h, i, None, 0)
+            buf = C.create_string_buffer(int(n) + 1)
+            lib().csvsimd_tape_header_name(self._h, i, buf, n)
+            names.append(buf.raw[:n].decode("utf-8", "replace"))
+        return names
+
+    def index(self) -> np.ndarray:
+        n = C.c_uint64()
+        p = lib().csvsimd_tape_index(self._h, C.byref(n))
+        return np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+
+    def bytes(self) -> bytes:
+        n = C.c_uint64()
+        p = lib().csvsimd_tape_bytes(self._h, C.byref(n))
+        return C.string_at(p, n.value)
+
+    def _span(self, fn, *idx) -> Optional[Tuple[int, int]]:
+        b, e, f = C.c_uint64(), C.c_uint64(), C.c_int()
+        _check(fn(self._h, *idx, C.byref(b), C.byref(e), C.byref(f)))
+        return (b.value, e.value) if f.value else None
+
+    def seek_record(self, record_idx: int) -> Optional[bytes]:
+        s = self._span(lib().csvsimd_tape_seek_record, record_idx)
+        return None if s is None else self.bytes()[s[0]: s[1]]
+
+    def seek_field(self, record_idx: int, field_idx: int) -> Optional[bytes]:
+        s = self._span(lib().csvsimd_tape_seek_field, record_idx, field_idx)
+        return None if s is None else self.bytes()[s[0]: s[1]]
+
+    def chunks(self, num: int) -> List[Tuple[int, int, int, int]]:
+        """Tape::chunks (src/tape.rs:95-140): [(id, start, end, record_cnt)] in index-key units."""
+        out = (_Chunk * max(num, 1))()
+        n = C.c_uint32()
+        _check(lib().csvsimd_tape_chunks(self._h, num, out, C.byref(n)))
+        return [(out[i].id, out[i].start, out[i].end, out[i].record_cnt) for i in range(n.value)]
+
+
+# ---- device utilities (raw device addresses; torch tensors' .data_ptr() fit) --------------------
+def synth_fill_device(dbuf: int, file_off: int, length: int, cols: int, width: int, seed: int,
+                      quote_pct: int = 0, stream: int = 0) -> None:
+    _check(lib().csvsimd_synth_fill_device(dbuf, file_off, length, cols, width, seed, quote_pct, stream or None))
+
+
+def tape_checksum_device(dtape: int, n: int, first_index: int, d_out: int, stream: int = 0) -> None:
+    _check(lib().csvsimd_tape_checksum_device(dtape or None, n, first_index, d_out, stream or None))
+
+
+# the synthetic corpora of SURVEY.md §8d / BASELINE.md: name -> (cols, width, seed, quote_pct)
+WORKLOADS = {
+    "16x32_noquote": (16, 32, 0xC5F00002, 0),
+    "16x32_q10": (16, 32, 0xC5F00003, 10),
+    "64x31_noquote": (64, 31, 0xC5F00004, 0),
+    "64x31_q10": (64, 31, 0xC5F00004, 10),
+    "1024x4_dense": (1024, 4, 0xC5F00005, 0),
+}
+
+
+def workload_len(name: str, target_bytes: int) -> int:
+    """Whole rows only: the largest multiple of the row size that fits target_bytes."""
+    cols, width, _, _ = WORKLOADS[name]
+    row = cols * (width + 1)
+    return (target_bytes // row) * row

@@ -1,0 +1,475 @@
+// capi.cpp — the C ABI of libcsvsimd_hip.so (include/csvsimd.h): context, stage-1 entry points,
+// shard stitch, tape accessors, csv_simd::create().  Compiled with hipcc (HIP runtime API only;
+// the kernels live in stage1_kernels.hip).  There is no CPU fallback anywhere in this file.
+#include <fcntl.h>
+#include <hip/hip_runtime.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../host/csv_simd.hpp"
+#include "csvsimd.h"
+#include "stage1_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail_hip(hipError_t e, const char* what) {
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return CSVSIMD_ERR_HIP;
+}
+#define HIP_TRY(expr)                                         \
+    do {                                                      \
+        hipError_t _e = (expr);                               \
+        if (_e != hipSuccess) return fail_hip(_e, #expr);     \
+    } while (0)
+
+}  // namespace
+
+struct csvsimd_ctx {
+    int device = 0;
+    void* scratch = nullptr;
+    uint64_t scratch_bytes = 0;
+    uint32_t max_blocks = 0;
+    csvsimd_shard_result* d_result = nullptr;  // for the synchronous entry points
+    // host-buffer path staging (grown on demand)
+    void* d_in = nullptr;
+    uint64_t d_in_bytes = 0;
+    void* d_tape = nullptr;
+    uint64_t d_tape_entries = 0;
+};
+
+extern "C" {
+
+const char* csvsimd_strerror(int code) {
+    switch (code) {
+        case CSVSIMD_OK: return "ok";
+        case CSVSIMD_ERR_IO: return "io error";
+        case CSVSIMD_ERR_MISSING_VALUE: return "Missing a value";
+        case CSVSIMD_ERR_INVALID_STATE: return "Invalid state";
+        case CSVSIMD_ERR_INVALID_CSV_FORMAT: return "Unsupported csv structure: likely variable number of fields";
+        case CSVSIMD_ERR_INVALID_ARG: return "invalid argument";
+        case CSVSIMD_ERR_TAPE_CAPACITY: return "tape capacity too small";
+        case CSVSIMD_ERR_HIP: return "HIP runtime error";
+        case CSVSIMD_ERR_NO_DEVICE: return "no HIP device";
+        case CSVSIMD_ERR_INTERNAL: return "internal error (look-back spin bound)";
+        default: return "unknown error";
+    }
+}
+
+const char* csvsimd_last_error(void) { return g_last_error.c_str(); }
+
+int csvsimd_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+uint32_t csvsimd_abi_version(void) { return 1; }
+
+int csvsimd_ctx_create(int device, csvsimd_ctx** out) {
+    if (!out) return CSVSIMD_ERR_INVALID_ARG;
+    *out = nullptr;
+    const int n = csvsimd_device_count();
+    if (n <= 0) {
+        g_last_error = "no HIP device visible: libcsvsimd_hip has no CPU fallback";
+        return CSVSIMD_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) return CSVSIMD_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    std::unique_ptr<csvsimd_ctx> ctx(new (std::nothrow) csvsimd_ctx);
+    if (!ctx) return CSVSIMD_ERR_INVALID_STATE;
+    ctx->device = device;
+    const int per_cu = csvsimd::stage1_max_blocks_per_cu();
+    ctx->max_blocks = (uint32_t)(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256) * (uint32_t)per_cu;
+    HIP_TRY(hipMalloc((void**)&ctx->d_result, sizeof(csvsimd_shard_result)));
+    *out = ctx.release();
+    const int rc = csvsimd_ctx_reserve(*out, 1ull << 30);
+    if (rc != CSVSIMD_OK) {
+        csvsimd_ctx_destroy(*out);
+        *out = nullptr;
+    }
+    return rc;
+}
+
+void csvsimd_ctx_destroy(csvsimd_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->d_result) (void)hipFree(ctx->d_result);
+    if (ctx->d_in) (void)hipFree(ctx->d_in);
+    if (ctx->d_tape) (void)hipFree(ctx->d_tape);
+    delete ctx;
+}
+
+int csvsimd_ctx_reserve(csvsimd_ctx* ctx, uint64_t max_len) {
+    if (!ctx) return CSVSIMD_ERR_INVALID_ARG;
+    const uint64_t need = csvsimd::Stage1Launch::scratch_bytes_for(max_len);
+    if (need <= ctx->scratch_bytes) return CSVSIMD_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (ctx->scratch) HIP_TRY(hipFree(ctx->scratch));
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    HIP_TRY(hipMalloc(&ctx->scratch, need));
+    ctx->scratch_bytes = need;
+    return CSVSIMD_OK;
+}
+
+int csvsimd_stage1_index_device_async(csvsimd_ctx* ctx, const void* dbuf, uint64_t len, uint64_t base_off,
+                                      uint32_t in_quote_in, void* dtape, uint64_t tape_cap, void* d_result,
+                                      void* hip_stream) {
+    if (!ctx || !d_result || (len && !dbuf) || (!dtape && tape_cap)) return CSVSIMD_ERR_INVALID_ARG;
+    if (len >= (1ull << 60)) return CSVSIMD_ERR_INVALID_ARG;
+    if (((uintptr_t)dtape & 7) || ((uintptr_t)d_result & 7)) return CSVSIMD_ERR_INVALID_ARG;
+    if (csvsimd::Stage1Launch::scratch_bytes_for(len) > ctx->scratch_bytes) {
+        const int rc = csvsimd_ctx_reserve(ctx, len);  // allocates + synchronises: not capturable
+        if (rc != CSVSIMD_OK) return rc;
+    }
+    csvsimd::Stage1Launch L;
+    L.dbuf = dbuf;
+    L.len = len;
+    L.base_off = base_off;
+    L.in_quote_in = in_quote_in ? 1u : 0u;
+    L.dtape = dtape;
+    L.tape_cap = tape_cap;
+    L.d_result = (csvsimd_shard_result*)d_result;
+    L.bind_scratch(ctx->scratch);
+    L.max_blocks = ctx->max_blocks;
+    HIP_TRY(csvsimd::launch_stage1(L, (hipStream_t)hip_stream));
+    return CSVSIMD_OK;
+}
+
+int csvsimd_stage1_index_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len, uint64_t base_off,
+                                uint32_t in_quote_in, void* dtape, uint64_t tape_cap,
+                                csvsimd_shard_result* result, void* hip_stream) {
+    if (!ctx || !result) return CSVSIMD_ERR_INVALID_ARG;
+    int rc = csvsimd_stage1_index_device_async(ctx, dbuf, len, base_off, in_quote_in, dtape, tape_cap,
+                                               ctx->d_result, hip_stream);
+    if (rc != CSVSIMD_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(result, ctx->d_result, sizeof(*result), hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
+    if (result->error) {
+        g_last_error = "stage1 kernel: look-back spin bound hit";
+        return CSVSIMD_ERR_INTERNAL;
+    }
+    if (dtape && result->count > tape_cap) return CSVSIMD_ERR_TAPE_CAPACITY;
+    return CSVSIMD_OK;
+}
+
+int csvsimd_stage1_bound(uint64_t len, uint64_t* max_entries) {
+    if (!max_entries) return CSVSIMD_ERR_INVALID_ARG;
+    *max_entries = len + 1;  // every byte structural + the sentinel
+    return CSVSIMD_OK;
+}
+
+// Host-buffer drop-in for reader::read.  The file is streamed through the GPU in chunks; the two
+// loop-carried values of the reference (inside_str, array_idx: src/reader.rs:217-218) are
+// carried between chunks on the host.
+int csvsimd_stage1_index(csvsimd_ctx* ctx, const uint8_t* buf, uint64_t len, uint64_t* tape, uint64_t tape_cap,
+                         uint64_t* tape_len, uint32_t* in_quote_out) {
+    if (!ctx || (len && !buf) || (!tape && tape_cap) || !tape_len) return CSVSIMD_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    constexpr uint64_t kChunk = 256ull << 20;  // bytes per pass
+    const uint64_t chunk_max = std::min<uint64_t>(len ? len : 1, kChunk);
+    if (ctx->d_in_bytes < chunk_max) {
+        if (ctx->d_in) HIP_TRY(hipFree(ctx->d_in));
+        ctx->d_in = nullptr;
+        ctx->d_in_bytes = 0;
+        HIP_TRY(hipMalloc(&ctx->d_in, (chunk_max + 255) & ~255ull));
+        ctx->d_in_bytes = chunk_max;
+    }
+    auto ensure_tape = [&](uint64_t entries) -> int {
+        if (ctx->d_tape_entries >= entries) return CSVSIMD_OK;
+        if (ctx->d_tape) HIP_TRY(hipFree(ctx->d_tape));
+        ctx->d_tape = nullptr;
+        ctx->d_tape_entries = 0;
+        HIP_TRY(hipMalloc(&ctx->d_tape, std::max<uint64_t>(entries, 1) * 8));
+        ctx->d_tape_entries = std::max<uint64_t>(entries, 1);
+        return CSVSIMD_OK;
+    };
+
+    uint64_t n = 0;  // entries so far, sentinel included
+    if (tape && tape_cap >= 1) tape[0] = 0;  // src/reader.rs:216
+    n = 1;
+    uint32_t inq = 0;
+    for (uint64_t off = 0; off < len; off += kChunk) {
+        const uint64_t clen = std::min<uint64_t>(kChunk, len - off);
+        HIP_TRY(hipMemcpy(ctx->d_in, buf + off, clen, hipMemcpyHostToDevice));
+        csvsimd_shard_result r;
+        int rc;
+        if (!tape) {
+            rc = csvsimd_stage1_index_device(ctx, ctx->d_in, clen, off, inq, nullptr, 0, &r, nullptr);
+            if (rc != CSVSIMD_OK) return rc;
+        } else {
+            // first guess: one entry per 4 bytes; exact retry if the chunk is denser
+            rc = ensure_tape(std::max<uint64_t>(clen / 4, 4096));
+            if (rc != CSVSIMD_OK) return rc;
+            rc = csvsimd_stage1_index_device(ctx, ctx->d_in, clen, off, inq, ctx->d_tape, ctx->d_tape_entries, &r,
+                                             nullptr);
+            if (rc == CSVSIMD_ERR_TAPE_CAPACITY) {
+                rc = ensure_tape(r.count);
+                if (rc != CSVSIMD_OK) return rc;
+                rc = csvsimd_stage1_index_device(ctx, ctx->d_in, clen, off, inq, ctx->d_tape, ctx->d_tape_entries,
+                                                 &r, nullptr);
+            }
+            if (rc != CSVSIMD_OK) return rc;
+            if (n < tape_cap) {
+                const uint64_t room = tape_cap - n;
+                const uint64_t ncopy = std::min<uint64_t>(room, r.count);
+                if (ncopy) HIP_TRY(hipMemcpy(tape + n, ctx->d_tape, ncopy * 8, hipMemcpyDeviceToHost));
+            }
+        }
+        n += r.count;
+        inq = r.in_quote_out;
+    }
+    *tape_len = n;
+    if (in_quote_out) *in_quote_out = inq;
+    if (tape && n > tape_cap) return CSVSIMD_ERR_TAPE_CAPACITY;
+    return CSVSIMD_OK;
+}
+
+int csvsimd_stitch_shards(const csvsimd_shard_result* results, uint32_t n_shards, uint32_t rank,
+                          uint32_t file_in_quote_in, csvsimd_stitch* out) {
+    if (!results || !out || rank >= n_shards) return CSVSIMD_ERR_INVALID_ARG;
+    uint32_t state = file_in_quote_in ? 1u : 0u;
+    uint64_t idx = 1;  // the sentinel occupies global index 0
+    for (uint32_t i = 0; i < n_shards; ++i) {
+        const uint64_t cnt = state ? results[i].count_enter_inside : results[i].count_enter_outside;
+        if (i == rank) {
+            out->in_quote_in = state;
+            out->count = cnt;
+            out->tape_index_base = idx;
+        }
+        idx += cnt;
+        state ^= results[i].quote_parity & 1u;
+    }
+    out->in_quote_final = state;
+    out->total_entries = idx;
+    return CSVSIMD_OK;
+}
+
+/* ---- tape --------------------------------------------------------------------------------- */
+
+}  // extern "C"
+
+struct csvsimd_tape {
+    csv_simd::Tape tape;
+    // owned storage when built by csvsimd_create
+    void* map = nullptr;
+    uint64_t map_len = 0;
+    std::vector<uint64_t> owned_index;
+};
+
+extern "C" {
+
+int csvsimd_tape_create(const uint8_t* bytes, uint64_t len, const uint64_t* index, uint64_t index_len,
+                        csvsimd_tape** out) {
+    if (!bytes || !index || !out) return CSVSIMD_ERR_INVALID_ARG;
+    *out = nullptr;
+    csv_simd::Header h;
+    csv_simd::StructureError e = csv_simd::Header::create(bytes, len, h);
+    if (e != csv_simd::StructureError::Ok) return (int)e;
+    std::unique_ptr<csvsimd_tape> t(new (std::nothrow) csvsimd_tape);
+    if (!t) return CSVSIMD_ERR_INVALID_STATE;
+    e = csv_simd::Tape::from_core(bytes, len, csv_simd::StructureIndex{index, index_len}, std::move(h), t->tape);
+    if (e != csv_simd::StructureError::Ok) return (int)e;
+    *out = t.release();
+    return CSVSIMD_OK;
+}
+
+void csvsimd_tape_destroy(csvsimd_tape* t) {
+    if (!t) return;
+    if (t->map) munmap(t->map, t->map_len);
+    delete t;
+}
+
+uint32_t csvsimd_tape_field_cnt(const csvsimd_tape* t) { return t->tape.header.field_cnt; }
+uint32_t csvsimd_tape_record_cnt(const csvsimd_tape* t) { return t->tape.record_cnt_; }
+uint64_t csvsimd_tape_record_jump_size(const csvsimd_tape* t) { return t->tape.record_jump_size_; }
+uint32_t csvsimd_tape_record_offset(const csvsimd_tape* t) { return t->tape.header.record_offset; }
+int csvsimd_tape_new_line(const csvsimd_tape* t) {
+    return t->tape.header.new_line == csv_simd::NewLine::CRLF ? CSVSIMD_NEWLINE_CRLF : CSVSIMD_NEWLINE_LF;
+}
+
+int64_t csvsimd_tape_header_name(const csvsimd_tape* t, uint32_t i, char* dst, uint64_t cap) {
+    if (!t || i >= t->tape.header.header.size()) return CSVSIMD_ERR_INVALID_ARG;
+    const std::string& s = t->tape.header.header[i];
+    if (dst && cap) memcpy(dst, s.data(), std::min<uint64_t>(cap, s.size()));
+    return (int64_t)s.size();
+}
+
+int csvsimd_tape_seek_record(const csvsimd_tape* t, uint32_t record_idx, uint64_t* begin, uint64_t* end, int* found) {
+    if (!t || !begin || !end || !found) return CSVSIMD_ERR_INVALID_ARG;
+    std::optional<std::pair<uint64_t, uint64_t>> span;
+    const auto e = csv_simd::RecordSource<csv_simd::Tape>::seek_record(t->tape, record_idx, span);
+    if (e != csv_simd::StructureError::Ok) return (int)e;
+    *found = span ? 1 : 0;
+    if (span) { *begin = span->first; *end = span->second; }
+    return CSVSIMD_OK;
+}
+
+int csvsimd_tape_seek_field(const csvsimd_tape* t, uint32_t record_idx, uint32_t field_idx, uint64_t* begin,
+                            uint64_t* end, int* found) {
+    if (!t || !begin || !end || !found) return CSVSIMD_ERR_INVALID_ARG;
+    std::optional<std::pair<uint64_t, uint64_t>> span;
+    const auto e = csv_simd::RecordSource<csv_simd::Tape>::seek_field(t->tape, record_idx, field_idx, span);
+    if (e != csv_simd::StructureError::Ok) return (int)e;
+    *found = span ? 1 : 0;
+    if (span) { *begin = span->first; *end = span->second; }
+    return CSVSIMD_OK;
+}
+
+int csvsimd_boundaries(uint32_t task_size, uint8_t job_count, csvsimd_boundary* out, uint32_t* n_out) {
+    if (!out || !n_out) return CSVSIMD_ERR_INVALID_ARG;
+    const auto b = csv_simd::boundaries(task_size, job_count);
+    if (!b) return CSVSIMD_ERR_INVALID_STATE;
+    *n_out = (uint32_t)b->size();
+    for (size_t i = 0; i < b->size(); ++i) out[i] = csvsimd_boundary{(*b)[i].start, (*b)[i].len};
+    return CSVSIMD_OK;
+}
+
+int csvsimd_tape_chunks(const csvsimd_tape* t, uint8_t num, csvsimd_chunk* out, uint32_t* n_out) {
+    if (!t || !out || !n_out) return CSVSIMD_ERR_INVALID_ARG;
+    std::vector<csv_simd::Chunk> c;
+    const auto e = t->tape.chunks(num, c);
+    if (e != csv_simd::StructureError::Ok) return (int)e;
+    *n_out = (uint32_t)c.size();
+    for (size_t i = 0; i < c.size(); ++i) out[i] = csvsimd_chunk{c[i].id, c[i].start, c[i].end, c[i].record_cnt};
+    return CSVSIMD_OK;
+}
+
+const uint64_t* csvsimd_tape_index(const csvsimd_tape* t, uint64_t* index_len) {
+    if (index_len) *index_len = t->tape.index().len();
+    return t->tape.index().data;
+}
+const uint8_t* csvsimd_tape_bytes(const csvsimd_tape* t, uint64_t* len) {
+    if (len) *len = t->tape.data_len();
+    return t->tape.data_bytes();
+}
+
+// csv_simd::create (src/lib.rs:61-74): open, mmap, Header::new, reader::read (GPU), tape
+int csvsimd_create(csvsimd_ctx* ctx, const char* filename, csvsimd_tape** out) {
+    if (!ctx || !filename || !out) return CSVSIMD_ERR_INVALID_ARG;
+    *out = nullptr;
+    const int fd = open(filename, O_RDONLY);
+    if (fd < 0) { g_last_error = std::string("open: ") + strerror(errno); return CSVSIMD_ERR_IO; }
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); return CSVSIMD_ERR_IO; }
+    const uint64_t len = (uint64_t)st.st_size;
+    if (len == 0) { close(fd); return CSVSIMD_ERR_IO; }  // memmap refuses empty files too
+    void* map = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (map == MAP_FAILED) { g_last_error = std::string("mmap: ") + strerror(errno); return CSVSIMD_ERR_IO; }
+    std::unique_ptr<csvsimd_tape> t(new (std::nothrow) csvsimd_tape);
+    if (!t) { munmap(map, len); return CSVSIMD_ERR_INVALID_STATE; }
+    t->map = map;
+    t->map_len = len;
+    const uint8_t* bytes = (const uint8_t*)map;
+    csv_simd::Header h;
+    csv_simd::StructureError e = csv_simd::Header::create(bytes, len, h);
+    if (e != csv_simd::StructureError::Ok) return (int)e;
+    // count-only pass sizes the index exactly, then the emitting pass fills it
+    uint64_t n = 0;
+    int rc = csvsimd_stage1_index(ctx, bytes, len, nullptr, 0, &n, nullptr);
+    if (rc != CSVSIMD_OK) return rc;
+    t->owned_index.resize(n);
+    rc = csvsimd_stage1_index(ctx, bytes, len, t->owned_index.data(), n, &n, nullptr);
+    if (rc != CSVSIMD_OK) return rc;
+    e = csv_simd::Tape::from_core(bytes, len, csv_simd::StructureIndex{t->owned_index.data(), n}, std::move(h),
+                                  t->tape);
+    if (e != csv_simd::StructureError::Ok) return (int)e;
+    *out = t.release();
+    return CSVSIMD_OK;
+}
+
+/* ---- utilities ------------------------------------------------------------------------------ */
+
+int csvsimd_synth_fill_device(void* dbuf, uint64_t file_off, uint64_t len, uint32_t cols, uint32_t width,
+                              uint64_t seed, uint32_t quote_pct, void* hip_stream) {
+    if ((len && !dbuf) || cols == 0 || width == 0 || ((uintptr_t)dbuf & 3)) return CSVSIMD_ERR_INVALID_ARG;
+    if (csvsimd_device_count() <= 0) return CSVSIMD_ERR_NO_DEVICE;
+    HIP_TRY(csvsimd::launch_synth(dbuf, file_off, len, cols, width, seed, quote_pct, (hipStream_t)hip_stream));
+    return CSVSIMD_OK;
+}
+
+int csvsimd_tape_checksum_device(const void* dtape, uint64_t n, uint64_t first_index, void* d_out,
+                                 void* hip_stream) {
+    if ((n && !dtape) || !d_out) return CSVSIMD_ERR_INVALID_ARG;
+    if (csvsimd_device_count() <= 0) return CSVSIMD_ERR_NO_DEVICE;
+    HIP_TRY(csvsimd::launch_checksum(dtape, n, first_index, d_out, (hipStream_t)hip_stream));
+    return CSVSIMD_OK;
+}
+
+int csvsimd_selftest_device(int device) {
+    const int n = csvsimd_device_count();
+    if (n <= 0) return CSVSIMD_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return CSVSIMD_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(device));
+    uint32_t* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, 8));
+    HIP_TRY(hipMemset(d, 0, 8));
+    hipError_t e = csvsimd::launch_selftest(d, nullptr);
+    uint32_t h[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpy(h, d, 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail_hip(e, "selftest");
+    if (h[0] || h[1]) {
+        char buf[96];
+        snprintf(buf, sizeof buf, "wavefront self-test failed: bits 0x%x / 0x%x", h[0], h[1]);
+        g_last_error = buf;
+        return CSVSIMD_ERR_INTERNAL;
+    }
+    return CSVSIMD_OK;
+}
+
+int csvsimd_stage1_time_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len, void* dtape, uint64_t tape_cap,
+                               void* d_result, void* hip_stream, int warmup, int iters, float* avg_ms) {
+    if (!ctx || !avg_ms || iters <= 0 || iters > 4096 || !d_result || !len) return CSVSIMD_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)hip_stream;
+    int rc = csvsimd_ctx_reserve(ctx, len);
+    if (rc != CSVSIMD_OK) return rc;
+    csvsimd::Stage1Launch L;
+    L.dbuf = dbuf;
+    L.len = len;
+    L.base_off = 0;
+    L.in_quote_in = 0;
+    L.dtape = dtape;
+    L.tape_cap = tape_cap;
+    L.d_result = (csvsimd_shard_result*)d_result;
+    L.bind_scratch(ctx->scratch);
+    L.max_blocks = ctx->max_blocks;
+    for (int i = 0; i < warmup; ++i) HIP_TRY(csvsimd::launch_stage1(L, s));
+    // one event pair per launch, recorded on the launch stream right around the stage-1 kernel
+    // (the memsets before it and the 1-wave finalize after it are outside the pair)
+    std::vector<hipEvent_t> ev(2 * (size_t)iters);
+    for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+    for (int i = 0; i < iters; ++i) {
+        L.ev_begin = ev[2 * i];
+        L.ev_end = ev[2 * i + 1];
+        HIP_TRY(csvsimd::launch_stage1(L, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    double total = 0;
+    for (int i = 0; i < iters; ++i) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+        total += ms;
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    *avg_ms = (float)(total / iters);
+    return CSVSIMD_OK;
+}
+
+}  // extern "C"

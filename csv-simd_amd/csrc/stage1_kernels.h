@@ -1,0 +1,56 @@
+// stage1_kernels.h — internal C++ interface between the C ABI (capi.cpp) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "csvsimd.h"
+
+#define CSVSIMD_TILE_BYTES (128 * 1024)
+
+namespace csvsimd {
+
+// scratch block layout (one hipMemsetAsync zeroes the used prefix before every launch):
+//   [0, 16)            ticket counter (u32) + padding
+//   [16, 16 + 512)     64 sharded u64 counters: total comma/CR/LF bytes
+//   [528, ...)         one u64 look-back descriptor per tile
+struct Stage1Launch {
+    const void* dbuf;
+    uint64_t len;
+    uint64_t base_off;
+    uint32_t in_quote_in;
+    void* dtape;
+    uint64_t tape_cap;
+    csvsimd_shard_result* d_result;
+    void* scratch_base;
+    uint32_t* scratch_ticket;
+    uint64_t* scratch_tot;
+    uint64_t* scratch_desc;
+    uint32_t max_blocks;
+    // optional: recorded immediately around the stage-1 kernel itself (bench roofline leg)
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+
+    static uint64_t scratch_bytes_for(uint64_t len) {
+        // + 1 tile: an unaligned dbuf shifts the data by up to 15 bytes
+        const uint64_t tiles = (len + 15 + CSVSIMD_TILE_BYTES - 1) / CSVSIMD_TILE_BYTES + 1;
+        return 528 + 8 * tiles + 16;
+    }
+    uint64_t scratch_zero_bytes(uint32_t num_tiles) const {
+        return (528 + 8 * (uint64_t)num_tiles + 15) & ~15ull;
+    }
+    void bind_scratch(void* base) {
+        scratch_base = base;
+        scratch_ticket = reinterpret_cast<uint32_t*>(base);
+        scratch_tot = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(base) + 16);
+        scratch_desc = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(base) + 528);
+    }
+};
+
+hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream);
+hipError_t launch_synth(void* dbuf, uint64_t file_off, uint64_t len, uint32_t cols, uint32_t width,
+                        uint64_t seed, uint32_t quote_pct, hipStream_t stream);
+hipError_t launch_checksum(const void* dtape, uint64_t n, uint64_t first_index, void* d_out,
+                           hipStream_t stream);
+hipError_t launch_selftest(uint32_t* d_out, hipStream_t stream);
+int stage1_max_blocks_per_cu();
+
+}  // namespace csvsimd

@@ -1,0 +1,185 @@
+/*
+ * csvsimd.h — C ABI of libcsvsimd_hip.so: MI355X (gfx950) stage-1 CSV structural indexer.
+ *
+ * Drop-in boundary for the reference crate's stage 1.  The reference has no FFI of its own; its
+ * seam is the Rust function
+ *
+ *     pub fn read(memmap: &Mmap) -> StructureIndex            (reference src/reader.rs:150)
+ *
+ * parameterised per ISA by `trait Stage1<T>` (src/stage1.rs:156-167), called from
+ * `csv_simd::create` (src/lib.rs:61-74) which then builds `TapeCore`/`Tape`
+ * (src/tape.rs:303-347, 83-94).  Every entry point below cites the reference interface it
+ * replaces.  INTEGRATION.md shows the ~30-line Rust `extern "C"` binding that swaps
+ * `reader::read` for `csvsimd_stage1_index`.
+ *
+ * Conventions: plain pointers and sizes; caller allocates and frees every buffer; no callbacks;
+ * thread-safe for distinct contexts; all functions return 0 or a negative CSVSIMD_ERR_* code.
+ * There is NO CPU fallback: without a HIP device every compute entry point fails with
+ * CSVSIMD_ERR_NO_DEVICE.
+ */
+#ifndef CSVSIMD_H
+#define CSVSIMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes: -1..-4 mirror reference StructureError (src/error.rs:7-21) ------------- */
+#define CSVSIMD_OK 0
+#define CSVSIMD_ERR_IO (-1)                 /* StructureError::Io               */
+#define CSVSIMD_ERR_MISSING_VALUE (-2)      /* StructureError::MissingValue     */
+#define CSVSIMD_ERR_INVALID_STATE (-3)      /* StructureError::InvalidState     */
+#define CSVSIMD_ERR_INVALID_CSV_FORMAT (-4) /* StructureError::InvalidCsvFormat */
+#define CSVSIMD_ERR_INVALID_ARG (-9)
+#define CSVSIMD_ERR_TAPE_CAPACITY (-11) /* tape_cap too small; *tape_len holds the needed size */
+#define CSVSIMD_ERR_HIP (-12)           /* HIP runtime error: csvsimd_last_error() has the text */
+#define CSVSIMD_ERR_NO_DEVICE (-13)
+#define CSVSIMD_ERR_INTERNAL (-14) /* in-kernel look-back spin bound hit (should never happen) */
+
+const char* csvsimd_strerror(int code);
+const char* csvsimd_last_error(void); /* thread-local text of the last HIP failure */
+int csvsimd_device_count(void);       /* number of HIP devices visible, 0 if none */
+uint32_t csvsimd_abi_version(void);
+
+/* ---- context: one per (thread, device); owns the look-back scratch ------------------------ */
+typedef struct csvsimd_ctx csvsimd_ctx;
+int csvsimd_ctx_create(int device, csvsimd_ctx** out);
+void csvsimd_ctx_destroy(csvsimd_ctx* ctx);
+
+/* What one stage-1 pass over a shard reports (device- or host-resident, 64 bytes).
+ * (quote_parity, count_enter_outside, count_enter_inside) is the composable shard descriptor
+ * of SURVEY.md §8e; the reference carries the same two quantities between 64-byte blocks as
+ * `inside_str` and `array_idx` (src/reader.rs:217-218). */
+typedef struct csvsimd_shard_result {
+    uint64_t count;               /* structural entries for the in_quote_in that was passed  */
+    uint64_t count_enter_outside; /* ... had the shard been entered outside a quoted string   */
+    uint64_t count_enter_inside;  /* ... had it been entered inside one                       */
+    uint32_t quote_parity;        /* number of '"' bytes in the shard, mod 2                  */
+    uint32_t in_quote_out;        /* in_quote_in ^ quote_parity                               */
+    uint32_t error;               /* 0, or CSVSIMD_ERR_INTERNAL's in-kernel flag              */
+    uint32_t reserved0;
+    uint64_t written;             /* min(count, tape_cap): entries actually stored            */
+    uint64_t reserved1[2];
+} csvsimd_shard_result;
+
+/* ---- stage 1, device-resident (the timed path) ---------------------------------------------
+ * Replaces the hot loop of reader::read (src/reader.rs:229-290) = SimdInput::structure
+ * (src/avx/stage1.rs:193-430) + Stage1::crush_set_bits (src/stage1.rs:162-296) for the bytes
+ * dbuf[0..len): writes, ascending, base_off + i for every i with dbuf[i] in {',', CR, LF} and
+ * an even number of '"' at positions <= i (counting in_quote_in as one earlier quote), as
+ * uint64_t (reference CodeUnitPos(usize), src/stage1.rs:67) to dtape[0..min(count,tape_cap)).
+ * No sentinel is written here (the reference's leading 0, src/reader.rs:216, belongs to the
+ * whole file, not to a shard).  dtape may be NULL with tape_cap 0 for a count-only pass.
+ * Asynchronous on hip_stream (a hipStream_t, NULL = default stream); d_result is DEVICE memory
+ * (>= sizeof(csvsimd_shard_result), 8-byte aligned), valid once the stream has drained.  No
+ * allocation and no synchronisation happens inside as long as the context scratch is large
+ * enough for len (grow it up front with csvsimd_ctx_reserve), so the call may be captured
+ * into a hipGraph.  Any dbuf alignment is accepted; 16-byte alignment is fastest. */
+int csvsimd_ctx_reserve(csvsimd_ctx* ctx, uint64_t max_len);
+int csvsimd_stage1_index_device_async(csvsimd_ctx* ctx, const void* dbuf, uint64_t len,
+                                      uint64_t base_off, uint32_t in_quote_in, void* dtape,
+                                      uint64_t tape_cap, void* d_result, void* hip_stream);
+/* Same, synchronous, result copied to host. Returns CSVSIMD_ERR_TAPE_CAPACITY if
+ * count > tape_cap and dtape != NULL (result still filled). */
+int csvsimd_stage1_index_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len,
+                                uint64_t base_off, uint32_t in_quote_in, void* dtape,
+                                uint64_t tape_cap, csvsimd_shard_result* result, void* hip_stream);
+
+/* ---- stage 1, host buffer: the drop-in for `reader::read(&Mmap) -> StructureIndex` -----------
+ * (src/reader.rs:150).  buf = the mmap; tape = caller-owned uint64_t[tape_cap]; on return
+ * tape[0] = 0 (sentinel, src/reader.rs:216) followed by every structural offset relative to
+ * buf[0]; *tape_len = entries including the sentinel (== StructureIndex.len()).
+ * csvsimd_stage1_bound gives a capacity that can never be exceeded (len + 1).  If tape_cap is
+ * too small nothing past it is written, *tape_len holds the exact size needed and the call
+ * returns CSVSIMD_ERR_TAPE_CAPACITY (retry once).  tape == NULL, tape_cap == 0 is a count-only
+ * call.  Streams the file through pinned staging in chunks; accepts any len >= 0 (the reference
+ * itself is only defined for len >= 64). */
+int csvsimd_stage1_bound(uint64_t len, uint64_t* max_entries);
+int csvsimd_stage1_index(csvsimd_ctx* ctx, const uint8_t* buf, uint64_t len, uint64_t* tape,
+                         uint64_t tape_cap, uint64_t* tape_len, uint32_t* in_quote_out);
+
+/* ---- multi-GPU stitch (host arithmetic; the exchange itself is one all-gather of these
+ * descriptors over RCCL, done by the caller's communicator) -----------------------------------
+ * New relative to the reference (single-threaded; README.md:24 lists it as a TODO).  Given the
+ * per-shard results of a speculative pass (in_quote_in = 0) in rank order, computes for shard
+ * `rank` its true entering state and the global tape index of its first entry (sentinel
+ * included), plus the whole-file totals. */
+typedef struct csvsimd_stitch {
+    uint32_t in_quote_in;      /* entering state of this shard                          */
+    uint32_t in_quote_final;   /* state after the last shard                            */
+    uint64_t count;            /* this shard's entry count under its true entering state */
+    uint64_t tape_index_base;  /* global index of this shard's first entry (>= 1)       */
+    uint64_t total_entries;    /* whole file, sentinel included                         */
+} csvsimd_stitch;
+int csvsimd_stitch_shards(const csvsimd_shard_result* results, uint32_t n_shards, uint32_t rank,
+                          uint32_t file_in_quote_in, csvsimd_stitch* out);
+
+/* ---- tape: host-side, after stage 1 (reference src/tape.rs, src/record_source.rs) ------------ */
+typedef struct csvsimd_tape csvsimd_tape;
+#define CSVSIMD_NEWLINE_LF 0   /* NewLine::LF   (src/stage1.rs:470-480) */
+#define CSVSIMD_NEWLINE_CRLF 1 /* NewLine::CRLF */
+
+/* Header::new (src/tape.rs:226-273) + TapeCore::create/init + Tape::from_core
+ * (src/tape.rs:303-347, 83-94).  Borrows bytes and index (they must outlive the tape).
+ * Fails with CSVSIMD_ERR_INVALID_CSV_FORMAT when (index_len-1) % jump != 0. */
+int csvsimd_tape_create(const uint8_t* bytes, uint64_t len, const uint64_t* index,
+                        uint64_t index_len, csvsimd_tape** out);
+void csvsimd_tape_destroy(csvsimd_tape* t);
+uint32_t csvsimd_tape_field_cnt(const csvsimd_tape* t);        /* Header.field_cnt      */
+uint32_t csvsimd_tape_record_cnt(const csvsimd_tape* t);       /* Tape.record_cnt (u32) */
+uint64_t csvsimd_tape_record_jump_size(const csvsimd_tape* t); /* Tape.record_jump_size */
+uint32_t csvsimd_tape_record_offset(const csvsimd_tape* t);    /* Header.record_offset  */
+int csvsimd_tape_new_line(const csvsimd_tape* t);              /* CSVSIMD_NEWLINE_*     */
+/* header name i, trimmed (src/tape.rs:259-262); returns length, copies <= cap bytes */
+int64_t csvsimd_tape_header_name(const csvsimd_tape* t, uint32_t i, char* dst, uint64_t cap);
+/* RecordSource::seek_record / seek_field (src/record_source.rs:70-140): [begin, end) delimit
+ * the field/record text in bytes; found == 0 mirrors Ok(None). */
+int csvsimd_tape_seek_record(const csvsimd_tape* t, uint32_t record_idx, uint64_t* begin,
+                             uint64_t* end, int* found);
+int csvsimd_tape_seek_field(const csvsimd_tape* t, uint32_t record_idx, uint32_t field_idx,
+                            uint64_t* begin, uint64_t* end, int* found);
+/* boundaries(task_size, job_count) (src/tape.rs:385-428): writes <= job_count (start,len)
+ * pairs, *n_out = how many; task_size == 0 or job_count == 0 -> CSVSIMD_ERR_INVALID_STATE
+ * (the reference returns None, which Tape::chunks maps to InvalidState, src/tape.rs:99-100). */
+typedef struct csvsimd_boundary {
+    uint64_t start, len;
+} csvsimd_boundary;
+int csvsimd_boundaries(uint32_t task_size, uint8_t job_count, csvsimd_boundary* out,
+                       uint32_t* n_out);
+/* Tape::chunks(num) (src/tape.rs:95-140): (id, start, end, record_cnt) in index-key units */
+typedef struct csvsimd_chunk {
+    uint8_t id;
+    uint64_t start, end; /* KeyToPos */
+    uint32_t record_cnt;
+} csvsimd_chunk;
+int csvsimd_tape_chunks(const csvsimd_tape* t, uint8_t num, csvsimd_chunk* out, uint32_t* n_out);
+
+/* csv_simd::create(filename) (src/lib.rs:61-74): open + mmap + Header::new + stage 1 on the
+ * GPU + tape.  The returned tape owns the mapping and the index. */
+int csvsimd_create(csvsimd_ctx* ctx, const char* filename, csvsimd_tape** out);
+const uint64_t* csvsimd_tape_index(const csvsimd_tape* t, uint64_t* index_len);
+const uint8_t* csvsimd_tape_bytes(const csvsimd_tape* t, uint64_t* len);
+
+/* ---- utilities used by the bench / tests (device-side, no reference counterpart) ------------- */
+/* Synthetic corpus bytes [file_off, file_off+len) of the cols x width shape. */
+int csvsimd_synth_fill_device(void* dbuf, uint64_t file_off, uint64_t len, uint32_t cols,
+                              uint32_t width, uint64_t seed, uint32_t quote_pct, void* hip_stream);
+/* Order-sensitive checksum of dtape[0..n) whose first element has global index first_index;
+ * d_out = device uint64_t[2] (accumulated into: zero it first). */
+int csvsimd_tape_checksum_device(const void* dtape, uint64_t n, uint64_t first_index, void* d_out,
+                                 void* hip_stream);
+/* Wavefront-primitive self test (DPP scans, ballots, ordered descriptor reduction). */
+int csvsimd_selftest_device(int device);
+/* Average duration in ms of `iters` back-to-back stage-1 launches measured with hipEvents on
+ * hip_stream itself (bench.py's roofline leg: torch events only see torch's own stream). */
+int csvsimd_stage1_time_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len, void* dtape,
+                               uint64_t tape_cap, void* d_result, void* hip_stream, int warmup,
+                               int iters, float* avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSVSIMD_H */

@@ -1,0 +1,45 @@
+/*
+ * oracle.h — CPU restatement of the reference's stage 1.  TEST INFRASTRUCTURE ONLY: see oracle.c.
+ * Nothing under csv-simd_amd/ may include this header.
+ */
+#ifndef CSVSIMD_ORACLE_H
+#define CSVSIMD_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORACLE_ERR_CAPACITY (-11)
+
+/* class byte of the reference's nibble tables (src/stage1.rs:23-48) */
+uint8_t oracle_byte_class(uint8_t b);
+
+/* scalar definition; offsets = base_off + i; no sentinel */
+int oracle_scalar_index(const uint8_t* buf, uint64_t len, uint64_t base_off, uint32_t in_quote_in,
+                        uint64_t* tape, uint64_t cap, uint64_t* n_out, uint32_t* in_quote_out);
+/* scalar definition with the reference's layout: tape[0] = 0 sentinel (src/reader.rs:216) */
+int oracle_scalar_read(const uint8_t* buf, uint64_t len, uint64_t* tape, uint64_t cap,
+                       uint64_t* n_out);
+/* (parity, count if the shard is entered outside a string, count if entered inside) */
+void oracle_shard_descriptor(const uint8_t* buf, uint64_t len, uint32_t* parity,
+                             uint64_t* cnt_enter_outside, uint64_t* cnt_enter_inside);
+
+/* faithful SSE restatement of reader::read (src/reader.rs:150-306); cap >= n + 64 */
+int oracle_sse_read(const uint8_t* buf, uint64_t len, uint64_t* tape, uint64_t cap,
+                    uint64_t* n_out);
+/* same, output in a Vec-like growing buffer (the timed "ref_sse_1t" baseline); oracle_free it */
+int oracle_sse_read_growing(const uint8_t* buf, uint64_t len, uint64_t** tape_out, uint64_t* n_out);
+void oracle_free(void* p);
+
+/* order-sensitive checksum of tape[0..n) whose first element has global index first_index */
+void oracle_tape_checksum(const uint64_t* tape, uint64_t n, uint64_t first_index, uint64_t* s1,
+                          uint64_t* s2);
+
+/* synthetic corpus bytes [file_off, file_off+len) of the (cols x width) shape, SURVEY.md §8d */
+void oracle_synth_fill(uint8_t* dst, uint64_t file_off, uint64_t len, uint32_t cols,
+                       uint32_t width, uint64_t seed, uint32_t quote_pct);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

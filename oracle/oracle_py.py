@@ -1,0 +1,120 @@
+"""ctypes loader for oracle/liboracle.so — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module, and
+only as the checker / CPU baseline.  Nothing under csv-simd_amd/ imports it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_u8p, _u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint64)
+_lib = None
+
+
+def build() -> None:
+    subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        h = C.CDLL(LIB_PATH)
+        h.oracle_byte_class.restype, h.oracle_byte_class.argtypes = C.c_uint8, [C.c_uint8]
+        h.oracle_scalar_index.restype = C.c_int
+        h.oracle_scalar_index.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64,
+                                          _u64p, C.POINTER(C.c_uint32)]
+        h.oracle_scalar_read.restype = C.c_int
+        h.oracle_scalar_read.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, _u64p]
+        h.oracle_shard_descriptor.restype = None
+        h.oracle_shard_descriptor.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32), _u64p, _u64p]
+        h.oracle_sse_read.restype = C.c_int
+        h.oracle_sse_read.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, _u64p]
+        h.oracle_sse_read_growing.restype = C.c_int
+        h.oracle_sse_read_growing.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(_u64p), _u64p]
+        h.oracle_free.restype, h.oracle_free.argtypes = None, [C.c_void_p]
+        h.oracle_tape_checksum.restype = None
+        h.oracle_tape_checksum.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, _u64p, _u64p]
+        h.oracle_synth_fill.restype = None
+        h.oracle_synth_fill.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64,
+                                        C.c_uint32]
+        _lib = h
+    return _lib
+
+
+def aligned_copy(data, align: int = 64, head: int = 0) -> np.ndarray:
+    """uint8 view whose address is `head` bytes past an `align` boundary (mmap-like when head=0)."""
+    b = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    raw = np.zeros(b.size + 2 * align + head, dtype=np.uint8)
+    off = (-raw.ctypes.data) % align + head
+    a = raw[off: off + b.size]
+    a[:] = b
+    return a
+
+
+def scalar_read(data) -> np.ndarray:
+    a = aligned_copy(data)
+    out = np.zeros(a.size + 2, dtype=np.uint64)
+    n = C.c_uint64()
+    rc = lib().oracle_scalar_read(a.ctypes.data, a.size, out.ctypes.data, out.size, C.byref(n))
+    assert rc == 0
+    return out[: n.value].copy()
+
+
+def scalar_index(data, base_off: int = 0, in_quote_in: int = 0):
+    """-> (entries uint64[], in_quote_out) without sentinel."""
+    a = data if isinstance(data, np.ndarray) else np.frombuffer(bytes(data), dtype=np.uint8)
+    a = np.ascontiguousarray(a)
+    out = np.zeros(a.size + 1, dtype=np.uint64)
+    n, q = C.c_uint64(), C.c_uint32()
+    rc = lib().oracle_scalar_index(a.ctypes.data, a.size, base_off, in_quote_in, out.ctypes.data, out.size,
+                                   C.byref(n), C.byref(q))
+    assert rc == 0
+    return out[: n.value].copy(), q.value
+
+
+def sse_read(data, head: int = 0) -> np.ndarray:
+    a = aligned_copy(data, head=head)
+    out = np.zeros(a.size + 130, dtype=np.uint64)
+    n = C.c_uint64()
+    rc = lib().oracle_sse_read(a.ctypes.data, a.size, out.ctypes.data, out.size, C.byref(n))
+    assert rc == 0
+    return out[: n.value].copy()
+
+
+def sse_read_growing_timed(a: np.ndarray):
+    """Runs the Vec-growing restatement once; returns (n_entries, seconds)."""
+    import time
+    p, n = _u64p(), C.c_uint64()
+    t0 = time.perf_counter()
+    rc = lib().oracle_sse_read_growing(a.ctypes.data, a.size, C.byref(p), C.byref(n))
+    dt = time.perf_counter() - t0
+    assert rc == 0
+    lib().oracle_free(p)
+    return n.value, dt
+
+
+def shard_descriptor(data):
+    a = data if isinstance(data, np.ndarray) else np.frombuffer(bytes(data), dtype=np.uint8)
+    a = np.ascontiguousarray(a)
+    p, c0, c1 = C.c_uint32(), C.c_uint64(), C.c_uint64()
+    lib().oracle_shard_descriptor(a.ctypes.data, a.size, C.byref(p), C.byref(c0), C.byref(c1))
+    return p.value, c0.value, c1.value
+
+
+def tape_checksum(tape: np.ndarray, first_index: int = 0):
+    t = np.ascontiguousarray(tape, dtype=np.uint64)
+    s1, s2 = C.c_uint64(), C.c_uint64()
+    lib().oracle_tape_checksum(t.ctypes.data, t.size, first_index, C.byref(s1), C.byref(s2))
+    return s1.value, s2.value
+
+
+def synth(file_off: int, length: int, cols: int, width: int, seed: int, quote_pct: int = 0) -> np.ndarray:
+    out = aligned_copy(np.zeros(length, dtype=np.uint8))
+    lib().oracle_synth_fill(out.ctypes.data, file_off, length, cols, width, seed, quote_pct)
+    return out

@@ -1,0 +1,55 @@
+"""world_size-N gloo worker for test_sharded.py (CPU).  The shard pass is a stand-in backed by
+the oracle (allowed here: tests/ may use the oracle; the product path is GPU only) so that the
+N>1 control flow — speculative pass, one all-gather, stitch, conditional re-emit — is exercised
+exactly as bench.py / the GPU path drive it."""
+import os
+import sys
+
+import numpy as np
+
+
+def make_data(n, seed, p_quote):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from conftest import random_csvish
+    return random_csvish(np.random.default_rng(seed), n, p_quote)
+
+
+def worker(rank, world, port, n, seed, p_quote, skew, outdir):
+    import torch
+    import torch.distributed as dist
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    oracle = graft.load_oracle()
+    from csv_simd_amd import sharded
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        data = make_data(n, seed, p_quote)
+        lo, hi = sharded.shard_range(n, rank, world, align=64, skew=skew)
+        shard = data[lo:hi]
+        passes = []
+
+        def run_pass(in_quote_in):
+            entries, inq_out = oracle.scalar_index(shard, base_off=lo, in_quote_in=in_quote_in)
+            p, c0, c1 = oracle.shard_descriptor(shard)
+            r = pkg.ShardResult()
+            r.count, r.count_enter_outside, r.count_enter_inside = entries.size, c0, c1
+            r.quote_parity, r.in_quote_out = p, inq_out
+            passes.append(in_quote_in)
+            run_pass.entries = entries
+            return r
+
+        st, final, re_emitted = sharded.index_sharded(run_pass, torch.device("cpu"))
+        assert final.count == st.count
+        assert re_emitted == bool(st.in_quote_in) and passes == ([0, 1] if re_emitted else [0])
+        np.save(os.path.join(outdir, f"shard{rank}.npy"), run_pass.entries)
+        np.save(os.path.join(outdir, f"meta{rank}.npy"),
+                np.array([st.in_quote_in, st.tape_index_base, st.total_entries, st.in_quote_final, lo, hi],
+                         dtype=np.uint64))
+    finally:
+        dist.destroy_process_group()

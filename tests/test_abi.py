@@ -1,0 +1,61 @@
+"""The C-ABI library loads and exports every symbol include/csvsimd.h declares (CPU only: no
+compute call is made here).  Without a GPU every compute entry point must fail loudly."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "csvsimd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(csvsimd_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_all_exported(pkg):
+    so = pkg.LIB_PATH
+    nm = subprocess.run(["nm", "-D", "--defined-only", so], check=True, capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (csvsimd_[a-z0-9_]+)", nm))
+    declared = header_symbols()
+    assert len(declared) >= 30
+    missing = [s for s in declared if s not in exported]
+    assert not missing, missing
+    # and the Python binding knows each of them
+    assert sorted(pkg.EXPORTED_SYMBOLS) == declared
+    pkg.lib()  # resolves all prototypes
+
+
+def test_abi_version_and_strerror(pkg):
+    L = pkg.lib()
+    assert L.csvsimd_abi_version() == 1
+    assert L.csvsimd_strerror(-4).decode().startswith("Unsupported csv structure")  # src/error.rs:19
+    assert L.csvsimd_strerror(-3).decode() == "Invalid state"                          # src/error.rs:17
+    assert L.csvsimd_strerror(-2).decode() == "Missing a value"                        # src/error.rs:15
+
+
+def test_no_cpu_fallback(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the no-device path cannot be observed")
+    assert pkg.device_count() == 0
+    with pytest.raises(pkg.StructureError) as e:
+        pkg.Context(0)
+    assert e.value.code == pkg.ERR_NO_DEVICE
+    with pytest.raises(pkg.StructureError) as e:
+        pkg.selftest(0)
+    assert e.value.code == pkg.ERR_NO_DEVICE
+
+
+def test_product_never_touches_oracle():
+    # the product path must not import, link or call anything under oracle/
+    pkg_dir = os.path.join(ROOT, "csv-simd_amd")
+    for dirpath, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle" not in text.lower(), os.path.join(dirpath, f)
+    ldd = subprocess.run(["ldd", os.path.join(pkg_dir, "csrc", "libcsvsimd_hip.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in ldd

@@ -1,0 +1,278 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the oracle on the same
+bytes, against the committed golden vectors, and — at BASELINE.json's full sizes — through
+size-independent properties (analytic tape of the quote-free corpora, sortedness, split
+invariance, idempotence, order-sensitive checksums).  Bit-exact everywhere: this is integer work.
+"""
+import numpy as np
+import pytest
+
+from conftest import random_csvish
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def gpu_index(ctx, torch, host: np.ndarray, *, base_off=0, in_quote_in=0, misalign=0, cap=None):
+    """Runs the device entry point on a copy of `host` placed `misalign` bytes past an aligned
+    device address.  Returns (entries uint64[], ShardResult)."""
+    n = host.size
+    dbuf = torch.zeros(n + 64, dtype=torch.uint8, device="cuda:0")
+    if n:
+        dbuf[misalign: misalign + n] = torch.from_numpy(host)
+    # poison around the payload: stray reads of neighbouring bytes must not leak into the tape
+    dbuf[:misalign] = 0x2C
+    dbuf[misalign + n:] = 0x2C
+    cap = (n + 1) if cap is None else cap
+    dtape = torch.full((cap + 8,), -1, dtype=torch.int64, device="cuda:0")
+    r = ctx.stage1_index_device(dbuf.data_ptr() + misalign, n, base_off, in_quote_in, dtape.data_ptr(), cap,
+                                allow_overflow=True)
+    torch.cuda.synchronize()
+    assert (dtape[cap:] == -1).all(), "wrote past tape_cap"
+    k = min(r.count, cap)
+    assert r.written == k
+    assert (dtape[k:] == -1).all(), "wrote more entries than counted"
+    return dtape[:k].cpu().numpy().view(np.uint64), r
+
+
+def test_wavefront_selftest(pkg, torch_cuda):
+    pkg.selftest(0)
+
+
+@pytest.mark.parametrize("name", ["reader_test01.csv", "sample.csv", "sample_rx.csv"])
+def test_golden_fixtures_via_read(ctx, golden, oracle, name):
+    # drop-in entry point == reader::read (src/reader.rs:150) on the reference's own fixtures
+    data, exp = golden[name]
+    got = ctx.read(data)
+    assert np.array_equal(got, np.array(exp["index"], dtype=np.uint64))
+    assert np.array_equal(got, oracle.sse_read(data))
+    if name == "reader_test01.csv":  # the reference's own assertion, src/reader.rs:325-326
+        assert got[1] == 4 and got[-1] == 95
+
+
+def test_config1_sample_csv_to_tape(ctx, pkg, golden, tmp_path):
+    # BASELINE config 1: res/sample.csv -> stage 1 -> tape, end to end through csv_simd::create
+    data, exp = golden["sample.csv"]
+    p = tmp_path / "sample.csv"
+    p.write_bytes(data)
+    t = ctx.create(str(p))
+    assert np.array_equal(t.index(), np.array(exp["index"], dtype=np.uint64))
+    assert (t.field_cnt, t.record_cnt, t.record_jump_size, t.new_line) == (3, 15, 3, "LF")
+    assert t.header() == ["Name", "Number", "Done"] and t.seek_record(0) == b'Edm nd,3, "o"'
+    # ragged file -> InvalidCsvFormat, as the reference's TapeCore::init (src/tape.rs:342-344)
+    data2, _ = golden["reader_test01.csv"]
+    p2 = tmp_path / "ragged.csv"
+    p2.write_bytes(data2)
+    with pytest.raises(pkg.StructureError) as e:
+        ctx.create(str(p2))
+    assert e.value.code == pkg.ERR_INVALID_CSV_FORMAT
+    with pytest.raises(pkg.StructureError) as e:
+        ctx.create(str(tmp_path / "missing.csv"))
+    assert e.value.code == pkg.ERR_IO
+
+
+def test_random_small_all_residues(ctx, torch_cuda, oracle):
+    # every len % 64 and len % 16, empty input included
+    rng = np.random.default_rng(2024)
+    for n in list(range(0, 200)) + [255, 256, 257, 1023, 1024, 1025, 4095, 4096, 4097]:
+        d = random_csvish(rng, n, 0.1)
+        got, r = gpu_index(ctx, torch_cuda, d)
+        want, inq = oracle.scalar_index(d)
+        assert np.array_equal(got, want), n
+        assert (r.count, r.in_quote_out, r.error) == (want.size, inq, 0), n
+        p, c0, c1 = oracle.shard_descriptor(d)
+        assert (r.quote_parity, r.count_enter_outside, r.count_enter_inside) == (p, c0, c1), n
+        if n >= 64:  # the reference's defined domain: also equal to the SSE restatement
+            assert np.array_equal(np.concatenate([[0], got]).astype(np.uint64), oracle.sse_read(d)), n
+
+
+def test_misaligned_base_off_and_entering_state(ctx, torch_cuda, oracle):
+    rng = np.random.default_rng(77)
+    for n in (1, 15, 16, 17, 100, 5000, 131072 - 3, 131072 + 5):
+        d = random_csvish(rng, n, 0.05)
+        for mis in (0, 1, 7, 15):
+            for inq in (0, 1):
+                got, r = gpu_index(ctx, torch_cuda, d, base_off=10**12 + 3, in_quote_in=inq, misalign=mis)
+                want, q = oracle.scalar_index(d, base_off=10**12 + 3, in_quote_in=inq)
+                assert np.array_equal(got, want), (n, mis, inq)
+                assert r.in_quote_out == q and r.count == want.size
+
+
+def test_tile_boundaries_and_lookback(ctx, torch_cuda, pkg, oracle):
+    # sizes around multiples of the 128 KiB tile; quotes make the in-string state cross tiles
+    rng = np.random.default_rng(31337)
+    T = pkg.TILE_BYTES
+    for n in (T - 1, T, T + 1, 2 * T - 16, 2 * T + 16, 5 * T + 12345, 37 * T + 1):
+        for pq in (0.0, 0.001, 0.2):
+            d = random_csvish(rng, n, pq)
+            got, r = gpu_index(ctx, torch_cuda, d)
+            want, q = oracle.scalar_index(d)
+            assert r.count == want.size and r.in_quote_out == q, (n, pq)
+            assert np.array_equal(got, want), (n, pq)
+
+
+def test_adversarial_densities(ctx, torch_cuda, pkg, oracle):
+    T = pkg.TILE_BYTES
+    n = 3 * T + 1000
+    cases = {
+        "all_commas": np.full(n, 0x2C, dtype=np.uint8),           # 1 entry per byte: compaction windows
+        "all_quotes": np.full(n, 0x22, dtype=np.uint8),
+        "all_lf": np.full(n, 0x0A, dtype=np.uint8),
+        "no_struct": np.full(n, 0x61, dtype=np.uint8),
+        "high_bytes": np.tile(np.array([0xAC, 0x8A, 0x8D, 0xA2, 0x2C, 0xFF], dtype=np.uint8), n // 6 + 1)[:n],
+        "quote_comma": np.tile(np.frombuffer(b'",', dtype=np.uint8), n // 2 + 1)[:n],
+        "one_open_quote": np.concatenate([np.frombuffer(b'"', dtype=np.uint8), np.full(n - 1, 0x2C, dtype=np.uint8)]),
+        "crlf_rows": np.tile(np.frombuffer(b"ab,cd,ef\r\n", dtype=np.uint8), n // 10 + 1)[:n],
+    }
+    for name, d in cases.items():
+        got, r = gpu_index(ctx, torch_cuda, d)
+        want, q = oracle.scalar_index(d)
+        assert r.count == want.size and r.in_quote_out == q, name
+        assert np.array_equal(got, want), name
+
+
+def test_tape_capacity_and_count_only(ctx, torch_cuda, pkg, oracle):
+    rng = np.random.default_rng(8)
+    d = random_csvish(rng, 300000, 0.01)
+    want, q = oracle.scalar_index(d)
+    for cap in (0, 1, 1000, want.size - 1, want.size):
+        got, r = gpu_index(ctx, torch_cuda, d, cap=cap)
+        assert r.count == want.size and np.array_equal(got, want[:cap])
+    # count-only (dtape NULL)
+    dbuf = torch_cuda.from_numpy(d).cuda()
+    r = ctx.stage1_index_device(dbuf.data_ptr(), d.size)
+    assert (r.count, r.in_quote_out) == (want.size, q)
+    # host entry point: exact retry protocol of include/csvsimd.h
+    rc, n, _ = ctx.read_into(d, np.zeros(10, dtype=np.uint64))
+    assert rc == pkg.ERR_TAPE_CAPACITY and n == want.size + 1
+    tape = np.zeros(n, dtype=np.uint64)
+    rc, n2, q2 = ctx.read_into(d, tape)
+    assert rc == 0 and n2 == n and q2 == q and tape[0] == 0 and np.array_equal(tape[1:], want)
+
+
+def test_synth_generator_matches_oracle(ctx, torch_cuda, pkg, oracle):
+    for name, (cols, width, seed, q) in pkg.WORKLOADS.items():
+        for off, n in ((0, 100000), (123457, 70001)):
+            d = torch_cuda.empty(n + 3, dtype=torch_cuda.uint8, device="cuda:0")
+            pkg.synth_fill_device(d.data_ptr(), off, n, cols, width, seed, q)
+            assert np.array_equal(d[:n].cpu().numpy(), oracle.synth(off, n, cols, width, seed, q)), name
+
+
+def test_checksum_kernel_matches_oracle(ctx, torch_cuda, pkg, oracle):
+    rng = np.random.default_rng(3)
+    t = np.sort(rng.integers(0, 2**40, size=100003).astype(np.uint64))
+    dt = torch_cuda.from_numpy(t.view(np.int64)).cuda()
+    out = torch_cuda.zeros(2, dtype=torch_cuda.int64, device="cuda:0")
+    pkg.tape_checksum_device(dt.data_ptr(), t.size, 17, out.data_ptr())
+    got = tuple(int(x) & (2**64 - 1) for x in out.cpu().tolist())
+    assert got == oracle.tape_checksum(t, 17)
+
+
+def test_split_invariance_and_idempotence(ctx, torch_cuda, pkg, oracle):
+    # a shard cut anywhere, with the carried state, reproduces the single-pass tape
+    cols, width, seed, q = pkg.WORKLOADS["16x32_q10"]
+    n = 6 * 1024 * 1024 + 999
+    dbuf = torch_cuda.empty(n, dtype=torch_cuda.uint8, device="cuda:0")
+    pkg.synth_fill_device(dbuf.data_ptr(), 0, n, cols, width, seed, q)
+    cap = n // 16
+    full = torch_cuda.empty(cap, dtype=torch_cuda.int64, device="cuda:0")
+    r = ctx.stage1_index_device(dbuf.data_ptr(), n, 0, 0, full.data_ptr(), cap)
+    again = torch_cuda.empty(cap, dtype=torch_cuda.int64, device="cuda:0")
+    r2 = ctx.stage1_index_device(dbuf.data_ptr(), n, 0, 0, again.data_ptr(), cap)
+    assert r2.count == r.count and torch_cuda.equal(full[: r.count], again[: r.count])
+    want, _ = oracle.scalar_index(dbuf.cpu().numpy())
+    assert np.array_equal(full[: r.count].cpu().numpy().view(np.uint64), want)
+    for cut in (777, 2 * 1024 * 1024 + 777, n - 5):
+        a = torch_cuda.empty(cap, dtype=torch_cuda.int64, device="cuda:0")
+        b = torch_cuda.empty(cap, dtype=torch_cuda.int64, device="cuda:0")
+        ra = ctx.stage1_index_device(dbuf.data_ptr(), cut, 0, 0, a.data_ptr(), cap)
+        rb = ctx.stage1_index_device(dbuf.data_ptr() + cut, n - cut, cut, ra.in_quote_out, b.data_ptr(), cap)
+        assert ra.count + rb.count == r.count and rb.in_quote_out == r.in_quote_out
+        cat = torch_cuda.cat([a[: ra.count], b[: rb.count]])
+        assert torch_cuda.equal(cat, full[: r.count]), cut
+        # and the stitch arithmetic agrees with the carried run
+        spec = ctx.stage1_index_device(dbuf.data_ptr() + cut, n - cut, cut, 0)
+        st = pkg.stitch_shards([ra, spec], 1)
+        assert (st.in_quote_in, st.count, st.tape_index_base) == (ra.in_quote_out, rb.count, 1 + ra.count)
+
+
+# ---- BASELINE.json configs at full size ------------------------------------------------------------
+def run_workload(ctx, torch, pkg, name, target):
+    cols, width, seed, q = pkg.WORKLOADS[name]
+    n = pkg.workload_len(name, target)
+    dbuf = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    pkg.synth_fill_device(dbuf.data_ptr(), 0, n, cols, width, seed, q)
+    cap = n // (width + 1) + 16
+    dtape = torch.empty(cap, dtype=torch.int64, device="cuda:0")
+    r = ctx.stage1_index_device(dbuf.data_ptr(), n, 0, 0, dtape.data_ptr(), cap)
+    assert r.error == 0
+    return n, dbuf, dtape, r, (cols, width, seed, q)
+
+
+@pytest.mark.parametrize("name", ["16x32_noquote", "1024x4_dense", "64x31_noquote"])
+def test_full_size_noquote_analytic_tape(ctx, torch_cuda, pkg, oracle, name):
+    # configs 2, 5 and the 1-GPU shape of config 4 at 1 GiB: the tape of a quote-free corpus is
+    # known in closed form (every (width+1)-th byte), so the whole tape is checked bit for bit.
+    torch = torch_cuda
+    n, dbuf, dtape, r, (cols, width, seed, q) = run_workload(ctx, torch, pkg, name, 1 << 30)
+    S = n // (width + 1)
+    assert r.count == S and r.in_quote_out == 0 and r.quote_parity == 0
+    want = torch.arange(1, S + 1, dtype=torch.int64, device="cuda:0") * (width + 1) - 1
+    assert torch.equal(dtape[:S], want)
+    # oracle (the SSE restatement) on a 64 MiB window of the same bytes, entry by entry
+    win = 64 << 20
+    host = dbuf[:win].cpu().numpy()
+    o = oracle.sse_read(host)
+    assert np.array_equal(o[1:], dtape[: o.size - 1].cpu().numpy().view(np.uint64))
+    # checksum of checksums: device kernel == oracle formula on the analytic tape's first window
+    out = torch.zeros(2, dtype=torch.int64, device="cuda:0")
+    pkg.tape_checksum_device(dtape.data_ptr(), o.size - 1, 1, out.data_ptr())
+    assert tuple(int(x) & (2**64 - 1) for x in out.cpu().tolist()) == oracle.tape_checksum(o[1:], 1)
+
+
+def test_full_size_quoted_config3(ctx, torch_cuda, pkg, oracle):
+    # config 3: 1 GiB, 10 % quoted fields hiding ',' and LF: the quote-carry path end to end
+    torch = torch_cuda
+    n, dbuf, dtape, r, (cols, width, seed, q) = run_workload(ctx, torch, pkg, "16x32_q10", 1 << 30)
+    S = n // (width + 1)
+    assert r.count == S and r.in_quote_out == 0   # hidden delimiters are not counted
+    t = dtape[:S]
+    assert bool((t[1:] > t[:-1]).all())           # strictly ascending
+    b = dbuf[t]                                    # every entry points at a structural byte
+    assert bool(((b == 0x2C) | (b == 0x0A)).all())
+    rows = n // (cols * (width + 1))
+    assert int((b == 0x0A).sum()) == rows
+    # full compare with the oracle on the first 256 MiB (entry by entry) and a checksum on all of it
+    host = dbuf.cpu().numpy()
+    win = 256 << 20
+    o = oracle.sse_read(host[:win])
+    assert np.array_equal(o[1:], t[: o.size - 1].cpu().numpy().view(np.uint64))
+    want, inq = oracle.scalar_index(host)
+    assert want.size == S and inq == 0
+    out = torch.zeros(2, dtype=torch.int64, device="cuda:0")
+    pkg.tape_checksum_device(dtape.data_ptr(), S, 1, out.data_ptr())
+    assert tuple(int(x) & (2**64 - 1) for x in out.cpu().tolist()) == oracle.tape_checksum(want, 1)
+
+
+def test_config4_shard_8gib_analytic(ctx, torch_cuda, pkg):
+    # config 4's per-GPU shard: 8 GiB of the 64-col corpus taken from the MIDDLE of the 64 GiB
+    # file (rank 3 of 8), with the deliberately misaligned start (+777 bytes, mid-row).
+    torch = torch_cuda
+    cols, width, seed, q = pkg.WORKLOADS["64x31_noquote"]
+    shard = 1 << 33
+    lo = 3 * shard + 777
+    dbuf = torch.empty(shard, dtype=torch.uint8, device="cuda:0")
+    pkg.synth_fill_device(dbuf.data_ptr(), lo, shard, cols, width, seed, q)
+    first = lo // (width + 1) * (width + 1) + width  # first delimiter at or after lo
+    S = (lo + shard - 1 - first) // (width + 1) + 1
+    dtape = torch.empty(S + 8, dtype=torch.int64, device="cuda:0")
+    ctx.reserve(shard)
+    r = ctx.stage1_index_device(dbuf.data_ptr(), shard, lo, 0, dtape.data_ptr(), S + 8)
+    assert r.count == S and r.error == 0 and r.in_quote_out == 0
+    want = torch.arange(0, S, dtype=torch.int64, device="cuda:0") * (width + 1) + first
+    assert torch.equal(dtape[:S], want)
