@@ -237,12 +237,13 @@ struct RoundMasks {
 // hardware (zero bytes are class 0, exactly like the reference's zero padding of the last
 // block, src/avx/stage1.rs:54-92), so interior and last tiles share one branch-free path.
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
-__device__ __forceinline__ void load_round(rsrc_t rsrc, u32 voff, u32 soff, uint4 (&v)[kRows]) {
-    // voff = lane * 16 (one VGPR for the whole kernel), soff = wave/round offset (scalar),
-    // j * 1024 folds into the instruction's 12-bit immediate
+__device__ __forceinline__ void load_round(rsrc_t rsrc, u32 voff, uint4 (&v)[kRows]) {
+    // The whole tile-relative offset lives in voff: the hardware range check covers
+    // voffset + immediate only (soffset is excluded from bounds checking), and the check is what
+    // makes reading "past the end" of the last tile safe.  j * 1024 folds into the 12-bit immediate.
 #pragma unroll
     for (int j = 0; j < kRows; ++j) {
-        const auto x = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(voff + (u32)j * 1024u), (int)soff, 0);
+        const auto x = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(voff + (u32)j * 1024u), 0, 0);
         v[j] = make_uint4(x[0], x[1], x[2], x[3]);
     }
 }
@@ -313,11 +314,15 @@ __device__ __forceinline__ EdgeKeep edge_keep_of_tile(u32 lane, u32 w, u32 lo_re
 __device__ __forceinline__ void count_phase(rsrc_t rsrc, u32 lane, u32 w, const EdgeKeep& ek,
                                             RoundMasks (&m)[kRounds], u32& carry, u32& cnt_a, u32& cnt_t) {
     uint4 v[2][kRows];
-    const u32 voff = lane * 16u, soff0 = w * (u32)kSpanBytes;
-    load_round(rsrc, voff, soff0, v[0]);
+    u32 voff = w * (u32)kSpanBytes + lane * 16u;  // one running VGPR, advanced per round
+    load_round(rsrc, voff, v[0]);
 #pragma unroll
     for (int r = 0; r < kRounds; ++r) {
-        if (r + 1 < kRounds) load_round(rsrc, voff, soff0 + (u32)(r + 1) * kRoundBytes, v[(r + 1) & 1]);
+        if (r + 1 < kRounds) {
+            voff += (u32)kRoundBytes;
+            asm volatile("" : "+v"(voff));  // opaque: keeps hipcc from materialising 32 offsets up front
+            load_round(rsrc, voff, v[(r + 1) & 1]);
+        }
         __builtin_amdgcn_sched_barrier(0);
         u64 keep = ek.back_round == (u32)r ? ek.back_keep : ~0ull;
         if (r == 0) keep &= ek.front_keep;
