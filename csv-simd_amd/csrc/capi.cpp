@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -450,6 +451,10 @@ int csvsimd_stage1_time_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len,
     L.d_result = (csvsimd_shard_result*)d_result;
     L.bind_scratch(ctx->scratch);
     L.max_blocks = ctx->max_blocks;
+    if (const char* dbg = getenv("CSVSIMD_PROBE_MODE")) {  // development probes only (scripts/probe.py)
+        L.debug_mode = atoi(dbg);
+        if (const char* mb = getenv("CSVSIMD_PROBE_BLOCKS_PER_CU")) L.max_blocks = 256u * (uint32_t)atoi(mb);
+    }
     for (int i = 0; i < warmup; ++i) HIP_TRY(csvsimd::launch_stage1(L, s));
     // one event pair per launch, recorded on the launch stream right around the stage-1 kernel
     // (the memsets before it and the 1-wave finalize after it are outside the pair)

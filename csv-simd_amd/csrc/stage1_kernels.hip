@@ -7,20 +7,27 @@
 //                               (src/stage1.rs:162-296).
 //
 // How (MI355X-first; nothing here mirrors the SSE code's structure):
-//   * one pass over the input, HBM-bound: every byte is read once with 16-B/lane coalesced
-//     loads (a wave covers 1 KiB per instruction); no table lookups, the byte classes come
-//     from SWAR compares + v_dot4 bit gathers.
-//   * a wave owns a contiguous span; per round it holds 4 KiB as 64 lanes x 4 chunks of 16 B and
-//     keeps only two 64-bit masks per lane (4 x 16-bit fields: structural bits, in-string bits).
-//   * in-string mask = per-field prefix-xor (4 shift-xor steps) + ballot/mbcnt carry across
-//     lanes + scalar carry across rows/rounds (CDNA has no carry-less multiply).
+//   * one pass over the input, every byte read once from HBM with 16-B/lane fully coalesced
+//     buffer loads (a wave covers 1 KiB per instruction; the descriptor's range check makes the
+//     ragged last tile branch-free).
+//   * measured on gfx950: every 32-bit VALU instruction costs 4 cycles per wave64 per SIMD, so the
+//     kernel is bound by VALU ISSUE, not HBM, unless the per-byte instruction count is tiny.
+//     Hence: (a) classification = one v_perm 8-entry LUT keyed by 3 hashed bits + xor +
+//     v_lerp_u8 (carry-free per-byte add) + two v_bitop3 + two v_dot4 bit gathers = 10 VALU per
+//     4 bytes for BOTH masks; (b) data is transposed through a wave-private 4-KiB LDS image
+//     (ds_write_b128 / ds_read_b128, XOR-swizzled: conflict-free, zero VALU) so that each lane
+//     owns one 64-byte stripe = one 64-bit structural mask + one 64-bit quote mask.
+//   * in-string mask = 6 shift-xor steps on the lane's 64-bit word (CDNA has no carry-less
+//     multiply) + ONE ballot/mbcnt per 4 KiB for the carry across lanes + a scalar carry across
+//     rounds.  Masks of the whole 32-KiB wave span stay in registers (2 x u64 per round).
 //   * the two loop-carried quantities of the reference (inside_str, array_idx:
 //     src/reader.rs:217-218) become a composable tile descriptor
 //     (quote parity, count if entered outside, count if entered inside) resolved across
 //     workgroups by a single-pass decoupled look-back over one 64-bit word per tile
 //     (relaxed agent-scope atomics: the data is the flag, no fences).
-//   * ordered compaction: per-lane counts -> packed DPP wave scan -> u16 offsets scattered into a
-//     wave-private LDS window -> fully coalesced 8-B tape stores.
+//   * ordered compaction: one DPP wave scan of per-lane popcounts per 4 KiB; sparse rounds store
+//     straight to the tape (consecutive lanes write consecutive entries: near-coalesced), dense
+//     rounds go through a u16 LDS window and leave as fully coalesced 8-byte stores.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -34,11 +41,14 @@ namespace csvsimd {
 static constexpr int kWaves = 4;                        // waves per workgroup
 static constexpr int kThreads = kWaves * 64;            // 256
 static constexpr int kRows = 4;                         // 1-KiB rows (dwordx4 wave loads) per round
-static constexpr int kRoundBytes = kRows * 1024;        // 4 KiB per wave per round
+static constexpr int kRoundBytes = kRows * 1024;        // 4 KiB per wave per round = 64 stripes of 64 B
 static constexpr int kRounds = 8;                       // rounds per wave per tile
 static constexpr int kSpanBytes = kRounds * kRoundBytes;  // 32 KiB contiguous per wave
 static constexpr int kTileBytes = kWaves * kSpanBytes;    // 128 KiB per workgroup tile
-static constexpr int kCompCap = 2048;                   // u16 entries per wave compaction window
+static constexpr int kCompCap = 2048;                   // u16 entries per wave compaction window (aliases the stage image)
+// every input byte is read exactly once and every tape byte written exactly once: non-temporal
+// on both sides (measured on the same traffic mix: +11 % over default-policy loads and stores)
+static constexpr int kLoadAux = 2;                      // buffer-load cache policy bits: nt
 
 static_assert(kTileBytes == CSVSIMD_TILE_BYTES, "tile geometry must match the host header");
 
@@ -83,33 +93,39 @@ __device__ __forceinline__ u32 wave_sum(u32 v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// byte classification: 16 bytes -> 16 structural bits + 16 quote bits (bit i = byte i)
+// byte classification: 4 bytes -> 0x80 flags per byte for "structural" and for "quote".
 // Equal to the reference's class table (src/stage1.rs:23-48): structural = class & 3
 // ({0x2c, 0x0a, 0x0d}), quote = class & 16 ({0x22}); every other byte incl. >= 0x80 is 0.
+//
+//   key  = (b ^ (b >> 3)) & 7         0x0a->3  0x0d->4  0x22->6  0x2c->1   (all distinct)
+//   e    = LUT[key]                   the only special byte that has this key (v_perm_b32)
+//   nz   = (b ^ e) != 0               v_lerp_u8(y, 0xff, 0) = (y + 255) >> 1: bit 7 <=> y >= 1,
+//                                     a per-byte add that cannot carry into the next byte
+//   special bytes with bit 3 set are structural, the one with bit 3 clear (0x22) is the quote.
+// Unused LUT slots hold 0x2c, whose own key (1) differs from theirs, so they can never match.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void classify_dword(u32 x, u32 w, u32& acc_ns, u32& acc_nq) {
-    // exact SWAR zero-byte test on the low 7 bits; bit 7 of x set => never a match.
-    const u32 vm = x & 0x7f7f7f7fu;
-    const u32 tc = (vm ^ 0x2c2c2c2cu) + 0x7f7f7f7fu;  // bit7(byte) = 1 iff low7 != ','
-    const u32 tl = (vm ^ 0x0a0a0a0au) + 0x7f7f7f7fu;
-    const u32 tr = (vm ^ 0x0d0d0d0du) + 0x7f7f7f7fu;
-    const u32 tq = (vm ^ 0x22222222u) + 0x7f7f7f7fu;
-    const u32 ns = (((tc & tl) & tr) | x) & 0x80808080u;  // 0x80 per byte that is NOT structural
-    const u32 nq = (tq | x) & 0x80808080u;                // 0x80 per byte that is NOT a quote
-    // gather the four bit-7 flags: sum(0x80 * weight) — weights are 1<<i, no carries
-    acc_ns = __builtin_amdgcn_udot4(ns, w, acc_ns, false);
-    acc_nq = __builtin_amdgcn_udot4(nq, w, acc_nq, false);
+__device__ __forceinline__ void classify_dword(u32 x, u32 w, u32& acc_s, u32& acc_q) {
+    const u32 key = ((x >> 3) ^ x) & 0x07070707u;
+    const u32 e = __builtin_amdgcn_perm(0x2c222c0du, 0x0a2c2c2cu, key);
+    const u32 nz = __builtin_amdgcn_lerp(x ^ e, 0xffffffffu, 0u);
+    const u32 xs = x << 4;  // bit 3 of every byte -> bit 7
+    const u32 fs = ~nz & xs & 0x80808080u;
+    const u32 fq = ~nz & ~xs & 0x80808080u;
+    // gather the four bit-7 flags: sum(0x80 * weight) — weights are 1 << i, no carries
+    acc_s = __builtin_amdgcn_udot4(fs, w, acc_s, false);
+    acc_q = __builtin_amdgcn_udot4(fq, w, acc_q, false);
 }
 
+// 16 bytes -> 16 structural bits + 16 quote bits (bit i = byte i)
 __device__ __forceinline__ void classify16(uint4 v, u32& st16, u32& q16) {
-    u32 ns_lo = 0, nq_lo = 0, ns_hi = 0, nq_hi = 0;
-    classify_dword(v.x, 0x08040201u, ns_lo, nq_lo);
-    classify_dword(v.y, 0x80402010u, ns_lo, nq_lo);
-    classify_dword(v.z, 0x08040201u, ns_hi, nq_hi);
-    classify_dword(v.w, 0x80402010u, ns_hi, nq_hi);
-    // acc = 128 * (8-bit "not" mask); assemble 16 bits and invert
-    st16 = (((ns_lo >> 7) | (ns_hi << 1)) ^ 0xffffu) & 0xffffu;
-    q16 = (((nq_lo >> 7) | (nq_hi << 1)) ^ 0xffffu) & 0xffffu;
+    u32 s_lo = 0, q_lo = 0, s_hi = 0, q_hi = 0;
+    classify_dword(v.x, 0x08040201u, s_lo, q_lo);
+    classify_dword(v.y, 0x80402010u, s_lo, q_lo);
+    classify_dword(v.z, 0x08040201u, s_hi, q_hi);
+    classify_dword(v.w, 0x80402010u, s_hi, q_hi);
+    // acc = 128 * (8-bit mask)
+    st16 = (s_lo >> 7) | (s_hi << 1);
+    q16 = (q_lo >> 7) | (q_hi << 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -154,67 +170,94 @@ __device__ __forceinline__ u64 load_desc(const u64* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ __forceinline__ void lookback(u64* desc, u32 tile, Desc agg, u32 in_quote_in, u32 lane,
-                                         u32& pin_out, u64& base_out, u32& err) {
+__device__ __forceinline__ void publish_aggregate(u64* desc, u32 tile, Desc agg) {
+    store_desc(desc + tile, kStatusAgg | ((u64)agg.p << 61) | ((u64)agg.b << 24) | (u64)agg.a);
+}
+
+// Resolves the entering state and tape base of `tile` (whose aggregate is already published) and
+// publishes its inclusive word.  Whole wave; every poll looks at 256 predecessors (4 per lane):
+// on MI355X a cross-XCD poll costs 1-2 us while tiles complete every ~30 ns chip-wide, so the
+// nearest inclusive word is routinely > 64 tiles back.
+__device__ __forceinline__ void resolve(u64* desc, u32 tile, Desc agg, u32 in_quote_in, u32 lane, u32& pin_out,
+                                        u64& base_out, u32& err) {
     u32 pin = in_quote_in;
     u64 base = 0;
-    if (tile != 0) {
-        if (lane == 0)
-            store_desc(desc + tile, kStatusAgg | ((u64)agg.p << 61) | ((u64)agg.b << 24) | (u64)agg.a);
-        // acc = composition of the tiles in (hi, tile): function of the state entering tile hi+1
-        u32 acc_p = 0;
-        u64 acc_a = 0, acc_b = 0;
-        int64_t hi = (int64_t)tile - 1;
-        u32 spins = 0;
-        for (;;) {
-            const int64_t j = hi - (int64_t)lane;
+    // acc = composition of the tiles in (hi, tile): function of the state entering tile hi+1
+    u32 acc_p = 0;
+    u64 acc_a = 0, acc_b = 0;
+    int64_t hi = (int64_t)tile - 1;  // position 0 of the window; tile 0 sees only the virtual word
+    u32 spins = 0;
+    for (;;) {
+        // lane k holds window positions 4k .. 4k+3 (position 0 = nearest predecessor)
+        u64 d[4];
+        u32 linv = 4, linc = 4;  // first invalid / first inclusive among this lane's four
+#pragma unroll
+        for (int i = 3; i >= 0; --i) {
+            const int64_t j = hi - (int64_t)(4 * lane + i);
             // virtual tile -1 = inclusive (in_quote_in, 0): the shard's entering state
-            u64 d = kStatusInc | ((u64)in_quote_in << 61);
-            if (j >= 0) d = load_desc(desc + j);
-            const u32 status = (u32)(d >> 62);
-            const u64 inv = __ballot(status == 0);
-            const u64 inc = __ballot(status == 2);
-            const u32 first_inv = inv ? (u32)__builtin_ctzll(inv) : 64u;
-            const u32 first_inc = inc ? (u32)__builtin_ctzll(inc) : 64u;
-            Desc f;
-            f.p = (u32)(d >> 61) & 1u;
-            f.a = (u32)d & 0xffffffu;
-            f.b = (u32)(d >> 24) & 0xffffffu;
-            if (first_inc < first_inv) {
-                const Desc F = wave_compose_ordered(f, lane, first_inc);
-                const u32 Fp = (u32)__builtin_amdgcn_readfirstlane((int)F.p);
-                const u32 Fa = (u32)__builtin_amdgcn_readfirstlane((int)F.a);
-                const u32 Fb = (u32)__builtin_amdgcn_readfirstlane((int)F.b);
-                const u32 dlo = (u32)__builtin_amdgcn_readlane((int)(u32)d, (int)first_inc);
-                const u32 dhi = (u32)__builtin_amdgcn_readlane((int)(u32)(d >> 32), (int)first_inc);
-                const u64 dinc = ((u64)dhi << 32) | dlo;
-                u32 s = (u32)(dinc >> 61) & 1u;
-                u64 n = dinc & ((1ull << 61) - 1);
-                n += s ? Fb : Fa;
-                s ^= Fp;
-                n += s ? acc_b : acc_a;
-                s ^= acc_p;
-                pin = s;
-                base = n;
-                break;
-            }
-            // fold the resolved-aggregate prefix [0, first_inv) and slide the window past it
-            if (first_inv > 0) {
-                const Desc F = wave_compose_ordered(f, lane, first_inv);
-                const u32 Fp = (u32)__builtin_amdgcn_readfirstlane((int)F.p);
-                const u32 Fa = (u32)__builtin_amdgcn_readfirstlane((int)F.a);
-                const u32 Fb = (u32)__builtin_amdgcn_readfirstlane((int)F.b);
-                const u64 na = (u64)Fa + (Fp ? acc_b : acc_a);
-                const u64 nb = (u64)Fb + (Fp ? acc_a : acc_b);
-                acc_a = na;
-                acc_b = nb;
-                acc_p ^= Fp;
-                hi -= (int64_t)first_inv;
-            }
-            if (first_inv < 64) {  // predecessor not published yet: back off, bounded
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > kSpinLimit) { err = 1; break; }
-            }
+            d[i] = kStatusInc | ((u64)in_quote_in << 61);
+            if (j >= 0) d[i] = load_desc(desc + j);
+        }
+#pragma unroll
+        for (int i = 3; i >= 0; --i) {
+            const u32 status = (u32)(d[i] >> 62);
+            if (status == 0) linv = (u32)i;
+            if (status == 2) linc = (u32)i;
+        }
+        const u64 minv = __ballot(linv < 4);
+        const u64 minc = __ballot(linc < 4);
+        u32 first_inv = 256, first_inc = 256;
+        if (minv) {
+            const u32 l = (u32)__builtin_ctzll(minv);
+            first_inv = 4 * l + (u32)__builtin_amdgcn_readlane((int)linv, (int)l);
+        }
+        if (minc) {
+            const u32 l = (u32)__builtin_ctzll(minc);
+            first_inc = 4 * l + (u32)__builtin_amdgcn_readlane((int)linc, (int)l);
+        }
+        const bool done = first_inc < first_inv;
+        const u32 limit = done ? first_inc : first_inv;
+        // compose this lane's aggregates at positions < limit (earliest = largest position first)
+        Desc f = {0, 0, 0};
+#pragma unroll
+        for (int i = 3; i >= 0; --i) {
+            Desc g;
+            g.p = (u32)(d[i] >> 61) & 1u;
+            g.a = (u32)d[i] & 0xffffffu;
+            g.b = (u32)(d[i] >> 24) & 0xffffffu;
+            if (4 * lane + (u32)i >= limit) { g.p = 0; g.a = 0; g.b = 0; }
+            f = compose(f, g);
+        }
+        const Desc F = wave_compose_ordered(f, lane, 64);
+        const u32 Fp = (u32)__builtin_amdgcn_readfirstlane((int)F.p);
+        const u32 Fa = (u32)__builtin_amdgcn_readfirstlane((int)F.a);
+        const u32 Fb = (u32)__builtin_amdgcn_readfirstlane((int)F.b);
+        if (done) {
+            const u32 sel = first_inc & 3u;  // wave-uniform
+            const u64 dsel = sel == 0 ? d[0] : sel == 1 ? d[1] : sel == 2 ? d[2] : d[3];
+            const u32 dlo = (u32)__builtin_amdgcn_readlane((int)(u32)dsel, (int)(first_inc >> 2));
+            const u32 dhi = (u32)__builtin_amdgcn_readlane((int)(u32)(dsel >> 32), (int)(first_inc >> 2));
+            const u64 dinc = ((u64)dhi << 32) | dlo;
+            u32 st = (u32)(dinc >> 61) & 1u;
+            u64 n = dinc & ((1ull << 61) - 1);
+            n += st ? Fb : Fa;
+            st ^= Fp;
+            n += st ? acc_b : acc_a;
+            st ^= acc_p;
+            pin = st;
+            base = n;
+            break;
+        }
+        // fold the resolved-aggregate prefix [0, first_inv) and slide the window past it
+        const u64 na = (u64)Fa + (Fp ? acc_b : acc_a);
+        const u64 nb = (u64)Fb + (Fp ? acc_a : acc_b);
+        acc_a = na;
+        acc_b = nb;
+        acc_p ^= Fp;
+        hi -= (int64_t)first_inv;
+        if (first_inv < 256) {  // a predecessor has not published yet: back off, bounded
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > kSpinLimit) { err = 1; break; }
         }
     }
     const u32 state_out = pin ^ agg.p;
@@ -228,14 +271,10 @@ __device__ __forceinline__ void lookback(u64* desc, u32 tile, Desc agg, u32 in_q
 // the stage-1 kernel
 // ---------------------------------------------------------------------------------------------
 struct RoundMasks {
-    u64 st;  // 4 x 16-bit fields (row j in bits [16j, 16j+16)): comma/CR/LF bits
-    u64 s;   // same layout: in-string mask relative to the wave span's start (entered outside)
+    u64 st;  // bit i = byte i of this lane's 64-byte stripe is ',', CR or LF
+    u64 s;   // in-string mask relative to the wave span's start (span entered outside a string)
 };
 
-// One round = 4 rows x 1 KiB of this wave's span, 16 B per lane per row, through a buffer
-// descriptor that covers exactly the tile's valid bytes: chunks past the end read as zero in
-// hardware (zero bytes are class 0, exactly like the reference's zero padding of the last
-// block, src/avx/stage1.rs:54-92), so interior and last tiles share one branch-free path.
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ void load_round(rsrc_t rsrc, u32 voff, uint4 (&v)[kRows]) {
     // The whole tile-relative offset lives in voff: the hardware range check covers
@@ -243,47 +282,22 @@ __device__ __forceinline__ void load_round(rsrc_t rsrc, u32 voff, uint4 (&v)[kRo
     // makes reading "past the end" of the last tile safe.  j * 1024 folds into the 12-bit immediate.
 #pragma unroll
     for (int j = 0; j < kRows; ++j) {
-        const auto x = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(voff + (u32)j * 1024u), 0, 0);
+        const auto x = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(voff + (u32)j * 1024u), 0, kLoadAux);
         v[j] = make_uint4(x[0], x[1], x[2], x[3]);
     }
 }
 
-__device__ __forceinline__ RoundMasks masks_of_round(const uint4 (&v)[kRows], u32& carry, u64 keep) {
-    u32 st16[kRows], q16[kRows];
-#pragma unroll
-    for (int j = 0; j < kRows; ++j) classify16(v[j], st16[j], q16[j]);
-    const u64 st = ((u64)(st16[0] | (st16[1] << 16)) | ((u64)(st16[2] | (st16[3] << 16)) << 32)) & keep;
-    u64 x = ((u64)(q16[0] | (q16[1] << 16)) | ((u64)(q16[2] | (q16[3] << 16)) << 32)) & keep;
-    // inclusive prefix-xor inside each 16-bit field
-    x ^= (x << 1) & 0xfffefffefffefffeull;
-    x ^= (x << 2) & 0xfffcfffcfffcfffcull;
-    x ^= (x << 4) & 0xfff0fff0fff0fff0ull;
-    x ^= (x << 8) & 0xff00ff00ff00ff00ull;
-    // carry across lanes (ballot + mbcnt) and across rows (scalar), sequence order = row, lane
-    u64 flip = 0;
-#pragma unroll
-    for (int j = 0; j < kRows; ++j) {
-        const u64 par = __ballot((x >> (16 * j + 15)) & 1ull);
-        const u32 enter = (mbcnt64(par) ^ carry) & 1u;
-        flip |= enter ? (0xffffull << (16 * j)) : 0ull;
-        carry ^= (u32)__builtin_popcountll(par) & 1u;
-    }
-    RoundMasks m;
-    m.st = st;
-    m.s = x ^ flip;
-    return m;
-}
-
-// A shard whose start is not 16-byte aligned, or whose end is not a multiple of 16, has one
-// partially valid 16-byte chunk at each end.  Loads always fetch whole chunks (a chunk never
-// crosses a page; chunks entirely past the end read as zero through the buffer descriptor) and
-// the stray bytes of those two chunks are dropped at the bit level after classification.  Each
-// lane knows, per tile, at most one "back" special chunk (round, 64-bit keep mask); the "front"
-// special chunk can only be chunk 0 of the shard (tile 0, wave 0, round 0, row 0, lane 0).
+// A shard whose start is not 16-byte aligned, or whose end is not a multiple of 64, has one
+// partially valid stripe at each end.  Loads always fetch whole 16-byte chunks (a chunk never
+// crosses a page; chunks entirely past the end read as zero through the buffer descriptor — zero
+// bytes are class 0, exactly like the reference's zero padding of its last block,
+// src/avx/stage1.rs:54-92) and the stray bytes of those two stripes are dropped at the bit level
+// after classification.  Each lane knows, per tile, at most one "back" special stripe; the
+// "front" one can only be stripe 0 of the shard (tile 0, wave 0, round 0, lane 0).
 struct EdgeKeep {
-    u32 back_round;   // round index of this lane's partial last chunk, or 0xff
-    u64 back_keep;    // bits to keep in that round
-    u64 front_keep;   // bits to keep in round 0 (all ones unless this lane holds chunk 0 and lo > 0)
+    u32 back_round;  // round index of this lane's partially valid last stripe, or 0xff
+    u64 back_keep;   // bits to keep in that round
+    u64 front_keep;  // bits to keep in round 0 (all ones unless this lane holds stripe 0 and lo > 0)
 };
 
 __device__ __forceinline__ EdgeKeep edge_keep_of_tile(u32 lane, u32 w, u32 lo_rel, u32 hi_rel) {
@@ -291,42 +305,82 @@ __device__ __forceinline__ EdgeKeep edge_keep_of_tile(u32 lane, u32 w, u32 lo_re
     e.back_round = 0xffu;
     e.back_keep = ~0ull;
     e.front_keep = ~0ull;
-    const u32 span_lo = w * (u32)kSpanBytes;
-    if ((hi_rel & 15u) != 0u) {
-        const u32 bp = hi_rel & ~15u;  // tile-relative position of the partial chunk
-        const u32 rel = bp - span_lo;  // wraps when the chunk is not in this wave's span
-        if (rel < (u32)kSpanBytes && ((bp >> 4) & 63u) == lane) {
-            e.back_round = rel >> 12;
-            const u32 j = (rel >> 10) & 3u;
-            const u64 drop = (u64)(0xffffu & ~((1u << (hi_rel & 15u)) - 1u)) << (16 * j);
-            e.back_keep = ~drop;
+    if ((hi_rel & 63u) != 0u) {
+        const u32 sb = hi_rel >> 6;  // tile-relative index of the partial stripe
+        if ((sb >> 9) == w && (sb & 63u) == lane) {  // 512 stripes per wave span
+            e.back_round = (sb >> 6) & 7u;
+            e.back_keep = (1ull << (hi_rel & 63u)) - 1ull;
         }
     }
-    if (lo_rel != 0u && w == 0 && lane == 0) e.front_keep = ~(u64)((1u << lo_rel) - 1u);  // lo_rel < 16
+    if (lo_rel != 0u && w == 0 && lane == 0) e.front_keep = ~((1ull << lo_rel) - 1ull);  // lo_rel < 16
     return e;
 }
 
-// Count phase of one wave span.  Two rounds (8 KiB per wave) are in flight: round r+1 is
-// requested before round r is classified.  The body must stay ONE basic block and must not be
+// wave-private 4-KiB LDS image of one round, in 16-byte slots.  Chunk (stripe s, k) lives in slot
+// 4 s + (k ^ ((s >> 2) & 3)): the coalesced writers (8 consecutive lanes = two whole stripes) and
+// the stripe-owning readers (ds_read_b128 lane groups) are both bank-conflict free.
+struct StageAddr {
+    u32 wslot;  // slot this lane writes for row 0 (row j: + 64 j)
+    u32 rslot;  // slot of chunk 0 of this lane's stripe (chunk k: rslot ^ k)
+};
+__device__ __forceinline__ StageAddr stage_addr_of_lane(u32 lane) {
+    StageAddr a;
+    a.wslot = (lane & ~3u) | ((lane & 3u) ^ ((lane >> 4) & 3u));
+    a.rslot = lane * 4u + ((lane >> 2) & 3u);
+    return a;
+}
+
+// Count phase of one wave span.  Round r+1 is requested before round r is classified (4 KiB per
+// wave in flight).  The body must stay ONE basic block and must not be
 // duplicated under a branch: with control flow around it LLVM hoists/sinks the classification
 // across all eight rounds (128+ live VGPRs, one wave per SIMD).  The sched_barriers keep the
 // machine scheduler from doing the same and the opaque asm anchors each round's results.
-__device__ __forceinline__ void count_phase(rsrc_t rsrc, u32 lane, u32 w, const EdgeKeep& ek,
-                                            RoundMasks (&m)[kRounds], u32& carry, u32& cnt_a, u32& cnt_t) {
-    uint4 v[2][kRows];
+__device__ __forceinline__ void count_phase(rsrc_t rsrc, u32 lane, u32 w, const EdgeKeep& ek, uint4* stage,
+                                            const StageAddr sa, RoundMasks (&m)[kRounds], u32& carry,
+                                            u32& cnt_a, u32& cnt_t) {
+    uint4 v[kRows];
     u32 voff = w * (u32)kSpanBytes + lane * 16u;  // one running VGPR, advanced per round
-    load_round(rsrc, voff, v[0]);
+    load_round(rsrc, voff, v);
 #pragma unroll
     for (int r = 0; r < kRounds; ++r) {
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- transpose: lane l ends up with stripe l (64 contiguous bytes) of this round -------
+#pragma unroll
+        for (int j = 0; j < kRows; ++j) stage[sa.wslot + 64u * j] = v[j];
+        // the registers are free again as soon as the LDS writes have issued: request the next
+        // round now, it streams in while this round is classified (4 KiB per wave in flight)
         if (r + 1 < kRounds) {
             voff += (u32)kRoundBytes;
             asm volatile("" : "+v"(voff));  // opaque: keeps hipcc from materialising 32 offsets up front
-            load_round(rsrc, voff, v[(r + 1) & 1]);
+            load_round(rsrc, voff, v);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        u32 st16[kRows], q16[kRows];
+#pragma unroll
+        for (int k = 0; k < kRows; ++k) classify16(stage[sa.rslot ^ (u32)k], st16[k], q16[k]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         u64 keep = ek.back_round == (u32)r ? ek.back_keep : ~0ull;
         if (r == 0) keep &= ek.front_keep;
-        m[r] = masks_of_round(v[r & 1], carry, keep);
+        const u64 st = ((u64)(st16[0] | (st16[1] << 16)) | ((u64)(st16[2] | (st16[3] << 16)) << 32)) & keep;
+        u64 x = ((u64)(q16[0] | (q16[1] << 16)) | ((u64)(q16[2] | (q16[3] << 16)) << 32)) & keep;
+        // inclusive prefix-xor over the stripe's 64 bits (src/avx/stage1.rs:342-361 does this
+        // with one PCLMULQDQ; CDNA has no carry-less multiply)
+        x ^= x << 1;
+        x ^= x << 2;
+        x ^= x << 4;
+        x ^= x << 8;
+        x ^= x << 16;
+        x ^= x << 32;
+        // carry across lanes (one ballot + mbcnt) and across rounds (scalar)
+        const u64 par = __ballot((x >> 63) != 0);
+        const u32 enter = (mbcnt64(par) ^ carry) & 1u;
+        carry ^= (u32)__builtin_popcountll(par) & 1u;
+        m[r].st = st;
+        m[r].s = x ^ (enter ? ~0ull : 0ull);
         cnt_a += (u32)__builtin_popcountll(m[r].st & ~m[r].s);
         cnt_t += (u32)__builtin_popcountll(m[r].st);
         // anchor this round's results here: an opaque asm cannot be sunk or re-ordered
@@ -349,139 +403,239 @@ struct KernelArgs {
     csvsimd_shard_result* result;
 };
 
-template <bool EMIT>
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Writes window entries comp[0, n) (u16 offsets relative to the span) to tape[run, run + n) as
+// fully coalesced non-temporal stores, 16 bytes (two entries) per lane wherever the address allows.
+__device__ __forceinline__ void flush_window(const KernelArgs& args, const unsigned short* comp, u32 n, u64 run,
+                                             u64 span_off, u32 lane) {
+    if (n == 0) return;
+    u64* const tape = args.tape;
+    // entry k sits at byte address tape + 8 (run + k): peel one entry if that is not 16-byte aligned
+    const u32 head = (u32)((((uintptr_t)tape >> 3) + run) & 1u);
+    if (head && lane == 0 && run < args.tape_cap) __builtin_nontemporal_store(span_off + comp[0], tape + run);
+    const u32 npairs = (n - head) >> 1;
+    for (u32 i = lane; i < npairs; i += 64) {
+        const u32 k = head + 2 * i;
+        const u64 idx = run + k;
+        const u64 e0 = span_off + comp[k], e1 = span_off + comp[k + 1];
+        if (idx + 1 < args.tape_cap) {
+            const u32x4 x = {(u32)e0, (u32)(e0 >> 32), (u32)e1, (u32)(e1 >> 32)};
+            __builtin_nontemporal_store(x, reinterpret_cast<u32x4*>(tape + idx));
+        } else if (idx < args.tape_cap) {
+            __builtin_nontemporal_store(e0, tape + idx);
+        }
+    }
+    if (((n - head) & 1u) && lane == 0) {
+        const u64 idx = run + n - 1;
+        if (idx < args.tape_cap) __builtin_nontemporal_store(span_off + comp[n - 1], tape + idx);
+    }
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// scatters the set bits of R (this lane's stripe of round r) as u16 span-relative offsets to
+// comp[p], comp[p+1], ... keeping only positions < kCompCap (p wraps for entries before a window)
+__device__ __forceinline__ void scatter_bits(unsigned short* comp, u64 R, u32 p, u32 stripe_rel) {
+    u32 lo = (u32)R, hi = (u32)(R >> 32);
+    while (lo) {
+        const u32 b = (u32)__builtin_ctz(lo);
+        lo &= lo - 1;
+        if (p < (u32)kCompCap) comp[p] = (unsigned short)(stripe_rel + b);
+        ++p;
+    }
+    while (hi) {
+        const u32 b = (u32)__builtin_ctz(hi) + 32u;
+        hi &= hi - 1;
+        if (p < (u32)kCompCap) comp[p] = (unsigned short)(stripe_rel + b);
+        ++p;
+    }
+}
+
+// Emits the tape entries of one wave span from its held masks: ordered compaction through the
+// wave-private LDS window.  Rounds are batched into the window until it is full, so a sparse span
+// (CSV with long fields) leaves as one long run of 16-byte stores.
+//   wstate: absolute in-string state entering the span; run: tape index of the span's first entry
+__device__ __forceinline__ void emit_span(const KernelArgs& args, const RoundMasks (&m)[kRounds], u32 lane, u64 span0,
+                                          u32 wstate, u64 run, unsigned short* comp) {
+    const u64 flipall = wstate ? ~0ull : 0ull;
+    const u64 span_off = args.base_off + span0 - args.lo;  // tape value of the span's byte 0
+    u32 fill = 0;                                           // entries waiting in the window
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+        const u64 R = m[r].st & ~(m[r].s ^ flipall);
+        const u32 c = (u32)__builtin_popcountll(R);
+        const u32 incl = wave_incl_scan_add(c);
+        const u32 n_r = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        const u32 excl = incl - c;
+        const u32 stripe_rel = (u32)r * kRoundBytes + lane * 64u;
+        if (fill + n_r > (u32)kCompCap) {
+            wave_lds_fence();
+            flush_window(args, comp, fill, run, span_off, lane);
+            wave_lds_fence();
+            run += fill;
+            fill = 0;
+        }
+        if (n_r <= (u32)kCompCap) {
+            scatter_bits(comp, R, fill + excl, stripe_rel);
+            fill += n_r;
+        } else {
+            // more than half of this round's bytes are structural: several window passes
+            for (u32 win = 0; win < n_r; win += kCompCap) {
+                scatter_bits(comp, R, excl - win, stripe_rel);
+                wave_lds_fence();
+                const u32 n_win = (n_r - win) < (u32)kCompCap ? (n_r - win) : (u32)kCompCap;
+                flush_window(args, comp, n_win, run, span_off, lane);
+                wave_lds_fence();
+                run += n_win;
+            }
+        }
+    }
+    wave_lds_fence();
+    flush_window(args, comp, fill, run, span_off, lane);
+    wave_lds_fence();
+}
+
+// DBG (development probes only, never used by the product entry points): 0 = normal,
+// bit 0 = skip classification (loads only), bit 1 = static tiles (no ticket), bit 2 = no look-back
+template <bool EMIT, int DBG = 0>
 __global__ __launch_bounds__(kThreads) void stage1_kernel(const KernelArgs args) {
     __shared__ u32 s_tile;
     __shared__ u32 s_wdesc[kWaves][3];
     __shared__ u32 s_pin;
     __shared__ u64 s_base;
     __shared__ u32 s_err;
-    __shared__ unsigned short s_comp[EMIT ? kWaves : 1][EMIT ? kCompCap : 1];
+    // wave-private 4-KiB image: input transpose in the count phase, u16 compaction window in the
+    // emit phase (the two uses never overlap in time within a wave)
+    __shared__ uint4 s_stage[kWaves][kRoundBytes / 16];
+    static_assert(kCompCap * 2 <= kRoundBytes, "compaction window must fit the stage image");
 
     const u32 t = threadIdx.x;
     const u32 lane = t & 63u;
     const u32 w = (u32)__builtin_amdgcn_readfirstlane((int)(t >> 6));
     if (t == 0) s_err = 0;
+    const StageAddr sa = stage_addr_of_lane(lane);
 
-    for (;;) {
-        if (t == 0) s_tile = atomicAdd(args.ticket, 1u);
+    // The tile whose count phase ran in the PREVIOUS iteration is held in registers (masks of the
+    // whole span + its descriptors) and is resolved and emitted one iteration later, after the next
+    // tile's count phase.  Measured reason: a tile can only resolve once every predecessor back to
+    // the nearest inclusive word (~100 tiles at MI355X's poll latency) has published, so resolving
+    // right away makes every workgroup wait for the slowest of its ~100 concurrently running
+    // predecessors (-25 % throughput).  One tile-time later they have all long published and the
+    // look-back is one or two polls with no spinning.  Count phases never wait on anything, so
+    // forward progress holds: every aggregate is eventually published by a running workgroup.
+    RoundMasks held[kRounds];
+    Desc held_agg = {0, 0, 0}, held_before = {0, 0, 0};
+    u32 held_tile = 0;
+    bool have_held = false;
+
+    // Tile ids come from an atomic ticket drawn when the workgroup is ready to start the tile, so
+    // that tiles start (and finish) in nearly ticket order whatever the dispatch order was —
+    // drawing the ticket early was measured: it scrambles the start order and costs 40 %.
+    for (u32 iter = 0;; ++iter) {
+        if (t == 0) s_tile = (DBG & 2) ? blockIdx.x + iter * gridDim.x : atomicAdd(args.ticket, 1u);
         __syncthreads();
         const u32 tile = (u32)__builtin_amdgcn_readfirstlane((int)s_tile);
-        if (tile >= args.num_tiles) break;
+        const bool have_cur = tile < args.num_tiles;
+        if (!have_cur && !have_held) break;
 
-        const u64 tile0 = (u64)tile * kTileBytes;                // relative to abase
-        const u64 span0 = tile0 + (u64)w * kSpanBytes;
-        // descriptor over this tile's valid bytes, rounded up to whole 16-byte chunks (a chunk
-        // never straddles a page, so the <= 15 extra bytes are always mapped)
-        const u64 hi16 = (args.hi + 15) & ~15ull;
-        const u64 avail = hi16 - tile0;
-        const rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<uint8_t*>(args.abase) + tile0, 0, (int)(avail < (u64)kTileBytes ? avail : (u64)kTileBytes),
-            0x00020000);
-        // valid bytes of this tile are [lo_rel, hi_rel) relative to the tile start
-        const u32 lo_rel = args.lo > tile0 ? (u32)(args.lo - tile0) : 0u;  // lo < 16
-        const u32 hi_rel = args.hi - tile0 < (u64)kTileBytes ? (u32)(args.hi - tile0) : (u32)kTileBytes;
-
-        // ---- count phase: masks for the whole span stay in registers -------------------------
         RoundMasks m[kRounds];
-        u32 carry = 0, cnt_a = 0, cnt_t = 0;
-        const EdgeKeep ek = edge_keep_of_tile(lane, w, lo_rel, hi_rel);
-        count_phase(rsrc, lane, w, ek, m, carry, cnt_a, cnt_t);
-        const u32 wave_a = wave_sum(cnt_a);
-        const u32 wave_t = wave_sum(cnt_t);
-        if (lane == 0) {
-            s_wdesc[w][0] = carry;
-            s_wdesc[w][1] = wave_a;
-            s_wdesc[w][2] = wave_t - wave_a;
+        Desc agg = {0, 0, 0}, before = {0, 0, 0};
+        if (have_cur) {
+            const u64 tile0 = (u64)tile * kTileBytes;  // relative to abase
+            // descriptor over this tile's valid bytes, rounded up to whole 16-byte chunks (a chunk
+            // never straddles a page, so the <= 15 extra bytes are always mapped)
+            const u64 hi16 = (args.hi + 15) & ~15ull;
+            const u64 avail = hi16 - tile0;
+            const rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<uint8_t*>(args.abase) + tile0, 0,
+                (int)(avail < (u64)kTileBytes ? avail : (u64)kTileBytes), 0x00020000);
+            // valid bytes of this tile are [lo_rel, hi_rel) relative to the tile start
+            const u32 lo_rel = args.lo > tile0 ? (u32)(args.lo - tile0) : 0u;  // lo < 16
+            const u32 hi_rel = args.hi - tile0 < (u64)kTileBytes ? (u32)(args.hi - tile0) : (u32)kTileBytes;
+
+            // ---- count phase: masks for the whole span stay in registers ---------------------
+            u32 carry = 0, cnt_a = 0, cnt_t = 0;
+            const EdgeKeep ek = edge_keep_of_tile(lane, w, lo_rel, hi_rel);
+            if (DBG & 1) {
+                uint4 v[kRows];
+                u32 acc = 0;
+#pragma unroll
+                for (int r = 0; r < kRounds; ++r) {
+                    load_round(rsrc, w * (u32)kSpanBytes + lane * 16u + (u32)r * kRoundBytes, v);
+#pragma unroll
+                    for (int j = 0; j < kRows; ++j) acc ^= v[j].x ^ v[j].y ^ v[j].z ^ v[j].w;
+                    m[r].st = 0;
+                    m[r].s = 0;
+                }
+                cnt_a = acc & 1u;
+            } else {
+                count_phase(rsrc, lane, w, ek, s_stage[w], sa, m, carry, cnt_a, cnt_t);
+            }
+            const u32 wave_a = wave_sum(cnt_a);
+            const u32 wave_t = wave_sum(cnt_t);
+            if (lane == 0) {
+                s_wdesc[w][0] = carry;
+                s_wdesc[w][1] = wave_a;
+                s_wdesc[w][2] = wave_t - wave_a;
+            }
         }
         __syncthreads();
 
-        // ---- tile aggregate; this wave's entering state/offset relative to the tile ----------
-        Desc agg = {0, 0, 0}, before = {0, 0, 0};
+        if (have_cur) {
+            // ---- tile aggregate; this wave's entering state/offset relative to the tile ------
 #pragma unroll
-        for (int k = 0; k < kWaves; ++k) {
-            Desc d = {s_wdesc[k][0], s_wdesc[k][1], s_wdesc[k][2]};
-            if ((u32)k == w) before = agg;
-            agg = compose(agg, d);
+            for (int k = 0; k < kWaves; ++k) {
+                Desc d = {s_wdesc[k][0], s_wdesc[k][1], s_wdesc[k][2]};
+                if ((u32)k == w) before = agg;
+                agg = compose(agg, d);
+            }
         }
 
         if (w == 0) {
-            u32 pin, err = 0;
-            u64 base;
-            lookback(args.desc, tile, agg, args.in_quote_in, lane, pin, base, err);
-            if (lane == 0) {
-                s_pin = pin;
-                s_base = base;
-                if (err) s_err = 1;
+            if (have_cur && lane == 0) {
+                if (!(DBG & 4)) publish_aggregate(args.desc, tile, agg);
                 atomicAdd((unsigned long long*)(args.tot_struct + (tile & 63u)),
                           (unsigned long long)(agg.a + agg.b));
-                if (tile == args.num_tiles - 1) {
-                    const u64 count = base + (pin ? agg.b : agg.a);
-                    args.result->count = count;
-                    args.result->in_quote_out = pin ^ agg.p;
-                    args.result->quote_parity = pin ^ agg.p ^ args.in_quote_in;
-                    args.result->written = count < args.tape_cap ? count : args.tape_cap;
+            }
+            if (have_held) {
+                u32 pin = 0, err = 0;
+                u64 base = 0;
+                if (!(DBG & 4)) resolve(args.desc, held_tile, held_agg, args.in_quote_in, lane, pin, base, err);
+                if (lane == 0) {
+                    s_pin = pin;
+                    s_base = base;
+                    if (err) s_err = 1;
+                    if (held_tile == args.num_tiles - 1) {
+                        const u64 count = base + (pin ? held_agg.b : held_agg.a);
+                        args.result->count = count;
+                        args.result->in_quote_out = pin ^ held_agg.p;
+                        args.result->quote_parity = pin ^ held_agg.p ^ args.in_quote_in;
+                        args.result->written = count < args.tape_cap ? count : args.tape_cap;
+                    }
                 }
             }
         }
         __syncthreads();
-        if (EMIT) {
+        if (EMIT && have_held) {
             const u32 pin = s_pin;
             // state entering this wave's span and tape index of its first entry
-            const u32 wstate = pin ^ before.p;
-            u64 run = s_base + (pin ? before.b : before.a);
-            const u64 flipall = wstate ? ~0ull : 0ull;
-            unsigned short* comp = s_comp[w];
-#pragma unroll
-            for (int r = 0; r < kRounds; ++r) {
-                const u64 R = m[r].st & ~(m[r].s ^ flipall);
-                // per-row counts, packed 2 x 16 bit per register, scanned across lanes
-                const u32 c01 = (u32)__builtin_popcount((u32)R & 0xffffu) |
-                                ((u32)__builtin_popcount((u32)R >> 16) << 16);
-                const u32 c23 = (u32)__builtin_popcount((u32)(R >> 32) & 0xffffu) |
-                                ((u32)__builtin_popcount((u32)(R >> 48)) << 16);
-                const u32 i01 = wave_incl_scan_add(c01);
-                const u32 i23 = wave_incl_scan_add(c23);
-                const u32 t01 = (u32)__builtin_amdgcn_readlane((int)i01, 63);
-                const u32 t23 = (u32)__builtin_amdgcn_readlane((int)i23, 63);
-                const u32 e01 = i01 - c01, e23 = i23 - c23;
-                const u32 tot0 = t01 & 0xffffu, tot1 = t01 >> 16, tot2 = t23 & 0xffffu, tot3 = t23 >> 16;
-                const u32 n_r = tot0 + tot1 + tot2 + tot3;
-                u32 pos[kRows];
-                pos[0] = (e01 & 0xffffu);
-                pos[1] = tot0 + (e01 >> 16);
-                pos[2] = tot0 + tot1 + (e23 & 0xffffu);
-                pos[3] = tot0 + tot1 + tot2 + (e23 >> 16);
-                // byte offset of this round relative to the shard's first valid byte
-                const u64 round_off = args.base_off + (span0 + (u64)r * kRoundBytes) - args.lo;
-                for (u32 win = 0; win < n_r; win += kCompCap) {
-#pragma unroll
-                    for (int j = 0; j < kRows; ++j) {
-                        u32 bits = (u32)(R >> (16 * j)) & 0xffffu;
-                        u32 p = pos[j] - win;  // wraps for entries before the window
-                        const u32 off = (u32)j * 1024u + lane * 16u;
-                        while (bits) {
-                            const u32 b = (u32)__builtin_ctz(bits);
-                            bits &= bits - 1;
-                            if (p < (u32)kCompCap) comp[p] = (unsigned short)(off + b);
-                            ++p;
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    const u32 n_win = (n_r - win) < (u32)kCompCap ? (n_r - win) : (u32)kCompCap;
-                    for (u32 i = lane; i < n_win; i += 64) {
-                        const u64 idx = run + win + i;
-                        if (idx < args.tape_cap) args.tape[idx] = round_off + comp[i];
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                }
-                run += n_r;
-            }
+            const u32 wstate = pin ^ held_before.p;
+            const u64 run = s_base + (pin ? held_before.b : held_before.a);
+            const u64 span0 = (u64)held_tile * kTileBytes + (u64)w * kSpanBytes;
+            emit_span(args, held, lane, span0, wstate, run, reinterpret_cast<unsigned short*>(s_stage[w]));
         }
+        // the tile counted in this iteration becomes the held one
+        have_held = have_cur;
+        held_tile = tile;
+        held_agg = agg;
+        held_before = before;
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r) held[r] = m[r];
     }
     // the barrier at the loop head ordered every wave's s_err store of earlier tiles
     if (t == 0 && s_err) args.result->error = 1;
@@ -662,10 +816,20 @@ hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream) {
     if (a.num_tiles > 0) {
         const u32 grid = a.num_tiles < L.max_blocks ? a.num_tiles : L.max_blocks;
         if (L.ev_begin && (e = hipEventRecord(L.ev_begin, stream)) != hipSuccess) return e;
-        if (a.tape)
-            hipLaunchKernelGGL(stage1_kernel<true>, dim3(grid), dim3(kThreads), 0, stream, a);
+        if (L.debug_mode == 1)
+            hipLaunchKernelGGL((stage1_kernel<false, 1>), dim3(grid), dim3(kThreads), 0, stream, a);
+        else if (L.debug_mode == 2)
+            hipLaunchKernelGGL((stage1_kernel<false, 2>), dim3(grid), dim3(kThreads), 0, stream, a);
+        else if (L.debug_mode == 4)
+            hipLaunchKernelGGL((stage1_kernel<false, 4>), dim3(grid), dim3(kThreads), 0, stream, a);
+        else if (L.debug_mode == 6)
+            hipLaunchKernelGGL((stage1_kernel<false, 6>), dim3(grid), dim3(kThreads), 0, stream, a);
+        else if (L.debug_mode == 7)
+            hipLaunchKernelGGL((stage1_kernel<false, 7>), dim3(grid), dim3(kThreads), 0, stream, a);
+        else if (a.tape)
+            hipLaunchKernelGGL((stage1_kernel<true, 0>), dim3(grid), dim3(kThreads), 0, stream, a);
         else
-            hipLaunchKernelGGL(stage1_kernel<false>, dim3(grid), dim3(kThreads), 0, stream, a);
+            hipLaunchKernelGGL((stage1_kernel<false, 0>), dim3(grid), dim3(kThreads), 0, stream, a);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         if (L.ev_end && (e = hipEventRecord(L.ev_end, stream)) != hipSuccess) return e;
@@ -702,7 +866,7 @@ hipError_t launch_selftest(u32* d_out, hipStream_t stream) {
 
 int stage1_max_blocks_per_cu() {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, stage1_kernel<true>, kThreads, 0) != hipSuccess || n < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, stage1_kernel<true, 0>, kThreads, 0) != hipSuccess || n < 1)
         n = 2;
     return n;
 }
