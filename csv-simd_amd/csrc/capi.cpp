@@ -474,6 +474,16 @@ int csvsimd_stage1_time_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len,
     }
     for (auto& e : ev) (void)hipEventDestroy(e);
     *avg_ms = (float)(total / iters);
+    if (L.debug_mode == 8) {  // development probe: print the per-phase stamps of the last launch
+        uint64_t h[24];
+        HIP_TRY(hipMemcpy(h, (char*)ctx->scratch + 16, sizeof h, hipMemcpyDeviceToHost));
+        const double nwg = (double)std::min<uint64_t>(L.max_blocks, (len + CSVSIMD_TILE_BYTES - 1) / CSVSIMD_TILE_BYTES);
+        static const char* names[6] = {"ticket+barrier", "count phase", "barrier A", "publish+resolve", "barrier B", "emit"};
+        for (int wv = 0; wv < 2; ++wv)
+            for (int k = 0; k < 6; ++k)
+                fprintf(stderr, "PROF wave%d %-16s %.2f us per workgroup (sum over its tiles)\n", wv, names[k],
+                        (double)h[8 + wv * 8 + k] / nwg / 100.0);
+    }
     return CSVSIMD_OK;
 }
 

@@ -317,52 +317,74 @@ __device__ __forceinline__ EdgeKeep edge_keep_of_tile(u32 lane, u32 w, u32 lo_re
 }
 
 // wave-private 4-KiB LDS image of one round, in 16-byte slots.  Chunk (stripe s, k) lives in slot
-// 4 s + (k ^ ((s >> 2) & 3)): the coalesced writers (8 consecutive lanes = two whole stripes) and
-// the stripe-owning readers (ds_read_b128 lane groups) are both bank-conflict free.
+// 4 s + (k ^ ((s >> 2) & 3)): the stripe-owning readers (ds_read_b128 lane groups) are bank-conflict
+// free.  The image is filled by LDS-DMA (buffer_load_dwordx4 ... lds): the destination is linear
+// (slot = 64 j + lane for row j), so the swizzle sits on the SOURCE side — lane i of row j fetches
+// the chunk that belongs in slot 64 j + i.  Each quad of lanes still covers one whole 64-byte
+// segment, so the global access stays fully coalesced, and the data never touches a VGPR.
 struct StageAddr {
-    u32 wslot;  // slot this lane writes for row 0 (row j: + 64 j)
+    u32 src;    // tile-relative byte offset this lane fetches for row 0, round 0 of wave 0
     u32 rslot;  // slot of chunk 0 of this lane's stripe (chunk k: rslot ^ k)
 };
 __device__ __forceinline__ StageAddr stage_addr_of_lane(u32 lane) {
     StageAddr a;
-    a.wslot = (lane & ~3u) | ((lane & 3u) ^ ((lane >> 4) & 3u));
+    a.src = (lane >> 2) * 64u + (((lane & 3u) ^ ((lane >> 4) & 3u)) * 16u);
     a.rslot = lane * 4u + ((lane >> 2) & 3u);
     return a;
 }
 
-// Count phase of one wave span.  Round r+1 is requested before round r is classified (4 KiB per
-// wave in flight).  The body must stay ONE basic block and must not be
-// duplicated under a branch: with control flow around it LLVM hoists/sinks the classification
-// across all eight rounds (128+ live VGPRs, one wave per SIMD).  The sched_barriers keep the
-// machine scheduler from doing the same and the opaque asm anchors each round's results.
-__device__ __forceinline__ void count_phase(rsrc_t rsrc, u32 lane, u32 w, const EdgeKeep& ek, uint4* stage,
-                                            const StageAddr sa, RoundMasks (&m)[kRounds], u32& carry,
-                                            u32& cnt_a, u32& cnt_t) {
-    uint4 v[kRows];
-    u32 voff = w * (u32)kSpanBytes + lane * 16u;  // one running VGPR, advanced per round
-    load_round(rsrc, voff, v);
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+__device__ __forceinline__ void dma_round(rsrc_t rsrc, u32 voff, uint4* stage) {
+    // The whole tile-relative offset lives in voff (+ j * 1024 added in a VGPR): the hardware
+    // range check covers voffset + immediate only, and the check is what makes reading "past the
+    // end" of the last tile safe — out-of-range lanes deposit zeros.
+#pragma unroll
+    for (int j = 0; j < kRows; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(stage + 64 * j), 16, (int)(voff + (u32)j * 1024u), 0,
+                                                 0, kLoadAux);
+}
+
+// Count phase of one wave span.  Round r+2 is requested as soon as round r's image has been read
+// into registers.  The body must stay ONE
+// basic block and must not be duplicated under a branch: with control flow around it LLVM
+// hoists/sinks the classification across all eight rounds (128+ live VGPRs).  The sched_barriers
+// keep the machine scheduler from doing the same and the opaque asm anchors each round's results.
+__device__ __forceinline__ void count_phase(rsrc_t rsrc, u32 lane, u32 w, const EdgeKeep& ek, uint4* stage0,
+                                            uint4* stage1, const StageAddr sa, RoundMasks (&m)[kRounds],
+                                            u32& carry, u32& cnt_a, u32& cnt_t) {
+    // two images per wave: rounds r+1 and r+2 stream in (8 KiB per wave in flight, no VGPRs) while
+    // round r is classified
+    u32 voff = w * (u32)kSpanBytes + sa.src;  // one running VGPR, advanced per round
+    dma_round(rsrc, voff, stage0);
+    voff += (u32)kRoundBytes;
+    asm volatile("" : "+v"(voff));
+    dma_round(rsrc, voff, stage1);
 #pragma unroll
     for (int r = 0; r < kRounds; ++r) {
+        uint4* const stage = (r & 1) ? stage1 : stage0;
         __builtin_amdgcn_sched_barrier(0);
-        // ---- transpose: lane l ends up with stripe l (64 contiguous bytes) of this round -------
+        // this round's image has landed once all but the next round's 4 DMAs have retired (LDS-DMA
+        // is ordered for a ds_read only by the issuing wave's vmcnt, which counts in issue order)
+        if (r + 1 < kRounds)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        uint4 stripe[kRows];  // lane l: the 64 contiguous bytes of stripe l of this round
 #pragma unroll
-        for (int j = 0; j < kRows; ++j) stage[sa.wslot + 64u * j] = v[j];
-        // the registers are free again as soon as the LDS writes have issued: request the next
-        // round now, it streams in while this round is classified (4 KiB per wave in flight)
-        if (r + 1 < kRounds) {
+        for (int k = 0; k < kRows; ++k) stripe[k] = stage[sa.rslot ^ (u32)k];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // the image is free again: request round r+2 into it
+        if (r + 2 < kRounds) {
             voff += (u32)kRoundBytes;
             asm volatile("" : "+v"(voff));  // opaque: keeps hipcc from materialising 32 offsets up front
-            load_round(rsrc, voff, v);
+            dma_round(rsrc, voff, stage);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_sched_barrier(0);
         u32 st16[kRows], q16[kRows];
 #pragma unroll
-        for (int k = 0; k < kRows; ++k) classify16(stage[sa.rslot ^ (u32)k], st16[k], q16[k]);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int k = 0; k < kRows; ++k) classify16(stripe[k], st16[k], q16[k]);
         u64 keep = ek.back_round == (u32)r ? ek.back_keep : ~0ull;
         if (r == 0) keep &= ek.front_keep;
         const u64 st = ((u64)(st16[0] | (st16[1] << 16)) | ((u64)(st16[2] | (st16[3] << 16)) << 32)) & keep;
@@ -494,6 +516,9 @@ __device__ __forceinline__ void emit_span(const KernelArgs& args, const RoundMas
                 run += n_win;
             }
         }
+        // keep the rounds sequential: interleaving all eight scans costs ~40 VGPRs
+        asm volatile("" : "+s"(fill), "+s"(run));
+        __builtin_amdgcn_sched_barrier(0);
     }
     wave_lds_fence();
     flush_window(args, comp, fill, run, span_off, lane);
@@ -501,9 +526,10 @@ __device__ __forceinline__ void emit_span(const KernelArgs& args, const RoundMas
 }
 
 // DBG (development probes only, never used by the product entry points): 0 = normal,
-// bit 0 = skip classification (loads only), bit 1 = static tiles (no ticket), bit 2 = no look-back
+// bit 0 = skip classification (loads only), bit 1 = static tiles (no ticket), bit 2 = no look-back,
+// bit 3 = accumulate per-phase s_memrealtime stamps of waves 0 and 1 into tot_struct[8..] (timing build)
 template <bool EMIT, int DBG = 0>
-__global__ __launch_bounds__(kThreads) void stage1_kernel(const KernelArgs args) {
+__global__ __launch_bounds__(kThreads, 4) void stage1_kernel(const KernelArgs args) {
     __shared__ u32 s_tile;
     __shared__ u32 s_wdesc[kWaves][3];
     __shared__ u32 s_pin;
@@ -512,6 +538,7 @@ __global__ __launch_bounds__(kThreads) void stage1_kernel(const KernelArgs args)
     // wave-private 4-KiB image: input transpose in the count phase, u16 compaction window in the
     // emit phase (the two uses never overlap in time within a wave)
     __shared__ uint4 s_stage[kWaves][kRoundBytes / 16];
+    __shared__ uint4 s_stage_b[kWaves][kRoundBytes / 16];  // second input image (rounds 1, 3, 5, 7)
     static_assert(kCompCap * 2 <= kRoundBytes, "compaction window must fit the stage image");
 
     const u32 t = threadIdx.x;
@@ -536,9 +563,19 @@ __global__ __launch_bounds__(kThreads) void stage1_kernel(const KernelArgs args)
     // Tile ids come from an atomic ticket drawn when the workgroup is ready to start the tile, so
     // that tiles start (and finish) in nearly ticket order whatever the dispatch order was —
     // drawing the ticket early was measured: it scrambles the start order and costs 40 %.
+    u64 prof[6] = {0, 0, 0, 0, 0, 0};
+    u64 stamp = 0;
+#define CSVSIMD_STAMP(k)                                              \
+    if (DBG & 8) {                                                    \
+        const u64 now_ = __builtin_amdgcn_s_memrealtime();            \
+        prof[k] += now_ - stamp;                                      \
+        stamp = now_;                                                 \
+    }
+    if (DBG & 8) stamp = __builtin_amdgcn_s_memrealtime();
     for (u32 iter = 0;; ++iter) {
         if (t == 0) s_tile = (DBG & 2) ? blockIdx.x + iter * gridDim.x : atomicAdd(args.ticket, 1u);
         __syncthreads();
+        CSVSIMD_STAMP(0)  // ticket + barrier
         const u32 tile = (u32)__builtin_amdgcn_readfirstlane((int)s_tile);
         const bool have_cur = tile < args.num_tiles;
         if (!have_cur && !have_held) break;
@@ -574,7 +611,7 @@ __global__ __launch_bounds__(kThreads) void stage1_kernel(const KernelArgs args)
                 }
                 cnt_a = acc & 1u;
             } else {
-                count_phase(rsrc, lane, w, ek, s_stage[w], sa, m, carry, cnt_a, cnt_t);
+                count_phase(rsrc, lane, w, ek, s_stage[w], s_stage_b[w], sa, m, carry, cnt_a, cnt_t);
             }
             const u32 wave_a = wave_sum(cnt_a);
             const u32 wave_t = wave_sum(cnt_t);
@@ -584,7 +621,9 @@ __global__ __launch_bounds__(kThreads) void stage1_kernel(const KernelArgs args)
                 s_wdesc[w][2] = wave_t - wave_a;
             }
         }
+        CSVSIMD_STAMP(1)  // count phase
         __syncthreads();
+        CSVSIMD_STAMP(2)  // barrier A
 
         if (have_cur) {
             // ---- tile aggregate; this wave's entering state/offset relative to the tile ------
@@ -620,7 +659,9 @@ __global__ __launch_bounds__(kThreads) void stage1_kernel(const KernelArgs args)
                 }
             }
         }
+        CSVSIMD_STAMP(3)  // publish + resolve (wave 0)
         __syncthreads();
+        CSVSIMD_STAMP(4)  // barrier B
         if (EMIT && have_held) {
             const u32 pin = s_pin;
             // state entering this wave's span and tape index of its first entry
@@ -636,7 +677,14 @@ __global__ __launch_bounds__(kThreads) void stage1_kernel(const KernelArgs args)
         held_before = before;
 #pragma unroll
         for (int r = 0; r < kRounds; ++r) held[r] = m[r];
+        CSVSIMD_STAMP(5)  // emit
     }
+    if ((DBG & 8) && lane == 0 && w < 2) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            atomicAdd((unsigned long long*)(args.tot_struct + 8 + w * 8 + k), (unsigned long long)prof[k]);
+    }
+#undef CSVSIMD_STAMP
     // the barrier at the loop head ordered every wave's s_err store of earlier tiles
     if (t == 0 && s_err) args.result->error = 1;
 }
@@ -826,6 +874,10 @@ hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream) {
             hipLaunchKernelGGL((stage1_kernel<false, 6>), dim3(grid), dim3(kThreads), 0, stream, a);
         else if (L.debug_mode == 7)
             hipLaunchKernelGGL((stage1_kernel<false, 7>), dim3(grid), dim3(kThreads), 0, stream, a);
+        else if (L.debug_mode == 8 && a.tape)
+            hipLaunchKernelGGL((stage1_kernel<true, 8>), dim3(grid), dim3(kThreads), 0, stream, a);
+        else if (L.debug_mode == 8)
+            hipLaunchKernelGGL((stage1_kernel<false, 8>), dim3(grid), dim3(kThreads), 0, stream, a);
         else if (a.tape)
             hipLaunchKernelGGL((stage1_kernel<true, 0>), dim3(grid), dim3(kThreads), 0, stream, a);
         else
