@@ -397,6 +397,14 @@ int csvsimd_create(csvsimd_ctx* ctx, const char* filename, csvsimd_tape** out) {
 
 /* ---- utilities ------------------------------------------------------------------------------ */
 
+// development aid (not part of include/csvsimd.h): copies the look-back scratch block to the host
+int csvsimd_debug_copy_scratch(csvsimd_ctx* ctx, void* dst, uint64_t bytes) {
+    if (!ctx || !dst || bytes > ctx->scratch_bytes) return CSVSIMD_ERR_INVALID_ARG;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(dst, ctx->scratch, bytes, hipMemcpyDeviceToHost));
+    return CSVSIMD_OK;
+}
+
 int csvsimd_synth_fill_device(void* dbuf, uint64_t file_off, uint64_t len, uint32_t cols, uint32_t width,
                               uint64_t seed, uint32_t quote_pct, void* hip_stream) {
     if ((len && !dbuf) || cols == 0 || width == 0 || ((uintptr_t)dbuf & 3)) return CSVSIMD_ERR_INVALID_ARG;
@@ -478,11 +486,14 @@ int csvsimd_stage1_time_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len,
         uint64_t h[24];
         HIP_TRY(hipMemcpy(h, (char*)ctx->scratch + 16, sizeof h, hipMemcpyDeviceToHost));
         const double nwg = (double)std::min<uint64_t>(L.max_blocks, (len + CSVSIMD_TILE_BYTES - 1) / CSVSIMD_TILE_BYTES);
-        static const char* names[6] = {"ticket+barrier", "count phase", "barrier A", "publish+resolve", "barrier B", "emit"};
-        for (int wv = 0; wv < 2; ++wv)
-            for (int k = 0; k < 6; ++k)
-                fprintf(stderr, "PROF wave%d %-16s %.2f us per workgroup (sum over its tiles)\n", wv, names[k],
-                        (double)h[8 + wv * 8 + k] / nwg / 100.0);
+        static const char* cn[4] = {"barrier T", "count phase", "barrier A", "emit"};
+        static const char* kn[4] = {"barrier T", "resolve", "barrier A", "publish+ticket"};
+        for (int k = 0; k < 4; ++k)
+            fprintf(stderr, "PROF compute0 %-15s %.2f us per workgroup (sum over its tiles)\n", cn[k],
+                    (double)h[8 + k] / nwg / 100.0);
+        for (int k = 0; k < 4; ++k)
+            fprintf(stderr, "PROF control  %-15s %.2f us per workgroup (sum over its tiles)\n", kn[k],
+                    (double)h[16 + k] / nwg / 100.0);
     }
     return CSVSIMD_OK;
 }

@@ -38,8 +38,11 @@ namespace csvsimd {
 // ---------------------------------------------------------------------------------------------
 // geometry
 // ---------------------------------------------------------------------------------------------
-static constexpr int kWaves = 4;                        // waves per workgroup
-static constexpr int kThreads = kWaves * 64;            // 256
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+static constexpr int kWaves = 4;                        // COMPUTE waves per workgroup (one span each)
+static constexpr int kThreads = (kWaves + 1) * 64;      // + one control wave: ticket, publish, look-back
 static constexpr int kRows = 4;                         // 1-KiB rows (dwordx4 wave loads) per round
 static constexpr int kRoundBytes = kRows * 1024;        // 4 KiB per wave per round = 64 stripes of 64 B
 static constexpr int kRounds = 8;                       // rounds per wave per tile
@@ -52,14 +55,19 @@ static constexpr int kLoadAux = 2;                      // buffer-load cache pol
 
 static_assert(kTileBytes == CSVSIMD_TILE_BYTES, "tile geometry must match the host header");
 
-// descriptor word: [63:62] status, [61] parity/state, aggregate: [47:24] B, [23:0] A
-//                                                     inclusive: [60:0] running count
-static constexpr uint64_t kStatusAgg = 1ull << 62;
-static constexpr uint64_t kStatusInc = 2ull << 62;
+// descriptor word = two 32-bit halves, EACH tagged with the 2-bit status in its top bits:
+//   lo = status << 30 | x[29:0]     hi = status << 30 | x[59:30]
+//   aggregate  (status 1): x = P | A << 1 | B << 25          (A, B < 2^24)
+//   inclusive  (status 2): x = state | running_count << 1    (count < 2^59)
+// A word is valid only if both halves carry the same status.  Measured on MI355X: a 64-bit sc1
+// load that races with the aggregate -> inclusive rewrite of the same word can return one half of
+// each (observed as "status = aggregate, payload = an inclusive count", ~1 in 10^5 polls once the
+// look-back polls words while they are being rewritten); the duplicated tag turns that into a
+// harmless "not published yet".
+static constexpr u32 kStatusAgg = 1u;
+static constexpr u32 kStatusInc = 2u;
 static constexpr uint32_t kSpinLimit = 1u << 24;
 
-typedef uint32_t u32;
-typedef uint64_t u64;
 
 // ---------------------------------------------------------------------------------------------
 // wavefront primitives (wave64)
@@ -163,6 +171,17 @@ __device__ __forceinline__ Desc wave_compose_ordered(Desc f, u32 lane, u32 m) {
 // single-pass look-back (wave 0 of the workgroup).  Returns entering state and tape base of
 // `tile`, publishes this tile's aggregate and inclusive words.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 encode_desc(u32 status, u64 x) {
+    const u32 lo = (status << 30) | (u32)(x & 0x3fffffffu);
+    const u32 hi = (status << 30) | (u32)((x >> 30) & 0x3fffffffu);
+    return ((u64)hi << 32) | lo;
+}
+// status (0 = not published or torn) and 60-bit payload
+__device__ __forceinline__ u32 decode_desc(u64 d, u64& x) {
+    const u32 lo = (u32)d, hi = (u32)(d >> 32);
+    x = (u64)(lo & 0x3fffffffu) | ((u64)(hi & 0x3fffffffu) << 30);
+    return (lo >> 30) == (hi >> 30) ? (lo >> 30) : 0u;
+}
 __device__ __forceinline__ void store_desc(u64* p, u64 v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -171,7 +190,7 @@ __device__ __forceinline__ u64 load_desc(const u64* p) {
 }
 
 __device__ __forceinline__ void publish_aggregate(u64* desc, u32 tile, Desc agg) {
-    store_desc(desc + tile, kStatusAgg | ((u64)agg.p << 61) | ((u64)agg.b << 24) | (u64)agg.a);
+    store_desc(desc + tile, encode_desc(kStatusAgg, (u64)agg.p | ((u64)agg.a << 1) | ((u64)agg.b << 25)));
 }
 
 // Resolves the entering state and tape base of `tile` (whose aggregate is already published) and
@@ -189,20 +208,20 @@ __device__ __forceinline__ void resolve(u64* desc, u32 tile, Desc agg, u32 in_qu
     u32 spins = 0;
     for (;;) {
         // lane k holds window positions 4k .. 4k+3 (position 0 = nearest predecessor)
-        u64 d[4];
+        u64 d[4], x[4];
         u32 linv = 4, linc = 4;  // first invalid / first inclusive among this lane's four
 #pragma unroll
         for (int i = 3; i >= 0; --i) {
             const int64_t j = hi - (int64_t)(4 * lane + i);
             // virtual tile -1 = inclusive (in_quote_in, 0): the shard's entering state
-            d[i] = kStatusInc | ((u64)in_quote_in << 61);
+            d[i] = encode_desc(kStatusInc, (u64)in_quote_in);
             if (j >= 0) d[i] = load_desc(desc + j);
         }
 #pragma unroll
         for (int i = 3; i >= 0; --i) {
-            const u32 status = (u32)(d[i] >> 62);
+            const u32 status = decode_desc(d[i], x[i]);
             if (status == 0) linv = (u32)i;
-            if (status == 2) linc = (u32)i;
+            if (status == kStatusInc) linc = (u32)i;
         }
         const u64 minv = __ballot(linv < 4);
         const u64 minc = __ballot(linc < 4);
@@ -222,9 +241,9 @@ __device__ __forceinline__ void resolve(u64* desc, u32 tile, Desc agg, u32 in_qu
 #pragma unroll
         for (int i = 3; i >= 0; --i) {
             Desc g;
-            g.p = (u32)(d[i] >> 61) & 1u;
-            g.a = (u32)d[i] & 0xffffffu;
-            g.b = (u32)(d[i] >> 24) & 0xffffffu;
+            g.p = (u32)x[i] & 1u;
+            g.a = (u32)(x[i] >> 1) & 0xffffffu;
+            g.b = (u32)(x[i] >> 25) & 0xffffffu;
             if (4 * lane + (u32)i >= limit) { g.p = 0; g.a = 0; g.b = 0; }
             f = compose(f, g);
         }
@@ -234,12 +253,12 @@ __device__ __forceinline__ void resolve(u64* desc, u32 tile, Desc agg, u32 in_qu
         const u32 Fb = (u32)__builtin_amdgcn_readfirstlane((int)F.b);
         if (done) {
             const u32 sel = first_inc & 3u;  // wave-uniform
-            const u64 dsel = sel == 0 ? d[0] : sel == 1 ? d[1] : sel == 2 ? d[2] : d[3];
-            const u32 dlo = (u32)__builtin_amdgcn_readlane((int)(u32)dsel, (int)(first_inc >> 2));
-            const u32 dhi = (u32)__builtin_amdgcn_readlane((int)(u32)(dsel >> 32), (int)(first_inc >> 2));
-            const u64 dinc = ((u64)dhi << 32) | dlo;
-            u32 st = (u32)(dinc >> 61) & 1u;
-            u64 n = dinc & ((1ull << 61) - 1);
+            const u64 xsel = sel == 0 ? x[0] : sel == 1 ? x[1] : sel == 2 ? x[2] : x[3];
+            const u32 xlo = (u32)__builtin_amdgcn_readlane((int)(u32)xsel, (int)(first_inc >> 2));
+            const u32 xhi = (u32)__builtin_amdgcn_readlane((int)(u32)(xsel >> 32), (int)(first_inc >> 2));
+            const u64 xinc = ((u64)xhi << 32) | xlo;
+            u32 st = (u32)xinc & 1u;
+            u64 n = xinc >> 1;
             n += st ? Fb : Fa;
             st ^= Fp;
             n += st ? acc_b : acc_a;
@@ -262,7 +281,7 @@ __device__ __forceinline__ void resolve(u64* desc, u32 tile, Desc agg, u32 in_qu
     }
     const u32 state_out = pin ^ agg.p;
     const u64 count_out = base + (pin ? agg.b : agg.a);
-    if (lane == 0) store_desc(desc + tile, kStatusInc | ((u64)state_out << 61) | count_out);
+    if (lane == 0) store_desc(desc + tile, encode_desc(kStatusInc, (u64)state_out | (count_out << 1)));
     pin_out = pin;
     base_out = base;
 }
@@ -527,42 +546,57 @@ __device__ __forceinline__ void emit_span(const KernelArgs& args, const RoundMas
 
 // DBG (development probes only, never used by the product entry points): 0 = normal,
 // bit 0 = skip classification (loads only), bit 1 = static tiles (no ticket), bit 2 = no look-back,
-// bit 3 = accumulate per-phase s_memrealtime stamps of waves 0 and 1 into tot_struct[8..] (timing build)
+// bit 3 = accumulate per-phase s_memrealtime stamps of compute wave 0 and of the control wave into
+//         tot_struct[8..] (timing build)
+//
+// Workgroup = kWaves compute waves + 1 control wave, two barriers per tile (T: tile id known,
+// A: wave descriptors written).  Iteration i of every wave:
+//
+//   compute wave                                   control wave
+//   ------------                                   ------------
+//   barrier T                                      barrier T
+//   count phase of tile_i (masks -> registers)     resolve tile_{i-1}: look-back, publish inclusive,
+//   write wave descriptor                            leave (state, base) in LDS      [may spin]
+//   barrier A                                      barrier A
+//   emit tile_{i-1} from the held masks            compose + publish aggregate of tile_i,
+//   hold tile_i                                      draw the ticket for tile_{i+1}
+//
+// Measured reasons for this shape (MI355X): a cross-XCD poll queues behind the CU's own streaming
+// loads (3-5 us) and tiles complete every ~30 ns chip-wide, so (a) a look-back done by a compute
+// wave between count and emit costs 12-25 % of the tile time, however it is scheduled, and (b) it
+// must start as early as possible, because every microsecond of delay before the inclusive word is
+// published adds ~30 tiles to everybody else's look-back window.  The control wave takes every
+// memory round trip that is not streaming (ticket, descriptor polls) off the compute waves' path:
+// it resolves tile_{i-1} while they stream tile_i, and they only ever meet it at a barrier.
+// Count phases never wait on anything but their own loads, so every aggregate is eventually
+// published by a running workgroup: the look-back always terminates (tickets give forward progress
+// without any residency assumption).
+// Workgroup barrier that also drains this wave's LDS traffic first.  hipcc (ROCm 7.2) was observed to
+// emit a bare s_barrier for __syncthreads() when the preceding ds_write sits in a predecessor block
+// across a loop back-edge; the released waves' ds_reads then overtook the write (1 tile in ~10^5
+// read a stale tile id).  The wait is cheap and makes the hand-off independent of that analysis.
+__device__ __forceinline__ void wg_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 template <bool EMIT, int DBG = 0>
-__global__ __launch_bounds__(kThreads, 4) void stage1_kernel(const KernelArgs args) {
-    __shared__ u32 s_tile;
-    __shared__ u32 s_wdesc[kWaves][3];
-    __shared__ u32 s_pin;
-    __shared__ u64 s_base;
-    __shared__ u32 s_err;
-    // wave-private 4-KiB image: input transpose in the count phase, u16 compaction window in the
-    // emit phase (the two uses never overlap in time within a wave)
+__global__ __launch_bounds__(kThreads) void stage1_kernel(const KernelArgs args) {
+    __shared__ u32 s_tile[2];               // by iteration parity
+    __shared__ u32 s_wdesc[2][kWaves][3];   // by iteration parity
+    __shared__ u32 s_pin[2];                // by parity of the iteration that COUNTED the tile
+    __shared__ u64 s_base[2];
+    // wave-private images: input transpose in the count phase (two, double-buffered LDS-DMA), u16
+    // compaction window in the emit phase (the uses never overlap in time within a wave)
     __shared__ uint4 s_stage[kWaves][kRoundBytes / 16];
-    __shared__ uint4 s_stage_b[kWaves][kRoundBytes / 16];  // second input image (rounds 1, 3, 5, 7)
+    __shared__ uint4 s_stage_b[kWaves][kRoundBytes / 16];
     static_assert(kCompCap * 2 <= kRoundBytes, "compaction window must fit the stage image");
 
     const u32 t = threadIdx.x;
     const u32 lane = t & 63u;
     const u32 w = (u32)__builtin_amdgcn_readfirstlane((int)(t >> 6));
-    if (t == 0) s_err = 0;
-    const StageAddr sa = stage_addr_of_lane(lane);
+    const bool is_control = w == (u32)kWaves;
 
-    // The tile whose count phase ran in the PREVIOUS iteration is held in registers (masks of the
-    // whole span + its descriptors) and is resolved and emitted one iteration later, after the next
-    // tile's count phase.  Measured reason: a tile can only resolve once every predecessor back to
-    // the nearest inclusive word (~100 tiles at MI355X's poll latency) has published, so resolving
-    // right away makes every workgroup wait for the slowest of its ~100 concurrently running
-    // predecessors (-25 % throughput).  One tile-time later they have all long published and the
-    // look-back is one or two polls with no spinning.  Count phases never wait on anything, so
-    // forward progress holds: every aggregate is eventually published by a running workgroup.
-    RoundMasks held[kRounds];
-    Desc held_agg = {0, 0, 0}, held_before = {0, 0, 0};
-    u32 held_tile = 0;
-    bool have_held = false;
-
-    // Tile ids come from an atomic ticket drawn when the workgroup is ready to start the tile, so
-    // that tiles start (and finish) in nearly ticket order whatever the dispatch order was —
-    // drawing the ticket early was measured: it scrambles the start order and costs 40 %.
     u64 prof[6] = {0, 0, 0, 0, 0, 0};
     u64 stamp = 0;
 #define CSVSIMD_STAMP(k)                                              \
@@ -572,16 +606,92 @@ __global__ __launch_bounds__(kThreads, 4) void stage1_kernel(const KernelArgs ar
         stamp = now_;                                                 \
     }
     if (DBG & 8) stamp = __builtin_amdgcn_s_memrealtime();
+
+    if (is_control) {
+        // =========================== control wave ==============================================
+        u32 err = 0;
+        if (lane == 0) {
+            s_tile[0] = (DBG & 2) ? blockIdx.x : atomicAdd(args.ticket, 1u);
+        }
+        Desc held_agg = {0, 0, 0};
+        u32 held_tile = 0;
+        bool have_held = false;
+        for (u32 iter = 0;; ++iter) {
+            const u32 par = iter & 1u;
+            wg_barrier();  // barrier T
+            CSVSIMD_STAMP(0)
+            const u32 tile = (u32)__builtin_amdgcn_readfirstlane((int)s_tile[par]);
+            const bool have_cur = tile < args.num_tiles;
+            if (!have_cur && !have_held) break;
+            if (have_held) {
+                // tile_{i-1}: its aggregate went out right after the previous barrier A
+                u32 pin = 0;
+                u64 base = 0;
+                if (!(DBG & 4)) resolve(args.desc, held_tile, held_agg, args.in_quote_in, lane, pin, base, err);
+                if (lane == 0) {
+                    s_pin[par ^ 1u] = pin;
+                    s_base[par ^ 1u] = base;
+                    if (held_tile == args.num_tiles - 1) {
+                        const u64 count = base + (pin ? held_agg.b : held_agg.a);
+                        args.result->count = count;
+                        args.result->in_quote_out = pin ^ held_agg.p;
+                        args.result->quote_parity = pin ^ held_agg.p ^ args.in_quote_in;
+                        args.result->written = count < args.tape_cap ? count : args.tape_cap;
+                    }
+                }
+            }
+            CSVSIMD_STAMP(1)
+            wg_barrier();  // barrier A
+            CSVSIMD_STAMP(2)
+            Desc agg = {0, 0, 0};
+            if (have_cur) {
+#pragma unroll
+                for (int k = 0; k < kWaves; ++k) {
+                    Desc d = {s_wdesc[par][k][0], s_wdesc[par][k][1], s_wdesc[par][k][2]};
+                    agg = compose(agg, d);
+                }
+                if (lane == 0) {
+                    if (!(DBG & 4)) publish_aggregate(args.desc, tile, agg);
+                    atomicAdd((unsigned long long*)(args.tot_struct + (tile & 7u)),
+                              (unsigned long long)(agg.a + agg.b));
+                }
+            }
+            // ticket for the next iteration: its round trip hides behind the compute waves' emit
+            if (lane == 0)
+                s_tile[par ^ 1u] = (DBG & 2) ? blockIdx.x + (iter + 1) * gridDim.x : atomicAdd(args.ticket, 1u);
+            CSVSIMD_STAMP(3)
+            have_held = have_cur;
+            held_tile = tile;
+            held_agg = agg;
+        }
+        if (lane == 0 && err) args.result->error = 1;
+        if ((DBG & 8) && lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                atomicAdd((unsigned long long*)(args.tot_struct + 16 + k), (unsigned long long)prof[k]);
+        }
+        return;
+    }
+
+    // ============================== compute waves ==============================================
+    const StageAddr sa = stage_addr_of_lane(lane);
+    // The tile counted in the previous iteration is held in registers (masks of the whole span +
+    // its descriptors) and emitted one iteration later, once the control wave has resolved it.
+    RoundMasks held[kRounds];
+    Desc held_before = {0, 0, 0};
+    u32 held_tile = 0;
+    bool have_held = false;
+
     for (u32 iter = 0;; ++iter) {
-        if (t == 0) s_tile = (DBG & 2) ? blockIdx.x + iter * gridDim.x : atomicAdd(args.ticket, 1u);
-        __syncthreads();
-        CSVSIMD_STAMP(0)  // ticket + barrier
-        const u32 tile = (u32)__builtin_amdgcn_readfirstlane((int)s_tile);
+        const u32 par = iter & 1u;
+        wg_barrier();  // barrier T
+        CSVSIMD_STAMP(0)
+        const u32 tile = (u32)__builtin_amdgcn_readfirstlane((int)s_tile[par]);
         const bool have_cur = tile < args.num_tiles;
         if (!have_cur && !have_held) break;
 
         RoundMasks m[kRounds];
-        Desc agg = {0, 0, 0}, before = {0, 0, 0};
+        Desc before = {0, 0, 0};
         if (have_cur) {
             const u64 tile0 = (u64)tile * kTileBytes;  // relative to abase
             // descriptor over this tile's valid bytes, rounded up to whole 16-byte chunks (a chunk
@@ -616,84 +726,59 @@ __global__ __launch_bounds__(kThreads, 4) void stage1_kernel(const KernelArgs ar
             const u32 wave_a = wave_sum(cnt_a);
             const u32 wave_t = wave_sum(cnt_t);
             if (lane == 0) {
-                s_wdesc[w][0] = carry;
-                s_wdesc[w][1] = wave_a;
-                s_wdesc[w][2] = wave_t - wave_a;
+                s_wdesc[par][w][0] = carry;
+                s_wdesc[par][w][1] = wave_a;
+                s_wdesc[par][w][2] = wave_t - wave_a;
             }
         }
         CSVSIMD_STAMP(1)  // count phase
-        __syncthreads();
-        CSVSIMD_STAMP(2)  // barrier A
+        wg_barrier();  // barrier A
+        CSVSIMD_STAMP(2)
 
         if (have_cur) {
-            // ---- tile aggregate; this wave's entering state/offset relative to the tile ------
+            // this wave's entering state / offset relative to the tile: the waves before it
 #pragma unroll
             for (int k = 0; k < kWaves; ++k) {
-                Desc d = {s_wdesc[k][0], s_wdesc[k][1], s_wdesc[k][2]};
-                if ((u32)k == w) before = agg;
-                agg = compose(agg, d);
+                Desc d = {s_wdesc[par][k][0], s_wdesc[par][k][1], s_wdesc[par][k][2]};
+                if ((u32)k < w) before = compose(before, d);
             }
         }
-
-        if (w == 0) {
-            if (have_cur && lane == 0) {
-                if (!(DBG & 4)) publish_aggregate(args.desc, tile, agg);
-                atomicAdd((unsigned long long*)(args.tot_struct + (tile & 63u)),
-                          (unsigned long long)(agg.a + agg.b));
-            }
-            if (have_held) {
-                u32 pin = 0, err = 0;
-                u64 base = 0;
-                if (!(DBG & 4)) resolve(args.desc, held_tile, held_agg, args.in_quote_in, lane, pin, base, err);
-                if (lane == 0) {
-                    s_pin = pin;
-                    s_base = base;
-                    if (err) s_err = 1;
-                    if (held_tile == args.num_tiles - 1) {
-                        const u64 count = base + (pin ? held_agg.b : held_agg.a);
-                        args.result->count = count;
-                        args.result->in_quote_out = pin ^ held_agg.p;
-                        args.result->quote_parity = pin ^ held_agg.p ^ args.in_quote_in;
-                        args.result->written = count < args.tape_cap ? count : args.tape_cap;
-                    }
-                }
-            }
-        }
-        CSVSIMD_STAMP(3)  // publish + resolve (wave 0)
-        __syncthreads();
-        CSVSIMD_STAMP(4)  // barrier B
         if (EMIT && have_held) {
-            const u32 pin = s_pin;
-            // state entering this wave's span and tape index of its first entry
+            // tile_{i-1} was resolved by the control wave before it arrived at barrier A
+            const u32 pin = s_pin[par ^ 1u];
             const u32 wstate = pin ^ held_before.p;
-            const u64 run = s_base + (pin ? held_before.b : held_before.a);
+            const u64 run = s_base[par ^ 1u] + (pin ? held_before.b : held_before.a);
             const u64 span0 = (u64)held_tile * kTileBytes + (u64)w * kSpanBytes;
+            if ((DBG & 16) && lane == 0) {  // debug dump behind the tape: 4 words per (tile, wave)
+                u64* dbg = args.tape + args.tape_cap + ((u64)held_tile * kWaves + w) * 4;
+                dbg[0] = run;
+                dbg[1] = (u64)pin | ((u64)held_before.p << 1) | ((u64)(par ^ 1u) << 2) | ((u64)iter << 8);
+                dbg[2] = (u64)held_before.a | ((u64)held_before.b << 32);
+                dbg[3] = s_base[par ^ 1u];
+            }
             emit_span(args, held, lane, span0, wstate, run, reinterpret_cast<unsigned short*>(s_stage[w]));
         }
+        CSVSIMD_STAMP(3)  // emit
         // the tile counted in this iteration becomes the held one
         have_held = have_cur;
         held_tile = tile;
-        held_agg = agg;
         held_before = before;
 #pragma unroll
         for (int r = 0; r < kRounds; ++r) held[r] = m[r];
-        CSVSIMD_STAMP(5)  // emit
     }
-    if ((DBG & 8) && lane == 0 && w < 2) {
+    if ((DBG & 8) && lane == 0 && w == 0) {
 #pragma unroll
         for (int k = 0; k < 6; ++k)
-            atomicAdd((unsigned long long*)(args.tot_struct + 8 + w * 8 + k), (unsigned long long)prof[k]);
+            atomicAdd((unsigned long long*)(args.tot_struct + 8 + k), (unsigned long long)prof[k]);
     }
 #undef CSVSIMD_STAMP
-    // the barrier at the loop head ordered every wave's s_err store of earlier tiles
-    if (t == 0 && s_err) args.result->error = 1;
 }
 
 // sums the sharded structural-byte counters into the result (tiny, 1 wave)
 __global__ void finalize_kernel(const u64* tot_struct, csvsimd_shard_result* result, u32 in_quote_in,
                                 u32 num_tiles) {
     const u32 lane = threadIdx.x;
-    u64 v = tot_struct[lane];
+    u64 v = lane < 8 ? tot_struct[lane] : 0;  // 8 sharded counters; [8..] are timing-probe slots
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         const u32 lo = (u32)__shfl_xor((int)(u32)v, d);
@@ -874,6 +959,8 @@ hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream) {
             hipLaunchKernelGGL((stage1_kernel<false, 6>), dim3(grid), dim3(kThreads), 0, stream, a);
         else if (L.debug_mode == 7)
             hipLaunchKernelGGL((stage1_kernel<false, 7>), dim3(grid), dim3(kThreads), 0, stream, a);
+        else if (L.debug_mode == 16 && a.tape)
+            hipLaunchKernelGGL((stage1_kernel<true, 16>), dim3(grid), dim3(kThreads), 0, stream, a);
         else if (L.debug_mode == 8 && a.tape)
             hipLaunchKernelGGL((stage1_kernel<true, 8>), dim3(grid), dim3(kThreads), 0, stream, a);
         else if (L.debug_mode == 8)
