@@ -20,7 +20,6 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libcsvsimd_hip.so")
-TILE_BYTES = 128 * 1024
 
 OK = 0
 ERR_IO, ERR_MISSING_VALUE, ERR_INVALID_STATE, ERR_INVALID_CSV_FORMAT = -1, -2, -3, -4
@@ -78,6 +77,7 @@ _PROTOTYPES = {
     "csvsimd_last_error": (C.c_char_p, []),
     "csvsimd_device_count": (C.c_int, []),
     "csvsimd_abi_version": (C.c_uint32, []),
+    "csvsimd_tile_bytes": (C.c_uint32, []),
     "csvsimd_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "csvsimd_ctx_destroy": (None, [C.c_void_p]),
     "csvsimd_ctx_reserve": (C.c_int, [C.c_void_p, C.c_uint64]),
@@ -134,6 +134,10 @@ def lib() -> C.CDLL:
 def _check(rc: int) -> None:
     if rc != OK:
         raise StructureError(rc)
+
+
+def tile_bytes() -> int:
+    return lib().csvsimd_tile_bytes()
 
 
 def device_count() -> int:

@@ -76,6 +76,7 @@ int csvsimd_device_count(void) {
 }
 
 uint32_t csvsimd_abi_version(void) { return 1; }
+uint32_t csvsimd_tile_bytes(void) { return CSVSIMD_TILE_BYTES; }
 
 int csvsimd_ctx_create(int device, csvsimd_ctx** out) {
     if (!out) return CSVSIMD_ERR_INVALID_ARG;
@@ -483,9 +484,12 @@ int csvsimd_stage1_time_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len,
     for (auto& e : ev) (void)hipEventDestroy(e);
     *avg_ms = (float)(total / iters);
     if (L.debug_mode == 8) {  // development probe: print the per-phase stamps of the last launch
-        uint64_t h[24];
+        uint64_t h[32];
         HIP_TRY(hipMemcpy(h, (char*)ctx->scratch + 16, sizeof h, hipMemcpyDeviceToHost));
-        const double nwg = (double)std::min<uint64_t>(L.max_blocks, (len + CSVSIMD_TILE_BYTES - 1) / CSVSIMD_TILE_BYTES);
+        const double nwg = h[24] ? (double)h[24] : 1.0;
+        fprintf(stderr, "PROF grid %u workgroups launched, %llu drew at least one tile (normalising by the latter)\n",
+                (unsigned)std::min<uint64_t>(L.max_blocks, (len + CSVSIMD_TILE_BYTES - 1) / CSVSIMD_TILE_BYTES),
+                (unsigned long long)h[24]);
         static const char* cn[4] = {"barrier T", "count phase", "barrier A", "emit"};
         static const char* kn[4] = {"barrier T", "resolve", "barrier A", "publish+ticket"};
         for (int k = 0; k < 4; ++k)

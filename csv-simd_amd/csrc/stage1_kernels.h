@@ -5,7 +5,16 @@
 
 #include "csvsimd.h"
 
-#define CSVSIMD_TILE_BYTES (128 * 1024)
+// tile = CSVSIMD_COMPUTE_WAVES compute waves x CSVSIMD_ROUNDS rounds x 4 KiB; the workgroup has one
+// more wave (control).  Wave counts that are not a multiple of 4 waste SIMD slots: the dispatcher
+// was measured to reserve ceil(waves / 4) slots on EVERY SIMD (5-wave groups: 2 per CU, not 4).
+#ifndef CSVSIMD_ROUNDS
+#define CSVSIMD_ROUNDS 6
+#endif
+#ifndef CSVSIMD_COMPUTE_WAVES
+#define CSVSIMD_COMPUTE_WAVES 7
+#endif
+#define CSVSIMD_TILE_BYTES (CSVSIMD_COMPUTE_WAVES * CSVSIMD_ROUNDS * 4096)
 
 namespace csvsimd {
 

@@ -43,6 +43,8 @@ const char* csvsimd_strerror(int code);
 const char* csvsimd_last_error(void); /* thread-local text of the last HIP failure */
 int csvsimd_device_count(void);       /* number of HIP devices visible, 0 if none */
 uint32_t csvsimd_abi_version(void);
+/* bytes one workgroup indexes per look-back step (informational: tests probe sizes around it) */
+uint32_t csvsimd_tile_bytes(void);
 
 /* ---- context: one per (thread, device); owns the look-back scratch ------------------------ */
 typedef struct csvsimd_ctx csvsimd_ctx;

@@ -22,4 +22,4 @@ s = torch.cuda.current_stream().cuda_stream
 os.environ["CSVSIMD_PROBE_MODE"] = "8"
 for label, tp, c in (("EMIT", dtape.data_ptr(), cap), ("COUNT-ONLY", 0, 0)):
     ms = ctx.stage1_time_device(dbuf.data_ptr(), n, tp, c, dres.data_ptr(), s, 1, 1)
-    print(f"== {label} {name}: {ms:.4f} ms, {n / ms / 1e9:.3f} TB/s, tiles/WG = {n / 131072 / 1024:.1f}", file=sys.stderr)
+    print(f"== {label} {name}: {ms:.4f} ms, {n / ms / 1e9:.3f} TB/s, tile = {pkg.tile_bytes()} B", file=sys.stderr)

@@ -106,7 +106,7 @@ def test_misaligned_base_off_and_entering_state(ctx, torch_cuda, oracle):
 def test_tile_boundaries_and_lookback(ctx, torch_cuda, pkg, oracle):
     # sizes around multiples of the 128 KiB tile; quotes make the in-string state cross tiles
     rng = np.random.default_rng(31337)
-    T = pkg.TILE_BYTES
+    T = pkg.tile_bytes()
     for n in (T - 1, T, T + 1, 2 * T - 16, 2 * T + 16, 5 * T + 12345, 37 * T + 1):
         for pq in (0.0, 0.001, 0.2):
             d = random_csvish(rng, n, pq)
@@ -117,7 +117,7 @@ def test_tile_boundaries_and_lookback(ctx, torch_cuda, pkg, oracle):
 
 
 def test_adversarial_densities(ctx, torch_cuda, pkg, oracle):
-    T = pkg.TILE_BYTES
+    T = pkg.tile_bytes()
     n = 3 * T + 1000
     cases = {
         "all_commas": np.full(n, 0x2C, dtype=np.uint8),           # 1 entry per byte: compaction windows
