@@ -19,7 +19,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libcsvsimd_hip.so")
+LIB_PATH = os.environ.get("CSVSIMD_LIB") or os.path.join(_HERE, "csrc", "libcsvsimd_hip.so")  # override: tuning variants only
 
 OK = 0
 ERR_IO, ERR_MISSING_VALUE, ERR_INVALID_STATE, ERR_INVALID_CSV_FORMAT = -1, -2, -3, -4

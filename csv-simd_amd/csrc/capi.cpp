@@ -490,14 +490,11 @@ int csvsimd_stage1_time_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len,
         fprintf(stderr, "PROF grid %u workgroups launched, %llu drew at least one tile (normalising by the latter)\n",
                 (unsigned)std::min<uint64_t>(L.max_blocks, (len + CSVSIMD_TILE_BYTES - 1) / CSVSIMD_TILE_BYTES),
                 (unsigned long long)h[24]);
-        static const char* cn[4] = {"barrier T", "count phase", "barrier A", "emit"};
-        static const char* kn[4] = {"barrier T", "resolve", "barrier A", "publish+ticket"};
-        for (int k = 0; k < 4; ++k)
-            fprintf(stderr, "PROF compute0 %-15s %.2f us per workgroup (sum over its tiles)\n", cn[k],
-                    (double)h[8 + k] / nwg / 100.0);
-        for (int k = 0; k < 4; ++k)
-            fprintf(stderr, "PROF control  %-15s %.2f us per workgroup (sum over its tiles)\n", kn[k],
-                    (double)h[16 + k] / nwg / 100.0);
+        static const char* names[6] = {"ticket+barrier T", "count phase", "barrier A", "publish+resolve", "barrier B", "emit"};
+        for (int wv = 0; wv < 2; ++wv)
+            for (int k = 0; k < 6; ++k)
+                fprintf(stderr, "PROF wave%d %-16s %.2f us per workgroup (sum over its tiles)\n", wv, names[k],
+                        (double)h[8 + wv * 8 + k] / nwg / 100.0);
     }
     return CSVSIMD_OK;
 }

@@ -5,14 +5,18 @@
 
 #include "csvsimd.h"
 
-// tile = CSVSIMD_COMPUTE_WAVES compute waves x CSVSIMD_ROUNDS rounds x 4 KiB; the workgroup has one
-// more wave (control).  Wave counts that are not a multiple of 4 waste SIMD slots: the dispatcher
-// was measured to reserve ceil(waves / 4) slots on EVERY SIMD (5-wave groups: 2 per CU, not 4).
+// tile = CSVSIMD_COMPUTE_WAVES waves x CSVSIMD_ROUNDS rounds x 4 KiB.  Keep the wave count a multiple
+// of 4: the dispatcher was measured to reserve ceil(waves / 4) slots on EVERY SIMD (5-wave
+// workgroups: 2 per CU instead of 4).
 #ifndef CSVSIMD_ROUNDS
-#define CSVSIMD_ROUNDS 6
+#define CSVSIMD_ROUNDS 8
 #endif
 #ifndef CSVSIMD_COMPUTE_WAVES
-#define CSVSIMD_COMPUTE_WAVES 7
+#define CSVSIMD_COMPUTE_WAVES 8
+#endif
+// register budget: minimum waves per SIMD the stage-1 kernel is compiled for (0 = let hipcc choose)
+#ifndef CSVSIMD_WAVES_PER_EU
+#define CSVSIMD_WAVES_PER_EU 4
 #endif
 #define CSVSIMD_TILE_BYTES (CSVSIMD_COMPUTE_WAVES * CSVSIMD_ROUNDS * 4096)
 

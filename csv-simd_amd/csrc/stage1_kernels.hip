@@ -42,7 +42,7 @@ typedef uint32_t u32;
 typedef uint64_t u64;
 
 static constexpr int kWaves = CSVSIMD_COMPUTE_WAVES;    // COMPUTE waves per workgroup (one span each)
-static constexpr int kThreads = (kWaves + 1) * 64;      // + one control wave: ticket, publish, look-back
+static constexpr int kThreads = kWaves * 64;
 static constexpr int kRows = 4;                         // 1-KiB rows (dwordx4 wave loads) per round
 static constexpr int kRoundBytes = kRows * 1024;        // 4 KiB per wave per round = 64 stripes of 64 B
 static constexpr int kRounds = CSVSIMD_ROUNDS;          // rounds per wave per tile
@@ -561,33 +561,6 @@ __device__ __forceinline__ void emit_span(const KernelArgs& args, const RoundMas
     wave_lds_fence();
 }
 
-// DBG (development probes only, never used by the product entry points): 0 = normal,
-// bit 0 = skip classification (loads only), bit 1 = static tiles (no ticket), bit 2 = no look-back,
-// bit 3 = accumulate per-phase s_memrealtime stamps of compute wave 0 and of the control wave into
-//         tot_struct[8..] (timing build)
-//
-// Workgroup = kWaves compute waves + 1 control wave, two barriers per tile (T: tile id known,
-// A: wave descriptors written).  Iteration i of every wave:
-//
-//   compute wave                                   control wave
-//   ------------                                   ------------
-//   barrier T                                      barrier T
-//   count phase of tile_i (masks -> registers)     resolve tile_{i-1}: look-back, publish inclusive,
-//   write wave descriptor                            leave (state, base) in LDS      [may spin]
-//   barrier A                                      barrier A
-//   emit tile_{i-1} from the held masks            compose + publish aggregate of tile_i,
-//   hold tile_i                                      draw the ticket for tile_{i+1}
-//
-// Measured reasons for this shape (MI355X): a cross-XCD poll queues behind the CU's own streaming
-// loads (3-5 us) and tiles complete every ~30 ns chip-wide, so (a) a look-back done by a compute
-// wave between count and emit costs 12-25 % of the tile time, however it is scheduled, and (b) it
-// must start as early as possible, because every microsecond of delay before the inclusive word is
-// published adds ~30 tiles to everybody else's look-back window.  The control wave takes every
-// memory round trip that is not streaming (ticket, descriptor polls) off the compute waves' path:
-// it resolves tile_{i-1} while they stream tile_i, and they only ever meet it at a barrier.
-// Count phases never wait on anything but their own loads, so every aggregate is eventually
-// published by a running workgroup: the look-back always terminates (tickets give forward progress
-// without any residency assumption).
 // Workgroup barrier that also drains this wave's LDS traffic first.  hipcc (ROCm 7.2) was observed to
 // emit a bare s_barrier for __syncthreads() when the preceding ds_write sits in a predecessor block
 // across a loop back-edge; the released waves' ds_reads then overtook the write (1 tile in ~10^5
@@ -597,12 +570,39 @@ __device__ __forceinline__ void wg_barrier() {
     __syncthreads();
 }
 
+// DBG (development probes only, never used by the product entry points): 0 = normal,
+// bit 0 = skip classification (loads only), bit 1 = static tiles (no ticket; only without look-back),
+// bit 2 = no look-back, bit 3 = accumulate per-phase s_memrealtime stamps of waves 0 and 1 into
+// tot_struct[8..] (timing build)
+//
+// One iteration of the workgroup loop (three barriers):
+//   ticket -> [T] -> count phase of tile_i (masks -> registers) -> [A] -> wave 0: publish the
+//   aggregate of tile_i, then resolve tile_{i-1} (look-back) -> [B] -> all waves emit tile_{i-1}.
+//
+// The tile counted in iteration i-1 is HELD in registers (masks of the whole span + descriptors)
+// and is resolved and emitted one iteration later.  Measured reasons (MI355X): a cross-XCD poll
+// queues behind the CU's own streaming loads (3-5 us) while tiles complete every ~30 ns chip-wide,
+// so a tile can only resolve once every predecessor back to the nearest inclusive word (~100-300
+// tiles) has published.  Resolving right after the own count phase makes every workgroup wait for
+// the slowest of those concurrently running predecessors (-25 % throughput); one tile-time later
+// they have all long published and the look-back is one or two polls.  Variants measured and
+// rejected: drawing the ticket early (scrambles the start order), a dedicated control wave per
+// workgroup (5-wave groups halve residency: the dispatcher reserves ceil(waves/4) slots on every
+// SIMD; 7+1-wave groups resolve early and their compute waves wait for it: 3.6 vs 4.4 TB/s).
+// Count phases never wait on anything but their own loads, so every aggregate is eventually
+// published by a running workgroup: the look-back always terminates, with no residency assumption
+// (tile ids come from an atomic ticket drawn when the workgroup is ready to start the tile).
+#if CSVSIMD_WAVES_PER_EU > 0
+#define CSVSIMD_LAUNCH_BOUNDS __launch_bounds__(kThreads, CSVSIMD_WAVES_PER_EU)
+#else
+#define CSVSIMD_LAUNCH_BOUNDS __launch_bounds__(kThreads)
+#endif
 template <bool EMIT, int DBG = 0>
-__global__ __launch_bounds__(kThreads) void stage1_kernel(const KernelArgs args) {
-    __shared__ u32 s_tile[2];               // by iteration parity
-    __shared__ u32 s_wdesc[2][kWaves][3];   // by iteration parity
-    __shared__ u32 s_pin[2];                // by parity of the iteration that COUNTED the tile
-    __shared__ u64 s_base[2];
+__global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
+    __shared__ u32 s_tile;
+    __shared__ u32 s_wdesc[kWaves][3];
+    __shared__ u32 s_pin;
+    __shared__ u64 s_base;
     // wave-private images: input transpose in the count phase (two, double-buffered LDS-DMA), u16
     // compaction window in the emit phase (the uses never overlap in time within a wave)
     __shared__ uint4 s_stage[kWaves][kRoundBytes / 16];
@@ -612,7 +612,13 @@ __global__ __launch_bounds__(kThreads) void stage1_kernel(const KernelArgs args)
     const u32 t = threadIdx.x;
     const u32 lane = t & 63u;
     const u32 w = (u32)__builtin_amdgcn_readfirstlane((int)(t >> 6));
-    const bool is_control = w == (u32)kWaves;
+    const StageAddr sa = stage_addr_of_lane(lane);
+    u32 err = 0;  // wave 0 only
+
+    RoundMasks held[kRounds];
+    Desc held_agg = {0, 0, 0}, held_before = {0, 0, 0};
+    u32 held_tile = 0;
+    bool have_held = false;
 
     u64 prof[6] = {0, 0, 0, 0, 0, 0};
     u64 stamp = 0;
@@ -624,93 +630,16 @@ __global__ __launch_bounds__(kThreads) void stage1_kernel(const KernelArgs args)
     }
     if (DBG & 8) stamp = __builtin_amdgcn_s_memrealtime();
 
-    if (is_control) {
-        // =========================== control wave ==============================================
-        u32 err = 0;
-        if (lane == 0) {
-            s_tile[0] = (DBG & 2) ? blockIdx.x : atomicAdd(args.ticket, 1u);
-        }
-        Desc held_agg = {0, 0, 0};
-        u32 held_tile = 0;
-        bool have_held = false;
-        for (u32 iter = 0;; ++iter) {
-            const u32 par = iter & 1u;
-            wg_barrier();  // barrier T
-            CSVSIMD_STAMP(0)
-            const u32 tile = (u32)__builtin_amdgcn_readfirstlane((int)s_tile[par]);
-            const bool have_cur = tile < args.num_tiles;
-            if (!have_cur && !have_held) break;
-            if (have_held) {
-                // tile_{i-1}: its aggregate went out right after the previous barrier A
-                u32 pin = 0;
-                u64 base = 0;
-                if (!(DBG & 4)) resolve(args.desc, held_tile, held_agg, args.in_quote_in, lane, pin, base, err);
-                if (lane == 0) {
-                    s_pin[par ^ 1u] = pin;
-                    s_base[par ^ 1u] = base;
-                    if (held_tile == args.num_tiles - 1) {
-                        const u64 count = base + (pin ? held_agg.b : held_agg.a);
-                        args.result->count = count;
-                        args.result->in_quote_out = pin ^ held_agg.p;
-                        args.result->quote_parity = pin ^ held_agg.p ^ args.in_quote_in;
-                        args.result->written = count < args.tape_cap ? count : args.tape_cap;
-                    }
-                }
-            }
-            CSVSIMD_STAMP(1)
-            wg_barrier();  // barrier A
-            CSVSIMD_STAMP(2)
-            Desc agg = {0, 0, 0};
-            if (have_cur) {
-#pragma unroll
-                for (int k = 0; k < kWaves; ++k) {
-                    Desc d = {s_wdesc[par][k][0], s_wdesc[par][k][1], s_wdesc[par][k][2]};
-                    agg = compose(agg, d);
-                }
-                if (lane == 0) {
-                    if (!(DBG & 4)) publish_aggregate(args.desc, tile, agg);
-                    atomicAdd((unsigned long long*)(args.tot_struct + (tile & 7u)),
-                              (unsigned long long)(agg.a + agg.b));
-                }
-            }
-            // ticket for the next iteration: its round trip hides behind the compute waves' emit
-            if (lane == 0)
-                s_tile[par ^ 1u] = (DBG & 2) ? blockIdx.x + (iter + 1) * gridDim.x : atomicAdd(args.ticket, 1u);
-            CSVSIMD_STAMP(3)
-            have_held = have_cur;
-            held_tile = tile;
-            held_agg = agg;
-        }
-        if (lane == 0 && err) args.result->error = 1;
-        if ((DBG & 8) && lane == 0) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k)
-                atomicAdd((unsigned long long*)(args.tot_struct + 16 + k), (unsigned long long)prof[k]);
-            // census: workgroups that processed at least one tile, and total kernel-side lifetime
-            if (prof[1] + prof[3] != 0) atomicAdd((unsigned long long*)(args.tot_struct + 24), 1ull);
-        }
-        return;
-    }
-
-    // ============================== compute waves ==============================================
-    const StageAddr sa = stage_addr_of_lane(lane);
-    // The tile counted in the previous iteration is held in registers (masks of the whole span +
-    // its descriptors) and emitted one iteration later, once the control wave has resolved it.
-    RoundMasks held[kRounds];
-    Desc held_before = {0, 0, 0};
-    u32 held_tile = 0;
-    bool have_held = false;
-
     for (u32 iter = 0;; ++iter) {
-        const u32 par = iter & 1u;
+        if (t == 0) s_tile = (DBG & 2) ? blockIdx.x + iter * gridDim.x : atomicAdd(args.ticket, 1u);
         wg_barrier();  // barrier T
         CSVSIMD_STAMP(0)
-        const u32 tile = (u32)__builtin_amdgcn_readfirstlane((int)s_tile[par]);
+        const u32 tile = (u32)__builtin_amdgcn_readfirstlane((int)s_tile);
         const bool have_cur = tile < args.num_tiles;
         if (!have_cur && !have_held) break;
 
         RoundMasks m[kRounds];
-        Desc before = {0, 0, 0};
+        Desc agg = {0, 0, 0}, before = {0, 0, 0};
         if (have_cur) {
             const u64 tile0 = (u64)tile * kTileBytes;  // relative to abase
             // descriptor over this tile's valid bytes, rounded up to whole 16-byte chunks (a chunk
@@ -745,50 +674,74 @@ __global__ __launch_bounds__(kThreads) void stage1_kernel(const KernelArgs args)
             const u32 wave_a = wave_sum(cnt_a);
             const u32 wave_t = wave_sum(cnt_t);
             if (lane == 0) {
-                s_wdesc[par][w][0] = carry;
-                s_wdesc[par][w][1] = wave_a;
-                s_wdesc[par][w][2] = wave_t - wave_a;
+                s_wdesc[w][0] = carry;
+                s_wdesc[w][1] = wave_a;
+                s_wdesc[w][2] = wave_t - wave_a;
             }
         }
         CSVSIMD_STAMP(1)  // count phase
-        wg_barrier();  // barrier A
+        wg_barrier();     // barrier A
         CSVSIMD_STAMP(2)
 
         if (have_cur) {
-            // this wave's entering state / offset relative to the tile: the waves before it
+            // ---- tile aggregate; this wave's entering state/offset relative to the tile ------
 #pragma unroll
             for (int k = 0; k < kWaves; ++k) {
-                Desc d = {s_wdesc[par][k][0], s_wdesc[par][k][1], s_wdesc[par][k][2]};
-                if ((u32)k < w) before = compose(before, d);
+                Desc d = {s_wdesc[k][0], s_wdesc[k][1], s_wdesc[k][2]};
+                if ((u32)k == w) before = agg;
+                agg = compose(agg, d);
             }
         }
-        if (EMIT && have_held) {
-            // tile_{i-1} was resolved by the control wave before it arrived at barrier A
-            const u32 pin = s_pin[par ^ 1u];
-            const u32 wstate = pin ^ held_before.p;
-            const u64 run = s_base[par ^ 1u] + (pin ? held_before.b : held_before.a);
-            const u64 span0 = (u64)held_tile * kTileBytes + (u64)w * kSpanBytes;
-            if ((DBG & 16) && lane == 0) {  // debug dump behind the tape: 4 words per (tile, wave)
-                u64* dbg = args.tape + args.tape_cap + ((u64)held_tile * kWaves + w) * 4;
-                dbg[0] = run;
-                dbg[1] = (u64)pin | ((u64)held_before.p << 1) | ((u64)(par ^ 1u) << 2) | ((u64)iter << 8);
-                dbg[2] = (u64)held_before.a | ((u64)held_before.b << 32);
-                dbg[3] = s_base[par ^ 1u];
+
+        if (w == 0) {
+            if (have_cur && lane == 0) {
+                if (!(DBG & 4)) publish_aggregate(args.desc, tile, agg);
+                atomicAdd((unsigned long long*)(args.tot_struct + (tile & 7u)),
+                          (unsigned long long)(agg.a + agg.b));
             }
+            if (have_held) {
+                u32 pin = 0;
+                u64 base = 0;
+                if (!(DBG & 4)) resolve(args.desc, held_tile, held_agg, args.in_quote_in, lane, pin, base, err);
+                if (lane == 0) {
+                    s_pin = pin;
+                    s_base = base;
+                    if (held_tile == args.num_tiles - 1) {
+                        const u64 count = base + (pin ? held_agg.b : held_agg.a);
+                        args.result->count = count;
+                        args.result->in_quote_out = pin ^ held_agg.p;
+                        args.result->quote_parity = pin ^ held_agg.p ^ args.in_quote_in;
+                        args.result->written = count < args.tape_cap ? count : args.tape_cap;
+                    }
+                }
+            }
+        }
+        CSVSIMD_STAMP(3)  // publish + resolve (wave 0)
+        wg_barrier();     // barrier B
+        CSVSIMD_STAMP(4)
+        if (EMIT && have_held) {
+            const u32 pin = s_pin;
+            // state entering this wave's span and tape index of its first entry
+            const u32 wstate = pin ^ held_before.p;
+            const u64 run = s_base + (pin ? held_before.b : held_before.a);
+            const u64 span0 = (u64)held_tile * kTileBytes + (u64)w * kSpanBytes;
             emit_span(args, held, lane, span0, wstate, run, reinterpret_cast<unsigned short*>(s_stage[w]));
         }
-        CSVSIMD_STAMP(3)  // emit
         // the tile counted in this iteration becomes the held one
         have_held = have_cur;
         held_tile = tile;
+        held_agg = agg;
         held_before = before;
 #pragma unroll
         for (int r = 0; r < kRounds; ++r) held[r] = m[r];
+        CSVSIMD_STAMP(5)  // emit
     }
-    if ((DBG & 8) && lane == 0 && w == 0) {
+    if (w == 0 && lane == 0 && err) args.result->error = 1;
+    if ((DBG & 8) && lane == 0 && w < 2) {
 #pragma unroll
         for (int k = 0; k < 6; ++k)
-            atomicAdd((unsigned long long*)(args.tot_struct + 8 + k), (unsigned long long)prof[k]);
+            atomicAdd((unsigned long long*)(args.tot_struct + 8 + w * 8 + k), (unsigned long long)prof[k]);
+        if (w == 0) atomicAdd((unsigned long long*)(args.tot_struct + 24), 1ull);
     }
 #undef CSVSIMD_STAMP
 }
@@ -978,8 +931,6 @@ hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream) {
             hipLaunchKernelGGL((stage1_kernel<false, 6>), dim3(grid), dim3(kThreads), 0, stream, a);
         else if (L.debug_mode == 7)
             hipLaunchKernelGGL((stage1_kernel<false, 7>), dim3(grid), dim3(kThreads), 0, stream, a);
-        else if (L.debug_mode == 16 && a.tape)
-            hipLaunchKernelGGL((stage1_kernel<true, 16>), dim3(grid), dim3(kThreads), 0, stream, a);
         else if (L.debug_mode == 8 && a.tape)
             hipLaunchKernelGGL((stage1_kernel<true, 8>), dim3(grid), dim3(kThreads), 0, stream, a);
         else if (L.debug_mode == 8)
