@@ -154,7 +154,8 @@ def main():
         sys.exit("bench.py needs a GPU: the product path has no CPU fallback")
     if rank == 0:
         build_if_needed()
-    dist_on = world > 1
+    # under torch.distributed.run the collective path is exercised even with a single rank
+    dist_on = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("CSVSIMD_BENCH_FORCE_DIST") == "1"
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     if dist_on:

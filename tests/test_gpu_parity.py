@@ -276,3 +276,24 @@ def test_config4_shard_8gib_analytic(ctx, torch_cuda, pkg):
     assert r.count == S and r.error == 0 and r.in_quote_out == 0
     want = torch.arange(0, S, dtype=torch.int64, device="cuda:0") * (width + 1) + first
     assert torch.equal(dtape[:S], want)
+
+
+def test_repeatability_stress(ctx, torch_cuda, pkg):
+    # The look-back is a concurrent protocol: one green run proves little.  Re-run the 1 GiB quoted
+    # corpus many times (emitting and count-only kernels) and demand identical counts and tapes.
+    # (This test is what exposed a stale-tile-id race at ~1 in 10^5 tiles during development.)
+    torch = torch_cuda
+    n, dbuf, dtape, r0, (cols, width, seed, q) = run_workload(ctx, torch, pkg, "16x32_q10", 1 << 30)
+    S = n // (width + 1)
+    assert r0.count == S
+    ref = dtape[:S].clone()
+    cap = dtape.numel()
+    for rep in range(25):
+        dtape.fill_(-1)
+        r = ctx.stage1_index_device(dbuf.data_ptr(), n, 0, 0, dtape.data_ptr(), cap)
+        assert (r.count, r.in_quote_out, r.error) == (S, 0, 0), rep
+        assert torch.equal(dtape[:S], ref), rep
+        assert bool((dtape[S:] == -1).all())
+    for rep in range(50):
+        r = ctx.stage1_index_device(dbuf.data_ptr(), n)
+        assert (r.count, r.count_enter_outside, r.in_quote_out) == (S, S, 0), rep
