@@ -61,23 +61,25 @@ class ShardBench:
         self.ctx.reserve(self.n)
         torch.cuda.synchronize(device)
 
-    def run_pass(self, in_quote_in):
+    def launch(self, in_quote_in):
+        """Enqueue stage 1 over this rank's shard (asynchronous; result record -> d_result)."""
         s = torch.cuda.current_stream(self.device)
         self.ctx.stage1_index_device_async(self.dbuf.data_ptr(), self.n, self.lo, in_quote_in,
                                            self.dtape.data_ptr(), self.cap, self.d_result.data_ptr(),
                                            s.cuda_stream)
-        self.h_result.copy_(self.d_result, non_blocking=True)
-        s.synchronize()
-        h = self.h_result
-        r = self.pkg.ShardResult()
-        r.count, r.count_enter_outside, r.count_enter_inside = int(h[0]), int(h[1]), int(h[2])
-        r.quote_parity = int(h[3]) & 0xFFFFFFFF
-        r.in_quote_out = (int(h[3]) >> 32) & 0xFFFFFFFF
-        r.error = int(h[4]) & 0xFFFFFFFF
-        r.written = int(h[5])
+
+    def check(self, r):
         if r.error or r.count > self.cap:
             raise RuntimeError(f"stage1 failed: error={r.error} count={r.count} cap={self.cap}")
         return r
+
+    def run_pass(self, in_quote_in):
+        """Single-GPU step: launch, then read the result record back (the only synchronisation)."""
+        from csv_simd_amd import sharded
+        self.launch(in_quote_in)
+        self.h_result.copy_(self.d_result, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return self.check(sharded.result_from_words(self.h_result.tolist()))
 
 
 def time_steps(step, steps, warmup, device, dist_on):
@@ -171,7 +173,8 @@ def main():
 
     def step():
         if dist_on:
-            st, final, re = sharded.index_sharded(sb.run_pass, device)
+            st, final, re = sharded.index_sharded(sb.launch, sb.d_result)
+            sb.check(final)
             state["count"], state["re"] = st.count, re
             state["total_entries"] = st.total_entries
         else:

@@ -197,22 +197,28 @@ class Context:
 
     # ---- reader::read(&Mmap) -> StructureIndex (src/reader.rs:150) ---------------------------
     def read(self, data) -> np.ndarray:
-        """Host bytes -> index (uint64 array, [0] == 0 sentinel). Two passes: count, then fill."""
+        """Host bytes -> index (uint64 array, [0] == 0 sentinel).  One pass with a capacity guess
+        (one entry per 8 bytes), one exact retry if the file is denser — the protocol of
+        include/csvsimd.h, same as the Rust binding."""
         a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
         a = np.ascontiguousarray(a, dtype=np.uint8)
         n = C.c_uint64()
         ptr = a.ctypes.data if a.size else None
-        _check(lib().csvsimd_stage1_index(self._h, ptr, a.size, None, 0, C.byref(n), None))
-        out = np.empty(n.value, dtype=np.uint64)
-        _check(lib().csvsimd_stage1_index(self._h, ptr, a.size, out.ctypes.data, out.size, C.byref(n), None))
-        return out[: n.value]
+        out = np.empty(a.size // 8 + 64, dtype=np.uint64)
+        rc = lib().csvsimd_stage1_index(self._h, ptr, a.size, out.ctypes.data, out.size, C.byref(n), None)
+        if rc == ERR_TAPE_CAPACITY:
+            out = np.empty(n.value, dtype=np.uint64)
+            rc = lib().csvsimd_stage1_index(self._h, ptr, a.size, out.ctypes.data, out.size, C.byref(n), None)
+        _check(rc)
+        return out[: n.value].copy()
 
     def read_into(self, data: np.ndarray, tape: np.ndarray) -> Tuple[int, int, int]:
         """Raw csvsimd_stage1_index: returns (rc, tape_len, in_quote_out)."""
         n, q = C.c_uint64(), C.c_uint32()
+        has_tape = tape is not None and tape.size > 0
         rc = lib().csvsimd_stage1_index(self._h, data.ctypes.data if data.size else None, data.size,
-                                        tape.ctypes.data if tape is not None and tape.size else None,
-                                        tape.size if tape is not None else 0, C.byref(n), C.byref(q))
+                                        tape.ctypes.data if has_tape else None,
+                                        tape.size if has_tape else 0, C.byref(n), C.byref(q))
         return rc, n.value, q.value
 
     # ---- csv_simd::create(filename) -> Tape (src/lib.rs:61-74) ---------------------------------

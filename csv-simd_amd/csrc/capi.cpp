@@ -42,11 +42,18 @@ struct csvsimd_ctx {
     uint64_t scratch_bytes = 0;
     uint32_t max_blocks = 0;
     csvsimd_shard_result* d_result = nullptr;  // for the synchronous entry points
-    // host-buffer path staging (grown on demand)
-    void* d_in = nullptr;
-    uint64_t d_in_bytes = 0;
-    void* d_tape = nullptr;
-    uint64_t d_tape_entries = 0;
+    // host-buffer path (csvsimd_stage1_index): two-slot pipeline, allocated on first use
+    static constexpr uint64_t kChunk = 32ull << 20;  // bytes per slot
+    hipStream_t pipe_stream = nullptr;
+    void* pin_in[2] = {nullptr, nullptr};     // pinned staging of the input chunk
+    void* d_in[2] = {nullptr, nullptr};
+    uint64_t* d_tape[2] = {nullptr, nullptr};  // device tape of a chunk (grown on demand)
+    uint64_t d_tape_entries[2] = {0, 0};
+    uint64_t* pin_out[2] = {nullptr, nullptr};  // pinned staging of a chunk's tape
+    uint64_t pin_out_entries[2] = {0, 0};
+    csvsimd_shard_result* d_res[2] = {nullptr, nullptr};
+    csvsimd_shard_result* h_res = nullptr;     // pinned, 2 records
+    hipEvent_t ev[2] = {nullptr, nullptr};
 };
 
 extern "C" {
@@ -110,8 +117,16 @@ void csvsimd_ctx_destroy(csvsimd_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->d_result) (void)hipFree(ctx->d_result);
-    if (ctx->d_in) (void)hipFree(ctx->d_in);
-    if (ctx->d_tape) (void)hipFree(ctx->d_tape);
+    for (int k = 0; k < 2; ++k) {
+        if (ctx->pin_in[k]) (void)hipHostFree(ctx->pin_in[k]);
+        if (ctx->pin_out[k]) (void)hipHostFree(ctx->pin_out[k]);
+        if (ctx->d_in[k]) (void)hipFree(ctx->d_in[k]);
+        if (ctx->d_tape[k]) (void)hipFree(ctx->d_tape[k]);
+        if (ctx->d_res[k]) (void)hipFree(ctx->d_res[k]);
+        if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
+    }
+    if (ctx->h_res) (void)hipHostFree(ctx->h_res);
+    if (ctx->pipe_stream) (void)hipStreamDestroy(ctx->pipe_stream);
     delete ctx;
 }
 
@@ -176,66 +191,117 @@ int csvsimd_stage1_bound(uint64_t len, uint64_t* max_entries) {
     return CSVSIMD_OK;
 }
 
-// Host-buffer drop-in for reader::read.  The file is streamed through the GPU in chunks; the two
-// loop-carried values of the reference (inside_str, array_idx: src/reader.rs:217-218) are
-// carried between chunks on the host.
+// Host-buffer drop-in for reader::read (ingest).  The file is streamed through
+// the GPU in 32-MiB chunks over a two-slot pipeline on a private stream: while chunk i travels
+// (pinned staging -> H2D -> stage-1 kernel -> D2H of exactly its entries) the host thread stages
+// chunk i+1 and unloads the tape of chunk i-1.  The two loop-carried values of the reference
+// (inside_str, array_idx: src/reader.rs:217-218) are carried between chunks on the host.  This path
+// is PCIe / host-memcpy bound by construction; the HBM-resident entry points are the timed ones.
+static int pipe_setup(csvsimd_ctx* ctx) {
+    if (ctx->pipe_stream) return CSVSIMD_OK;
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->pipe_stream, hipStreamNonBlocking));
+    HIP_TRY(hipHostMalloc((void**)&ctx->h_res, 2 * sizeof(csvsimd_shard_result), hipHostMallocDefault));
+    for (int k = 0; k < 2; ++k) {
+        HIP_TRY(hipHostMalloc(&ctx->pin_in[k], csvsimd_ctx::kChunk, hipHostMallocDefault));
+        HIP_TRY(hipMalloc(&ctx->d_in[k], csvsimd_ctx::kChunk));
+        HIP_TRY(hipMalloc((void**)&ctx->d_res[k], sizeof(csvsimd_shard_result)));
+        HIP_TRY(hipEventCreateWithFlags(&ctx->ev[k], hipEventDisableTiming));
+    }
+    return CSVSIMD_OK;
+}
+static int pipe_ensure_tape(csvsimd_ctx* ctx, int k, uint64_t entries) {
+    if (ctx->d_tape_entries[k] >= entries) return CSVSIMD_OK;
+    HIP_TRY(hipStreamSynchronize(ctx->pipe_stream));
+    if (ctx->d_tape[k]) HIP_TRY(hipFree(ctx->d_tape[k]));
+    ctx->d_tape[k] = nullptr;
+    ctx->d_tape_entries[k] = 0;
+    HIP_TRY(hipMalloc((void**)&ctx->d_tape[k], entries * 8));
+    ctx->d_tape_entries[k] = entries;
+    return CSVSIMD_OK;
+}
+static int pipe_ensure_out(csvsimd_ctx* ctx, int k, uint64_t entries) {
+    if (ctx->pin_out_entries[k] >= entries) return CSVSIMD_OK;
+    HIP_TRY(hipStreamSynchronize(ctx->pipe_stream));
+    if (ctx->pin_out[k]) HIP_TRY(hipHostFree(ctx->pin_out[k]));
+    ctx->pin_out[k] = nullptr;
+    ctx->pin_out_entries[k] = 0;
+    HIP_TRY(hipHostMalloc((void**)&ctx->pin_out[k], entries * 8, hipHostMallocDefault));
+    ctx->pin_out_entries[k] = entries;
+    return CSVSIMD_OK;
+}
+
 int csvsimd_stage1_index(csvsimd_ctx* ctx, const uint8_t* buf, uint64_t len, uint64_t* tape, uint64_t tape_cap,
                          uint64_t* tape_len, uint32_t* in_quote_out) {
     if (!ctx || (len && !buf) || (!tape && tape_cap) || !tape_len) return CSVSIMD_ERR_INVALID_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
-    constexpr uint64_t kChunk = 256ull << 20;  // bytes per pass
-    const uint64_t chunk_max = std::min<uint64_t>(len ? len : 1, kChunk);
-    if (ctx->d_in_bytes < chunk_max) {
-        if (ctx->d_in) HIP_TRY(hipFree(ctx->d_in));
-        ctx->d_in = nullptr;
-        ctx->d_in_bytes = 0;
-        HIP_TRY(hipMalloc(&ctx->d_in, (chunk_max + 255) & ~255ull));
-        ctx->d_in_bytes = chunk_max;
-    }
-    auto ensure_tape = [&](uint64_t entries) -> int {
-        if (ctx->d_tape_entries >= entries) return CSVSIMD_OK;
-        if (ctx->d_tape) HIP_TRY(hipFree(ctx->d_tape));
-        ctx->d_tape = nullptr;
-        ctx->d_tape_entries = 0;
-        HIP_TRY(hipMalloc(&ctx->d_tape, std::max<uint64_t>(entries, 1) * 8));
-        ctx->d_tape_entries = std::max<uint64_t>(entries, 1);
+    int rc = pipe_setup(ctx);
+    if (rc != CSVSIMD_OK) return rc;
+    constexpr uint64_t kChunk = csvsimd_ctx::kChunk;
+    hipStream_t st = ctx->pipe_stream;
+    const uint64_t nchunks = (len + kChunk - 1) / kChunk;
+
+    uint64_t n = 1;  // entries so far, sentinel included
+    if (tape && tape_cap >= 1) tape[0] = 0;  // src/reader.rs:216
+    uint32_t inq = 0;
+
+    // what is still to be unloaded from a slot: `count` entries that belong at tape[at ...]
+    struct Pending { bool valid; uint64_t at, ncopy; } pend[2] = {{false, 0, 0}, {false, 0, 0}};
+    auto unload = [&](int k) -> int {  // waits for the slot's D2H, then copies to the user's tape
+        if (!pend[k].valid) return CSVSIMD_OK;
+        HIP_TRY(hipEventSynchronize(ctx->ev[k]));
+        if (pend[k].ncopy) memcpy(tape + pend[k].at, ctx->pin_out[k], pend[k].ncopy * 8);
+        pend[k].valid = false;
         return CSVSIMD_OK;
     };
 
-    uint64_t n = 0;  // entries so far, sentinel included
-    if (tape && tape_cap >= 1) tape[0] = 0;  // src/reader.rs:216
-    n = 1;
-    uint32_t inq = 0;
-    for (uint64_t off = 0; off < len; off += kChunk) {
-        const uint64_t clen = std::min<uint64_t>(kChunk, len - off);
-        HIP_TRY(hipMemcpy(ctx->d_in, buf + off, clen, hipMemcpyHostToDevice));
-        csvsimd_shard_result r;
-        int rc;
-        if (!tape) {
-            rc = csvsimd_stage1_index_device(ctx, ctx->d_in, clen, off, inq, nullptr, 0, &r, nullptr);
+    if (nchunks) memcpy(ctx->pin_in[0], buf, std::min<uint64_t>(kChunk, len));
+    for (uint64_t i = 0; i < nchunks; ++i) {
+        const int k = (int)(i & 1);
+        const uint64_t off = i * kChunk, clen = std::min<uint64_t>(kChunk, len - off);
+        HIP_TRY(hipMemcpyAsync(ctx->d_in[k], ctx->pin_in[k], clen, hipMemcpyHostToDevice, st));
+        // first guess: one entry per 4 bytes; exact retry below if the chunk is denser
+        uint64_t cap = 0;
+        if (tape) {
+            rc = pipe_ensure_tape(ctx, k, std::max<uint64_t>(clen / 4, 4096));
             if (rc != CSVSIMD_OK) return rc;
-        } else {
-            // first guess: one entry per 4 bytes; exact retry if the chunk is denser
-            rc = ensure_tape(std::max<uint64_t>(clen / 4, 4096));
+            cap = ctx->d_tape_entries[k];
+        }
+        rc = csvsimd_stage1_index_device_async(ctx, ctx->d_in[k], clen, off, inq, tape ? ctx->d_tape[k] : nullptr, cap,
+                                               ctx->d_res[k], st);
+        if (rc != CSVSIMD_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(&ctx->h_res[k], ctx->d_res[k], sizeof(csvsimd_shard_result), hipMemcpyDeviceToHost, st));
+        // while chunk i is in flight: stage chunk i+1, unload the tape of chunk i-1
+        if (i + 1 < nchunks) memcpy(ctx->pin_in[k ^ 1], buf + off + kChunk, std::min<uint64_t>(kChunk, len - off - kChunk));
+        rc = unload(k ^ 1);
+        if (rc != CSVSIMD_OK) return rc;
+        HIP_TRY(hipStreamSynchronize(st));
+        csvsimd_shard_result r = ctx->h_res[k];
+        if (r.error) { g_last_error = "stage1 kernel: look-back spin bound hit"; return CSVSIMD_ERR_INTERNAL; }
+        if (tape && r.count > cap) {  // denser than guessed: exact capacity, run the chunk again
+            rc = pipe_ensure_tape(ctx, k, r.count);
             if (rc != CSVSIMD_OK) return rc;
-            rc = csvsimd_stage1_index_device(ctx, ctx->d_in, clen, off, inq, ctx->d_tape, ctx->d_tape_entries, &r,
-                                             nullptr);
-            if (rc == CSVSIMD_ERR_TAPE_CAPACITY) {
-                rc = ensure_tape(r.count);
+            rc = csvsimd_stage1_index_device_async(ctx, ctx->d_in[k], clen, off, inq, ctx->d_tape[k],
+                                                   ctx->d_tape_entries[k], ctx->d_res[k], st);
+            if (rc != CSVSIMD_OK) return rc;
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+        if (tape && n < tape_cap) {
+            const uint64_t ncopy = std::min<uint64_t>(tape_cap - n, r.count);
+            if (ncopy) {
+                rc = pipe_ensure_out(ctx, k, std::max<uint64_t>(ncopy, 4096));
                 if (rc != CSVSIMD_OK) return rc;
-                rc = csvsimd_stage1_index_device(ctx, ctx->d_in, clen, off, inq, ctx->d_tape, ctx->d_tape_entries,
-                                                 &r, nullptr);
-            }
-            if (rc != CSVSIMD_OK) return rc;
-            if (n < tape_cap) {
-                const uint64_t room = tape_cap - n;
-                const uint64_t ncopy = std::min<uint64_t>(room, r.count);
-                if (ncopy) HIP_TRY(hipMemcpy(tape + n, ctx->d_tape, ncopy * 8, hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpyAsync(ctx->pin_out[k], ctx->d_tape[k], ncopy * 8, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipEventRecord(ctx->ev[k], st));
+                pend[k] = {true, n, ncopy};
             }
         }
         n += r.count;
         inq = r.in_quote_out;
     }
+    rc = unload(0);
+    if (rc != CSVSIMD_OK) return rc;
+    rc = unload(1);
+    if (rc != CSVSIMD_OK) return rc;
     *tape_len = n;
     if (in_quote_out) *in_quote_out = inq;
     if (tape && n > tape_cap) return CSVSIMD_ERR_TAPE_CAPACITY;
@@ -382,13 +448,16 @@ int csvsimd_create(csvsimd_ctx* ctx, const char* filename, csvsimd_tape** out) {
     csv_simd::Header h;
     csv_simd::StructureError e = csv_simd::Header::create(bytes, len, h);
     if (e != csv_simd::StructureError::Ok) return (int)e;
-    // count-only pass sizes the index exactly, then the emitting pass fills it
+    // one pass with a capacity guess (an entry per 8 bytes); one exact retry if the file is denser
     uint64_t n = 0;
-    int rc = csvsimd_stage1_index(ctx, bytes, len, nullptr, 0, &n, nullptr);
+    t->owned_index.resize(len / 8 + 64);
+    int rc = csvsimd_stage1_index(ctx, bytes, len, t->owned_index.data(), t->owned_index.size(), &n, nullptr);
+    if (rc == CSVSIMD_ERR_TAPE_CAPACITY) {
+        t->owned_index.resize(n);
+        rc = csvsimd_stage1_index(ctx, bytes, len, t->owned_index.data(), n, &n, nullptr);
+    }
     if (rc != CSVSIMD_OK) return rc;
     t->owned_index.resize(n);
-    rc = csvsimd_stage1_index(ctx, bytes, len, t->owned_index.data(), n, &n, nullptr);
-    if (rc != CSVSIMD_OK) return rc;
     e = csv_simd::Tape::from_core(bytes, len, csv_simd::StructureIndex{t->owned_index.data(), n}, std::move(h),
                                   t->tape);
     if (e != csv_simd::StructureError::Ok) return (int)e;

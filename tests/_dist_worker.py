@@ -34,17 +34,19 @@ def worker(rank, world, port, n, seed, p_quote, skew, outdir):
         shard = data[lo:hi]
         passes = []
 
+        d_result = torch.zeros(8, dtype=torch.int64)  # the result record, as the GPU path leaves it
+
         def run_pass(in_quote_in):
             entries, inq_out = oracle.scalar_index(shard, base_off=lo, in_quote_in=in_quote_in)
             p, c0, c1 = oracle.shard_descriptor(shard)
             r = pkg.ShardResult()
             r.count, r.count_enter_outside, r.count_enter_inside = entries.size, c0, c1
-            r.quote_parity, r.in_quote_out = p, inq_out
+            r.quote_parity, r.in_quote_out, r.written = p, inq_out, entries.size
+            d_result.copy_(torch.tensor(sharded.words_from_result(r), dtype=torch.int64))
             passes.append(in_quote_in)
             run_pass.entries = entries
-            return r
 
-        st, final, re_emitted = sharded.index_sharded(run_pass, torch.device("cpu"))
+        st, final, re_emitted = sharded.index_sharded(run_pass, d_result)
         assert final.count == st.count
         assert re_emitted == bool(st.in_quote_in) and passes == ([0, 1] if re_emitted else [0])
         np.save(os.path.join(outdir, f"shard{rank}.npy"), run_pass.entries)

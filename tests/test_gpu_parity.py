@@ -297,3 +297,34 @@ def test_repeatability_stress(ctx, torch_cuda, pkg):
     for rep in range(50):
         r = ctx.stage1_index_device(dbuf.data_ptr(), n)
         assert (r.count, r.count_enter_outside, r.in_quote_out) == (S, S, 0), rep
+
+
+def test_host_ingest_pipeline_multi_chunk(ctx, pkg, oracle, tmp_path):
+    # csvsimd_stage1_index streams the file in 32-MiB chunks over a two-slot pipeline: quoted
+    # regions and tape bases must carry across chunk boundaries; a dense chunk takes the
+    # exact-capacity retry; csvsimd_create runs the same path from a file.
+    rng = np.random.default_rng(4711)
+    n = (32 << 20) * 2 + 12345                      # 3 chunks, ragged tail
+    d = random_csvish(rng, n, 0.002)                # long quoted stretches cross the boundaries
+    d[(32 << 20) - 3: (32 << 20) + 3] = np.frombuffer(b',"\n,",', dtype=np.uint8)
+    got = ctx.read(d)
+    want = oracle.scalar_read(d)
+    assert got.size == want.size and np.array_equal(got, want)
+    dense = np.full((32 << 20) + 77, 0x2C, dtype=np.uint8)   # every byte structural: > 1 entry / 4 B
+    got = ctx.read(dense)
+    assert got.size == dense.size + 1 and got[0] == 0 and np.array_equal(got[1:], np.arange(dense.size, dtype=np.uint64))
+    # count-only call and capacity protocol across chunks
+    rc, cnt, q = ctx.read_into(d, None)
+    assert rc == 0 and cnt == want.size
+    small = np.zeros(1000, dtype=np.uint64)
+    rc, cnt, _ = ctx.read_into(d, small)
+    assert rc == pkg.ERR_TAPE_CAPACITY and cnt == want.size and np.array_equal(small, want[:1000])
+    # from a file: a regular 3-column CSV of ~40 MiB
+    rows = 1_500_000
+    body = b"Name,Number,Done\n" + b"".join(b"abc%07d,%09d,\"y,n\"\n" % (i, i * 7) for i in range(rows))
+    p = tmp_path / "big.csv"
+    p.write_bytes(body)
+    t = ctx.create(str(p))
+    assert (t.field_cnt, t.record_cnt, t.new_line) == (3, rows + 1, "LF")
+    assert t.seek_field(rows - 1, 2) == b'"y,n"' and t.seek_field(123456, 0) == b"abc0123456"
+    assert np.array_equal(t.index(), oracle.scalar_read(body))
