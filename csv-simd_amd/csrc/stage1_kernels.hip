@@ -6,17 +6,17 @@
 //                               (src/avx/stage1.rs:342-407), emitted ascending as u64
 //                               (src/stage1.rs:162-296).
 //
-// How (MI355X-first; nothing here mirrors the SSE code's structure):
-//   * one pass over the input, every byte read once from HBM with 16-B/lane fully coalesced
-//     buffer loads (a wave covers 1 KiB per instruction; the descriptor's range check makes the
-//     ragged last tile branch-free).
+// How (MI355X-first; nothing here mirrors the SSE code's structure) — DESIGN.md §4 has the numbers:
+//   * one pass over the input: every byte is read once from HBM by LDS-DMA
+//     (buffer_load_dwordx4 ... lds, non-temporal, 1 KiB per wave instruction, fully coalesced, no
+//     VGPRs); the buffer descriptor's range check makes the ragged last tile branch-free.
 //   * measured on gfx950: every 32-bit VALU instruction costs 4 cycles per wave64 per SIMD, so the
 //     kernel is bound by VALU ISSUE, not HBM, unless the per-byte instruction count is tiny.
 //     Hence: (a) classification = one v_perm 8-entry LUT keyed by 3 hashed bits + xor +
 //     v_lerp_u8 (carry-free per-byte add) + two v_bitop3 + two v_dot4 bit gathers = 10 VALU per
-//     4 bytes for BOTH masks; (b) data is transposed through a wave-private 4-KiB LDS image
-//     (ds_write_b128 / ds_read_b128, XOR-swizzled: conflict-free, zero VALU) so that each lane
-//     owns one 64-byte stripe = one 64-bit structural mask + one 64-bit quote mask.
+//     4 bytes for BOTH masks; (b) the transpose that gives each lane one 64-byte stripe (= one
+//     64-bit structural mask + one 64-bit quote mask) is done by the LDS image itself: swizzle
+//     on the DMA source side, conflict-free ds_read_b128 on the reader side, zero VALU.
 //   * in-string mask = 6 shift-xor steps on the lane's 64-bit word (CDNA has no carry-less
 //     multiply) + ONE ballot/mbcnt per 4 KiB for the carry across lanes + a scalar carry across
 //     rounds.  Masks of the whole 32-KiB wave span stay in registers (2 x u64 per round).
@@ -24,10 +24,11 @@
 //     src/reader.rs:217-218) become a composable tile descriptor
 //     (quote parity, count if entered outside, count if entered inside) resolved across
 //     workgroups by a single-pass decoupled look-back over one 64-bit word per tile
-//     (relaxed agent-scope atomics: the data is the flag, no fences).
-//   * ordered compaction: one DPP wave scan of per-lane popcounts per 4 KiB; sparse rounds store
-//     straight to the tape (consecutive lanes write consecutive entries: near-coalesced), dense
-//     rounds go through a u16 LDS window and leave as fully coalesced 8-byte stores.
+//     (relaxed agent-scope atomics: the data is the flag, no fences; status tag in both halves).
+//     The resolve of a tile is lagged by one tile (its masks are held in registers meanwhile).
+//   * ordered compaction: one DPP wave scan of per-lane popcounts per 4 KiB, set bits scattered as
+//     u16 offsets into a wave-private LDS window (rounds batched), flushed as fully coalesced
+//     non-temporal 16-byte stores.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -41,7 +42,7 @@ namespace csvsimd {
 typedef uint32_t u32;
 typedef uint64_t u64;
 
-static constexpr int kWaves = CSVSIMD_COMPUTE_WAVES;    // COMPUTE waves per workgroup (one span each)
+static constexpr int kWaves = CSVSIMD_COMPUTE_WAVES;    // waves per workgroup (one 32-KiB span each)
 static constexpr int kThreads = kWaves * 64;
 static constexpr int kRows = 4;                         // 1-KiB rows (dwordx4 wave loads) per round
 static constexpr int kRoundBytes = kRows * 1024;        // 4 KiB per wave per round = 64 stripes of 64 B
@@ -72,8 +73,6 @@ static constexpr uint32_t kSpinLimit = 1u << 20;  // bounded spins: a protocol b
 // ---------------------------------------------------------------------------------------------
 // wavefront primitives (wave64)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ u32 lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-
 // number of set bits of `mask` in lanes below this one
 __device__ __forceinline__ u32 mbcnt64(u64 mask) {
     return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
@@ -841,7 +840,7 @@ __global__ void selftest_kernel(u32* out) {
     __shared__ u32 s_d[64][3];
     const u32 lane = threadIdx.x;
     u32 fail = 0;
-    if (lane_id() != lane) fail |= 1;
+    if (mbcnt64(~0ull) != lane) fail |= 1;
     // scan
     const u32 v = (lane * 2654435761u >> 20) & 0x03ff03ffu;
     s_v[lane] = v;

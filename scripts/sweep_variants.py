@@ -11,7 +11,7 @@ ctx = pkg.Context(0)
 out = {}
 for name in sys.argv[1].split(","):
     cols, width, seed, q = pkg.WORKLOADS[name]
-    n = pkg.workload_len(name, 4 << 30)
+    n = pkg.workload_len(name, int(float(os.environ.get("SWEEP_GIB", "4")) * 2**30))
     dbuf = torch.empty(n, dtype=torch.uint8, device="cuda:0")
     pkg.synth_fill_device(dbuf.data_ptr(), 0, n, cols, width, seed, q)
     cap = n // (width + 1) + 64
