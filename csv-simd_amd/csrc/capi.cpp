@@ -149,7 +149,7 @@ int csvsimd_stage1_index_device_async(csvsimd_ctx* ctx, const void* dbuf, uint64
                                       void* hip_stream) {
     if (!ctx || !d_result || (len && !dbuf) || (!dtape && tape_cap)) return CSVSIMD_ERR_INVALID_ARG;
     if (len >= (1ull << 60)) return CSVSIMD_ERR_INVALID_ARG;
-    if (((uintptr_t)dtape & 7) || ((uintptr_t)d_result & 7)) return CSVSIMD_ERR_INVALID_ARG;
+    if (((uintptr_t)dtape & 7) || ((uintptr_t)d_result & 15)) return CSVSIMD_ERR_INVALID_ARG;
     if (csvsimd::Stage1Launch::scratch_bytes_for(len) > ctx->scratch_bytes) {
         const int rc = csvsimd_ctx_reserve(ctx, len);  // allocates + synchronises: not capturable
         if (rc != CSVSIMD_OK) return rc;

@@ -745,6 +745,16 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
 #undef CSVSIMD_STAMP
 }
 
+// Zeroes the scratch prefix (ticket, counters, look-back words) and the result record before every
+// launch.  A kernel of our own rather than hipMemsetAsync: captured into a hipGraph, ROCm 7.2's
+// memset node for these sizes replays a 16-byte pattern fill whose pattern is read from memory that
+// is gone after capture (observed: the scratch came back full of stale pointers on every replay).
+__global__ void zero_kernel(uint4* a, u32 a_vec16, uint4* b, u32 b_vec16) {
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < a_vec16; i += gridDim.x * blockDim.x) a[i] = z;
+    if (blockIdx.x == 0 && threadIdx.x < b_vec16) b[threadIdx.x] = z;
+}
+
 // sums the sharded structural-byte counters into the result (tiny, 1 wave)
 __global__ void finalize_kernel(const u64* tot_struct, csvsimd_shard_result* result, u32 in_quote_in,
                                 u32 num_tiles) {
@@ -912,10 +922,14 @@ hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream) {
     a.result = L.d_result;
 
     hipError_t e;
-    // one memset covers ticket + sharded totals + descriptors (contiguous in the scratch block)
-    e = hipMemsetAsync(L.scratch_base, 0, L.scratch_zero_bytes(a.num_tiles), stream);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(L.d_result, 0, sizeof(csvsimd_shard_result), stream);
+    // one launch zeroes ticket + sharded totals + descriptors (contiguous, 16-byte granular) and
+    // the result record
+    static_assert(sizeof(csvsimd_shard_result) % 16 == 0, "result record is zeroed 16 bytes at a time");
+    const u32 zvec = (u32)(L.scratch_zero_bytes(a.num_tiles) / 16);
+    const u32 zblocks = zvec > 256u * 64u ? 64u : (zvec + 255u) / 256u;
+    hipLaunchKernelGGL(zero_kernel, dim3(zblocks ? zblocks : 1), dim3(256), 0, stream, (uint4*)L.scratch_base, zvec,
+                       (uint4*)L.d_result, (u32)(sizeof(csvsimd_shard_result) / 16));
+    e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (a.num_tiles > 0) {
         const u32 grid = a.num_tiles < L.max_blocks ? a.num_tiles : L.max_blocks;

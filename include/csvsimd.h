@@ -46,7 +46,9 @@ uint32_t csvsimd_abi_version(void);
 /* bytes one workgroup indexes per look-back step (informational: tests probe sizes around it) */
 uint32_t csvsimd_tile_bytes(void);
 
-/* ---- context: one per (thread, device); owns the look-back scratch ------------------------ */
+/* ---- context: one per (thread, device); owns the look-back scratch.  All launches that use one
+ * context must be ordered with respect to each other (same stream, or explicit dependencies): they
+ * share the scratch block.  Use several contexts for concurrent streams. ---------------------- */
 typedef struct csvsimd_ctx csvsimd_ctx;
 int csvsimd_ctx_create(int device, csvsimd_ctx** out);
 void csvsimd_ctx_destroy(csvsimd_ctx* ctx);
@@ -76,7 +78,7 @@ typedef struct csvsimd_shard_result {
  * No sentinel is written here (the reference's leading 0, src/reader.rs:216, belongs to the
  * whole file, not to a shard).  dtape may be NULL with tape_cap 0 for a count-only pass.
  * Asynchronous on hip_stream (a hipStream_t, NULL = default stream); d_result is DEVICE memory
- * (>= sizeof(csvsimd_shard_result), 8-byte aligned), valid once the stream has drained.  No
+ * (>= sizeof(csvsimd_shard_result), 16-byte aligned), valid once the stream has drained.  No
  * allocation and no synchronisation happens inside as long as the context scratch is large
  * enough for len (grow it up front with csvsimd_ctx_reserve), so the call may be captured
  * into a hipGraph.  Any dbuf alignment is accepted; 16-byte alignment is fastest. */

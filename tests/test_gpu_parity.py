@@ -328,3 +328,55 @@ def test_host_ingest_pipeline_multi_chunk(ctx, pkg, oracle, tmp_path):
     assert (t.field_cnt, t.record_cnt, t.new_line) == (3, rows + 1, "LF")
     assert t.seek_field(rows - 1, 2) == b'"y,n"' and t.seek_field(123456, 0) == b"abc0123456"
     assert np.array_equal(t.index(), oracle.scalar_read(body))
+
+
+def test_async_entry_point_is_graph_capturable(ctx, torch_cuda, pkg, oracle):
+    # include/csvsimd.h promises: no allocation and no synchronisation inside
+    # csvsimd_stage1_index_device_async once the scratch is reserved -> it can be captured into a
+    # hipGraph (memset nodes + kernel nodes) and replayed on new contents of the same buffers.
+    torch = torch_cuda
+    rng = np.random.default_rng(12)
+    n = 3 * pkg.tile_bytes() + 4321
+    dbuf = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
+    cap = n + 1
+    dtape = torch.full((cap,), -1, dtype=torch.int64, device="cuda:0")
+    dres = torch.zeros(8, dtype=torch.int64, device="cuda:0")
+    ctx.reserve(n)
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ctx.stage1_index_device_async(dbuf.data_ptr(), n, 7, 0, dtape.data_ptr(), cap, dres.data_ptr(), side.cuda_stream)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        s = torch.cuda.current_stream().cuda_stream
+        ctx.stage1_index_device_async(dbuf.data_ptr(), n, 7, 0, dtape.data_ptr(), cap, dres.data_ptr(), s)
+    from csv_simd_amd import sharded
+    for rep in range(3):
+        d = random_csvish(rng, n, 0.05)
+        dbuf.copy_(torch.from_numpy(d))
+        dtape.fill_(-1)
+        g.replay()
+        torch.cuda.synchronize()
+        r = sharded.result_from_words(dres.cpu().tolist())
+        want, q = oracle.scalar_index(d, base_off=7)
+        assert (r.count, r.in_quote_out, r.error) == (want.size, q, 0), rep
+        assert np.array_equal(dtape[: r.count].cpu().numpy().view(np.uint64), want), rep
+
+
+def test_misaligned_tape_pointer(ctx, torch_cuda, oracle):
+    # the 16-byte tape stores peel one entry when the tape pointer / running index is odd
+    torch = torch_cuda
+    rng = np.random.default_rng(13)
+    d = random_csvish(rng, 500_000, 0.01)
+    want, _ = oracle.scalar_index(d)
+    dbuf = torch.from_numpy(d).cuda()
+    backing = torch.full((want.size + 16,), -1, dtype=torch.int64, device="cuda:0")
+    for shift in (0, 1):   # 8-byte shift = 16-byte misalignment of the shard's tape
+        backing.fill_(-1)
+        view = backing[shift:]
+        r = ctx.stage1_index_device(dbuf.data_ptr(), d.size, 0, 0, view.data_ptr(), want.size)
+        assert r.count == want.size
+        assert np.array_equal(view[: want.size].cpu().numpy().view(np.uint64), want)
+        assert bool((backing[:shift] == -1).all()) and bool((view[want.size:] == -1).all())
