@@ -105,6 +105,10 @@ _PROTOTYPES = {
     "csvsimd_create": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]),
     "csvsimd_tape_index": (_u64p, [C.c_void_p, _u64p]),
     "csvsimd_tape_bytes": (C.POINTER(C.c_uint8), [C.c_void_p, _u64p]),
+    "csvsimd_tape_field_spans_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32, C.c_uint64,
+                                                  C.c_uint64, C.c_void_p, C.c_void_p, _u64p, C.c_void_p]),
+    "csvsimd_gather_fields_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
+                                               C.c_uint32, C.c_void_p, C.c_void_p]),
     "csvsimd_synth_fill_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
                                             C.c_uint64, C.c_uint32, C.c_void_p]),
     "csvsimd_tape_checksum_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
@@ -337,6 +341,24 @@ class Tape:
         n = C.c_uint32()
         _check(lib().csvsimd_tape_chunks(self._h, num, out, C.byref(n)))
         return [(out[i].id, out[i].start, out[i].end, out[i].record_cnt) for i in range(n.value)]
+
+
+# ---- device-side consumers of a device-resident tape (raw device addresses) ----------------------
+def tape_field_spans_device(dindex: int, index_len: int, field_cnt: int, new_line: str, field_idx: int,
+                            first_record: int, n_records: int, d_begin: int, d_end: int, stream: int = 0) -> int:
+    """Bulk seek_field on the GPU; returns how many of the requested records exist."""
+    n = C.c_uint64()
+    _check(lib().csvsimd_tape_field_spans_device(dindex, index_len, field_cnt,
+                                                 NEWLINE_CRLF if new_line == "CRLF" else NEWLINE_LF, field_idx,
+                                                 first_record, n_records, d_begin or None, d_end or None,
+                                                 C.byref(n), stream or None))
+    return n.value
+
+
+def gather_fields_device(dbytes: int, d_begin: int, d_end: int, n_records: int, d_dst: int, stride: int,
+                         d_len: int = 0, stream: int = 0) -> None:
+    _check(lib().csvsimd_gather_fields_device(dbytes, d_begin, d_end, n_records, d_dst, stride, d_len or None,
+                                              stream or None))
 
 
 # ---- device utilities (raw device addresses; torch tensors' .data_ptr() fit) --------------------

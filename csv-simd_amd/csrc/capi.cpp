@@ -491,6 +491,35 @@ int csvsimd_tape_checksum_device(const void* dtape, uint64_t n, uint64_t first_i
     return CSVSIMD_OK;
 }
 
+int csvsimd_tape_field_spans_device(const void* dindex, uint64_t index_len, uint32_t field_cnt, int new_line,
+                                    uint32_t field_idx, uint64_t first_record, uint64_t n_records, void* d_begin,
+                                    void* d_end, uint64_t* n_valid, void* hip_stream) {
+    if (!dindex || !n_valid || field_cnt == 0 || (n_records && (!d_begin || !d_end))) return CSVSIMD_ERR_INVALID_ARG;
+    if (csvsimd_device_count() <= 0) return CSVSIMD_ERR_NO_DEVICE;
+    // TapeCore::init (src/tape.rs:315-347)
+    const uint64_t row_size = (uint64_t)field_cnt + (new_line == CSVSIMD_NEWLINE_CRLF ? 1 : 0);
+    if (index_len == 0) return CSVSIMD_ERR_INVALID_STATE;
+    if ((index_len - 1) % row_size != 0) return CSVSIMD_ERR_INVALID_CSV_FORMAT;
+    const uint64_t record_cnt = (index_len - 1) / row_size;  // includes the header row
+    *n_valid = 0;
+    // seek_field: Ok(None) when record_idx + 1 >= record_cnt or field_idx >= field_cnt
+    if (field_idx >= field_cnt || first_record + 1 >= record_cnt) return CSVSIMD_OK;
+    const uint64_t n = std::min<uint64_t>(n_records, record_cnt - 1 - first_record);
+    HIP_TRY(csvsimd::launch_field_spans(dindex, row_size, field_idx, first_record, n, d_begin, d_end,
+                                        (hipStream_t)hip_stream));
+    *n_valid = n;
+    return CSVSIMD_OK;
+}
+
+int csvsimd_gather_fields_device(const void* dbytes, const void* d_begin, const void* d_end, uint64_t n_records,
+                                 void* d_dst, uint32_t stride, void* d_len, void* hip_stream) {
+    if ((n_records && (!dbytes || !d_begin || !d_end || !d_dst)) || stride == 0) return CSVSIMD_ERR_INVALID_ARG;
+    if (csvsimd_device_count() <= 0) return CSVSIMD_ERR_NO_DEVICE;
+    HIP_TRY(csvsimd::launch_gather_fields(dbytes, d_begin, d_end, n_records, d_dst, stride, d_len,
+                                          (hipStream_t)hip_stream));
+    return CSVSIMD_OK;
+}
+
 int csvsimd_selftest_device(int device) {
     const int n = csvsimd_device_count();
     if (n <= 0) return CSVSIMD_ERR_NO_DEVICE;

@@ -167,6 +167,24 @@ int csvsimd_create(csvsimd_ctx* ctx, const char* filename, csvsimd_tape** out);
 const uint64_t* csvsimd_tape_index(const csvsimd_tape* t, uint64_t* index_len);
 const uint8_t* csvsimd_tape_bytes(const csvsimd_tape* t, uint64_t* len);
 
+/* ---- device-side consumers of a finished, device-resident tape ---------
+ * RecordSource::seek_field (src/record_source.rs:106-140) for a whole range of records at once.
+ * dindex = the tape WITH its leading sentinel (dindex[0] == 0), index_len entries.  For records
+ * [first_record, first_record + n_records) (0 = first data row, as in seek_field) and field
+ * field_idx writes d_begin[i], d_end[i] such that bytes[begin..end) is the field text — the same
+ * pair csvsimd_tape_seek_field returns.  *n_valid = how many of the requested records exist
+ * (seek_field's Ok(None) cases are simply not written).  Ragged index -> CSVSIMD_ERR_INVALID_CSV_FORMAT
+ * (TapeCore::init, src/tape.rs:327,342-344). */
+int csvsimd_tape_field_spans_device(const void* dindex, uint64_t index_len, uint32_t field_cnt, int new_line,
+                                    uint32_t field_idx, uint64_t first_record, uint64_t n_records,
+                                    void* d_begin, void* d_end, uint64_t* n_valid, void* hip_stream);
+/* Copies the text of each span into row i of d_dst (n_records x stride bytes, truncated to stride,
+ * zero padded); d_len[i] (uint32, may be NULL) = untruncated length.  The column-gather step of
+ * the reference's stated goal "frequency counts, and function search" (design_notes_1.md:1-4). */
+int csvsimd_gather_fields_device(const void* dbytes, const void* d_begin, const void* d_end,
+                                 uint64_t n_records, void* d_dst, uint32_t stride, void* d_len,
+                                 void* hip_stream);
+
 /* ---- utilities used by the bench / tests (device-side, no reference counterpart) ------------- */
 /* Synthetic corpus bytes [file_off, file_off+len) of the cols x width shape. */
 int csvsimd_synth_fill_device(void* dbuf, uint64_t file_off, uint64_t len, uint32_t cols,

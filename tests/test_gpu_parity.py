@@ -380,3 +380,54 @@ def test_misaligned_tape_pointer(ctx, torch_cuda, oracle):
         assert r.count == want.size
         assert np.array_equal(view[: want.size].cpu().numpy().view(np.uint64), want)
         assert bool((backing[:shift] == -1).all()) and bool((view[want.size:] == -1).all())
+
+
+def test_device_field_spans_and_gather(ctx, torch_cuda, pkg, golden, oracle):
+    # RecordSource::seek_field for all records at once on the device must agree
+    # with the host-side seek_field (reference src/record_source.rs:106-140)
+    torch = torch_cuda
+
+    def check(data: bytes, fields_to_check):
+        host_index = ctx.read(data)
+        t = pkg.Tape.from_index(np.frombuffer(data, dtype=np.uint8), host_index)
+        dbytes = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
+        # device-resident tape with its sentinel: entries land at dindex[1:]
+        dindex = torch.zeros(host_index.size + 4, dtype=torch.int64, device="cuda:0")
+        r = ctx.stage1_index_device(dbytes.data_ptr(), len(data), 0, 0, dindex.data_ptr() + 8, host_index.size + 3)
+        assert r.count + 1 == host_index.size
+        nrec = t.record_cnt - 1
+        for f in fields_to_check:
+            b = torch.full((nrec + 3,), -1, dtype=torch.int64, device="cuda:0")
+            e = torch.full((nrec + 3,), -1, dtype=torch.int64, device="cuda:0")
+            nv = pkg.tape_field_spans_device(dindex.data_ptr(), host_index.size, t.field_cnt, t.new_line, f, 0, nrec + 3,
+                                             b.data_ptr(), e.data_ptr())
+            assert nv == nrec and bool((b[nrec:] == -1).all())
+            stride = 48
+            dst = torch.zeros(nrec * stride, dtype=torch.uint8, device="cuda:0")
+            ln = torch.zeros(nrec, dtype=torch.int32, device="cuda:0")
+            pkg.gather_fields_device(dbytes.data_ptr(), b.data_ptr(), e.data_ptr(), nrec, dst.data_ptr(), stride, ln.data_ptr())
+            bh, eh, dh, lh = b.cpu().tolist(), e.cpu().tolist(), dst.cpu().numpy().reshape(nrec, stride), ln.cpu().tolist()
+            step = max(1, nrec // 500)
+            for rec in list(range(0, nrec, step)) + [nrec - 1]:
+                want = t.seek_field(rec, f)
+                assert data[bh[rec]: eh[rec]] == want, (rec, f)
+                assert lh[rec] == len(want)
+                row = bytes(dh[rec][: min(len(want), stride)])
+                assert row == want[:stride] and not dh[rec][len(want):].any()
+        # the Ok(None) cases of seek_field
+        assert pkg.tape_field_spans_device(dindex.data_ptr(), host_index.size, t.field_cnt, t.new_line, t.field_cnt, 0, 5, b.data_ptr(), e.data_ptr()) == 0
+        assert pkg.tape_field_spans_device(dindex.data_ptr(), host_index.size, t.field_cnt, t.new_line, 0, nrec, 5, b.data_ptr(), e.data_ptr()) == 0
+        return t
+
+    check(golden["sample.csv"][0], [0, 1, 2])
+    check(golden["sample_rx.csv"][0], [0, 2, 5, 7])       # BOM, CRLF, quoted commas
+    cols, width, seed, q = pkg.WORKLOADS["16x32_q10"]
+    data = bytes(oracle.synth(0, 4000 * cols * (width + 1), cols, width, seed, 0))   # LF rows, 16 fields
+    check(data, [0, 7, 15])
+    # a ragged index is rejected like TapeCore::init does
+    rag = golden["reader_test01.csv"][0]
+    idx = ctx.read(rag)
+    d = torch.from_numpy(idx.view(np.int64)).cuda()
+    with pytest.raises(pkg.StructureError) as ei:
+        pkg.tape_field_spans_device(d.data_ptr(), idx.size, 3, "LF", 0, 0, 1, d.data_ptr(), d.data_ptr())
+    assert ei.value.code == pkg.ERR_INVALID_CSV_FORMAT
