@@ -143,6 +143,9 @@ def main():
     ap.add_argument("--gib-per-gpu", type=float, default=8.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the other BASELINE shapes at N=1")
+    ap.add_argument("--native-rccl", action="store_true",
+                    help="do the sharded step inside the C ABI (csvsimd_stage1_index_sharded: ncclAllGather "
+                         "from C++) instead of torch.distributed.all_gather_into_tensor")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -171,8 +174,20 @@ def main():
     sb = ShardBench(pkg, device, args.workload, shard_bytes, rank, world)
     state = {}
 
+    comm = None
+    if dist_on and args.native_rccl:
+        import torch.distributed as dist
+        uid = [pkg.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)   # the 128-byte RCCL id travels over the existing group
+        comm = pkg.Comm(uid[0], rank, world, device.index)
+
     def step():
-        if dist_on:
+        if comm is not None:
+            r, st = comm.index_sharded(sb.ctx, sb.dbuf.data_ptr(), sb.n, sb.lo, sb.dtape.data_ptr(), sb.cap, 0,
+                                       torch.cuda.current_stream(device).cuda_stream)
+            sb.check(r)
+            state["count"], state["re"], state["total_entries"] = st.count, bool(st.in_quote_in), st.total_entries
+        elif dist_on:
             st, final, re = sharded.index_sharded(sb.launch, sb.d_result)
             sb.check(final)
             state["count"], state["re"] = st.count, re
@@ -208,7 +223,8 @@ def main():
         "config": {"workload": f"{args.workload}: {sb.cols} cols x {sb.width}-byte fields, LF rows, "
                                f"{sb.n / 2**30:.3f} GiB per GPU (BASELINE config 4's per-GPU shard shape)",
                    "bytes_per_gpu": sb.n, "total_bytes": total_bytes, "tape_entries": int(state["total_entries"]),
-                   "parallelism": f"chunk-sharded x{world}, one all-gather of shard descriptors"},
+                   "parallelism": f"chunk-sharded x{world}, one all-gather of shard descriptors"
+                                  + (" (native RCCL from the C ABI)" if comm is not None else "")},
         "rows_indexed_per_s": round(rows * args.steps / dt, 1),
         "gib_per_s_per_gpu": round(gib_s / world, 3),
         "roofline": roofline,

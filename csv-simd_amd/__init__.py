@@ -23,7 +23,7 @@ LIB_PATH = os.environ.get("CSVSIMD_LIB") or os.path.join(_HERE, "csrc", "libcsvs
 
 OK = 0
 ERR_IO, ERR_MISSING_VALUE, ERR_INVALID_STATE, ERR_INVALID_CSV_FORMAT = -1, -2, -3, -4
-ERR_INVALID_ARG, ERR_TAPE_CAPACITY, ERR_HIP, ERR_NO_DEVICE, ERR_INTERNAL = -9, -11, -12, -13, -14
+ERR_INVALID_ARG, ERR_TAPE_CAPACITY, ERR_HIP, ERR_NO_DEVICE, ERR_INTERNAL, ERR_RCCL = -9, -11, -12, -13, -14, -15
 NEWLINE_LF, NEWLINE_CRLF = 0, 1
 
 
@@ -90,6 +90,12 @@ _PROTOTYPES = {
                                        C.POINTER(C.c_uint32)]),
     "csvsimd_stitch_shards": (C.c_int, [C.POINTER(ShardResult), C.c_uint32, C.c_uint32, C.c_uint32,
                                         C.POINTER(Stitch)]),
+    "csvsimd_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "csvsimd_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "csvsimd_comm_destroy": (None, [C.c_void_p]),
+    "csvsimd_stage1_index_sharded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32,
+                                               C.c_void_p, C.c_uint64, C.POINTER(ShardResult), C.POINTER(Stitch),
+                                               C.c_void_p]),
     "csvsimd_tape_create": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "csvsimd_tape_destroy": (None, [C.c_void_p]),
     "csvsimd_tape_field_cnt": (C.c_uint32, [C.c_void_p]),
@@ -232,6 +238,33 @@ class Context:
         return Tape(h)
 
 
+class Comm:
+    """Native RCCL communicator for csvsimd_stage1_index_sharded (one per rank)."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        _check(lib().csvsimd_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, unique_id: bytes, rank: int, world: int, device: int):
+        h = C.c_void_p()
+        _check(lib().csvsimd_comm_create(C.create_string_buffer(unique_id, 128), rank, world, device, C.byref(h)))
+        self._h, self.rank, self.world = h, rank, world
+
+    def close(self) -> None:
+        if self._h:
+            lib().csvsimd_comm_destroy(self._h)
+            self._h = None
+
+    def index_sharded(self, ctx: "Context", dbuf: int, length: int, base_off: int, dtape: int, tape_cap: int,
+                      file_in_quote_in: int = 0, stream: int = 0) -> Tuple[ShardResult, Stitch]:
+        r, st = ShardResult(), Stitch()
+        _check(lib().csvsimd_stage1_index_sharded(ctx._h, self._h, dbuf, length, base_off, file_in_quote_in,
+                                                  dtape or None, tape_cap, C.byref(r), C.byref(st), stream or None))
+        return r, st
+
+
 def stage1_bound(length: int) -> int:
     n = C.c_uint64()
     _check(lib().csvsimd_stage1_bound(length, C.byref(n)))
@@ -318,9 +351,11 @@ class Tape:
         return np.ctypeslib.as_array(p, shape=(n.value,)).copy()
 
     def bytes(self) -> bytes:
-        n = C.c_uint64()
-        p = lib().csvsimd_tape_bytes(self._h, C.byref(n))
-        return C.string_at(p, n.value)
+        if getattr(self, "_bytes", None) is None:  # one copy, cached: seek_* slice it
+            n = C.c_uint64()
+            p = lib().csvsimd_tape_bytes(self._h, C.byref(n))
+            self._bytes = C.string_at(p, n.value)
+        return self._bytes
 
     def _span(self, fn, *idx) -> Optional[Tuple[int, int]]:
         b, e, f = C.c_uint64(), C.c_uint64(), C.c_int()

@@ -70,6 +70,7 @@ const char* csvsimd_strerror(int code) {
         case CSVSIMD_ERR_HIP: return "HIP runtime error";
         case CSVSIMD_ERR_NO_DEVICE: return "no HIP device";
         case CSVSIMD_ERR_INTERNAL: return "internal error (look-back spin bound)";
+        case CSVSIMD_ERR_RCCL: return "RCCL unavailable or collective failed";
         default: return "unknown error";
     }
 }
@@ -338,6 +339,12 @@ struct csvsimd_tape {
     void* map = nullptr;
     uint64_t map_len = 0;
     std::vector<uint64_t> owned_index;
+    csvsimd_tape() = default;
+    csvsimd_tape(const csvsimd_tape&) = delete;
+    csvsimd_tape& operator=(const csvsimd_tape&) = delete;
+    ~csvsimd_tape() {
+        if (map) munmap(map, map_len);  // also on every error path of csvsimd_create
+    }
 };
 
 extern "C" {
@@ -357,11 +364,7 @@ int csvsimd_tape_create(const uint8_t* bytes, uint64_t len, const uint64_t* inde
     return CSVSIMD_OK;
 }
 
-void csvsimd_tape_destroy(csvsimd_tape* t) {
-    if (!t) return;
-    if (t->map) munmap(t->map, t->map_len);
-    delete t;
-}
+void csvsimd_tape_destroy(csvsimd_tape* t) { delete t; }
 
 uint32_t csvsimd_tape_field_cnt(const csvsimd_tape* t) { return t->tape.header.field_cnt; }
 uint32_t csvsimd_tape_record_cnt(const csvsimd_tape* t) { return t->tape.record_cnt_; }

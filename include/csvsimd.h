@@ -38,6 +38,7 @@ extern "C" {
 #define CSVSIMD_ERR_HIP (-12)           /* HIP runtime error: csvsimd_last_error() has the text */
 #define CSVSIMD_ERR_NO_DEVICE (-13)
 #define CSVSIMD_ERR_INTERNAL (-14) /* in-kernel look-back spin bound hit (should never happen) */
+#define CSVSIMD_ERR_RCCL (-15)     /* librccl missing or a collective failed */
 
 const char* csvsimd_strerror(int code);
 const char* csvsimd_last_error(void); /* thread-local text of the last HIP failure */
@@ -120,6 +121,25 @@ typedef struct csvsimd_stitch {
 } csvsimd_stitch;
 int csvsimd_stitch_shards(const csvsimd_shard_result* results, uint32_t n_shards, uint32_t rank,
                           uint32_t file_in_quote_in, csvsimd_stitch* out);
+
+/* Native form of the same step for hosts without torch.distributed: one communicator per rank
+ * (one process per GPU).  Rank 0 obtains an id (ncclGetUniqueId) and hands its 128 bytes to the
+ * other ranks by whatever channel the application has; every rank then creates its communicator
+ * (ncclCommInitRank).  csvsimd_stage1_index_sharded = speculative pass (entered outside a string)
+ * -> ONE ncclAllGather of the 64-byte result records over xGMI -> one copy to the host (the only
+ * synchronisation) -> csvsimd_stitch_shards -> re-emit only if this shard starts inside a quoted
+ * string.  The tape stays sharded (entries of this rank's bytes, absolute offsets).  RCCL is
+ * resolved with dlopen at first use: CSVSIMD_ERR_RCCL if it is absent. */
+#define CSVSIMD_COMM_ID_BYTES 128
+typedef struct csvsimd_comm csvsimd_comm;
+int csvsimd_comm_unique_id(uint8_t id[CSVSIMD_COMM_ID_BYTES]);
+int csvsimd_comm_create(const uint8_t id[CSVSIMD_COMM_ID_BYTES], int rank, int world, int device,
+                        csvsimd_comm** out);
+void csvsimd_comm_destroy(csvsimd_comm* comm);
+int csvsimd_stage1_index_sharded(csvsimd_ctx* ctx, csvsimd_comm* comm, const void* dbuf, uint64_t len,
+                                 uint64_t base_off, uint32_t file_in_quote_in, void* dtape,
+                                 uint64_t tape_cap, csvsimd_shard_result* result,
+                                 csvsimd_stitch* stitch, void* hip_stream);
 
 /* ---- tape: host-side, after stage 1 (reference src/tape.rs, src/record_source.rs) ------------ */
 typedef struct csvsimd_tape csvsimd_tape;

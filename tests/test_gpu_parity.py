@@ -431,3 +431,25 @@ def test_device_field_spans_and_gather(ctx, torch_cuda, pkg, golden, oracle):
     with pytest.raises(pkg.StructureError) as ei:
         pkg.tape_field_spans_device(d.data_ptr(), idx.size, 3, "LF", 0, 0, 1, d.data_ptr(), d.data_ptr())
     assert ei.value.code == pkg.ERR_INVALID_CSV_FORMAT
+
+
+def test_native_rccl_sharded_step_single_rank(ctx, torch_cuda, pkg, oracle):
+    # csvsimd_stage1_index_sharded with a real RCCL communicator (world = 1 is all a 1-GPU box
+    # allows): speculative pass, ncclAllGather of the result record, stitch, forced re-emit.
+    torch = torch_cuda
+    rng = np.random.default_rng(21)
+    d = random_csvish(rng, 2 * pkg.tile_bytes() + 999, 0.03)
+    dbuf = torch.from_numpy(d).cuda()
+    cap = d.size
+    dtape = torch.full((cap,), -1, dtype=torch.int64, device="cuda:0")
+    comm = pkg.Comm(pkg.Comm.unique_id(), 0, 1, 0)
+    try:
+        for file_inq in (0, 1):   # 1: the shard really starts inside a string -> second pass
+            dtape.fill_(-1)
+            r, st = comm.index_sharded(ctx, dbuf.data_ptr(), d.size, 1000, dtape.data_ptr(), cap, file_inq)
+            want, q = oracle.scalar_index(d, base_off=1000, in_quote_in=file_inq)
+            assert (st.in_quote_in, st.count, st.tape_index_base, st.total_entries) == (file_inq, want.size, 1, want.size + 1)
+            assert (r.count, r.in_quote_out, st.in_quote_final) == (want.size, q, q)
+            assert np.array_equal(dtape[: r.count].cpu().numpy().view(np.uint64), want)
+    finally:
+        comm.close()
