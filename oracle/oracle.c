@@ -251,6 +251,126 @@ int oracle_sse_read_growing(const uint8_t* buf, uint64_t len, uint64_t** tape_ou
 void oracle_free(void* p) { free(p); }
 
 /* ------------------------------------------------------------------------------------------
+ * multi-threaded flavour ("ref_sse_mt"): the same SSE block loop on T contiguous
+ * chunks.  NOT something the reference does (it is single-threaded); it shows what the host CPU
+ * could do with the reference's algorithm plus the same quote-parity / count stitch the GPUs use.
+ * Every chunk is indexed twice by hypothesis only when needed: pass 1 assumes "entered outside a
+ * string" and records the chunk's quote parity; chunks whose true entering state is "inside" are
+ * redone; then the per-chunk tapes are concatenated behind the sentinel.
+ * ---------------------------------------------------------------------------------------- */
+#include <pthread.h>
+
+typedef struct {
+    const uint8_t* buf;   /* chunk start (64-byte aligned offset from a 64-byte aligned base) */
+    uint64_t len, base;   /* chunk length, file offset of the chunk */
+    int64_t enter;        /* 0 or -1 */
+    uint64_t* out;        /* chunk-private tape */
+    uint64_t cap;         /* its capacity: a guess first, len + 64 after an overflow */
+    uint64_t n;
+    uint32_t parity;
+    int overflow;
+} mt_job;
+
+static void* mt_worker(void* arg) {
+    mt_job* j = (mt_job*)arg;
+    u64vec acc = {j->out, 0, j->cap, 1, 0};
+    uint64_t set_bits = 0, pos = 0;
+    uint32_t array_idx = 0;
+    int64_t inside = j->enter;
+    uint32_t parity = 0;
+    while (pos + 64 <= j->len) {
+        simd_input in;
+        const __m128i* p = (const __m128i*)(j->buf + pos);
+        in.v0 = _mm_loadu_si128(p);
+        in.v1 = _mm_loadu_si128(p + 1);
+        in.v2 = _mm_loadu_si128(p + 2);
+        in.v3 = _mm_loadu_si128(p + 3);
+        const int64_t before = inside;
+        structure(&in, &set_bits, &inside);
+        parity ^= (uint32_t)((before ^ inside) & 1);
+        crush_set_bits(&acc, set_bits, j->base + pos, &array_idx);
+        pos += 64;
+    }
+    if (pos < j->len) { /* ragged end of the last chunk: zero padded block */
+        uint8_t padded[64];
+        memset(padded, 0, sizeof padded);
+        memcpy(padded, j->buf + pos, j->len - pos);
+        simd_input in;
+        in.v0 = _mm_loadu_si128((const __m128i*)(padded));
+        in.v1 = _mm_loadu_si128((const __m128i*)(padded + 16));
+        in.v2 = _mm_loadu_si128((const __m128i*)(padded + 32));
+        in.v3 = _mm_loadu_si128((const __m128i*)(padded + 48));
+        const int64_t before = inside;
+        structure(&in, &set_bits, &inside);
+        parity ^= (uint32_t)((before ^ inside) & 1);
+        crush_set_bits(&acc, set_bits, j->base + pos, &array_idx);
+    }
+    j->n = acc.len;
+    j->parity = parity;
+    j->overflow = acc.overflow;
+    return NULL;
+}
+
+int oracle_sse_read_mt(const uint8_t* buf, uint64_t len, int threads, uint64_t* tape, uint64_t cap,
+                       uint64_t* n_out) {
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    mt_job jobs[256];
+    pthread_t th[256];
+    const uint64_t per = ((len / (uint64_t)threads) + 63) & ~63ull;
+    int used = 0;
+    for (uint64_t off = 0; off < len && used < threads; off += per, ++used) {
+        mt_job* j = &jobs[used];
+        j->buf = buf + off;
+        j->base = off;
+        j->len = (used == threads - 1 || off + per > len) ? len - off : per;
+        j->enter = 0;
+        j->cap = j->len / 8 + 1024; /* typical CSV; a denser chunk is redone with the worst case */
+        j->out = (uint64_t*)malloc(j->cap * sizeof(uint64_t));
+        if (!j->out) return ORACLE_ERR_CAPACITY;
+    }
+    for (int k = 0; k < used; ++k) pthread_create(&th[k], NULL, mt_worker, &jobs[k]);
+    for (int k = 0; k < used; ++k) pthread_join(th[k], NULL);
+    for (int k = 0; k < used; ++k) {
+        if (!jobs[k].overflow) continue;
+        free(jobs[k].out);
+        jobs[k].cap = jobs[k].len + 128;
+        jobs[k].out = (uint64_t*)malloc(jobs[k].cap * sizeof(uint64_t));
+        if (!jobs[k].out) return ORACLE_ERR_CAPACITY;
+        mt_worker(&jobs[k]);
+    }
+    /* stitch: chunks whose true entering state is "inside" run again */
+    uint32_t state = 0;
+    int redo[256], nredo = 0;
+    for (int k = 0; k < used; ++k) {
+        if (state) { jobs[k].enter = -1; redo[nredo++] = k; }
+        state ^= jobs[k].parity;
+    }
+    for (int r = 0; r < nredo; ++r) pthread_create(&th[r], NULL, mt_worker, &jobs[redo[r]]);
+    for (int r = 0; r < nredo; ++r) pthread_join(th[r], NULL);
+    for (int r = 0; r < nredo; ++r) { /* the other hypothesis can be denser than the first */
+        mt_job* j = &jobs[redo[r]];
+        if (!j->overflow) continue;
+        free(j->out);
+        j->cap = j->len + 128;
+        j->out = (uint64_t*)malloc(j->cap * sizeof(uint64_t));
+        if (!j->out) return ORACLE_ERR_CAPACITY;
+        mt_worker(j);
+    }
+    uint64_t n = 1;
+    int rc = 0;
+    if (cap >= 1) tape[0] = 0; else rc = ORACLE_ERR_CAPACITY;
+    for (int k = 0; k < used; ++k) {
+        if (n + jobs[k].n <= cap) memcpy(tape + n, jobs[k].out, jobs[k].n * sizeof(uint64_t));
+        else rc = ORACLE_ERR_CAPACITY;
+        n += jobs[k].n;
+        free(jobs[k].out);
+    }
+    *n_out = n;
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------
  * order-sensitive tape checksum (parity at sizes where entry-by-entry compare is too slow)
  * ---------------------------------------------------------------------------------------- */
 

@@ -30,6 +30,10 @@ int oracle_sse_read(const uint8_t* buf, uint64_t len, uint64_t* tape, uint64_t c
 /* same, output in a Vec-like growing buffer (the timed "ref_sse_1t" baseline); oracle_free it */
 int oracle_sse_read_growing(const uint8_t* buf, uint64_t len, uint64_t** tape_out, uint64_t* n_out);
 void oracle_free(void* p);
+/* the same block loop on `threads` contiguous chunks with a quote-parity / count stitch (not a
+ * reference behaviour: the reference is single-threaded); tape[0] = 0 sentinel */
+int oracle_sse_read_mt(const uint8_t* buf, uint64_t len, int threads, uint64_t* tape, uint64_t cap,
+                       uint64_t* n_out);
 
 /* order-sensitive checksum of tape[0..n) whose first element has global index first_index */
 void oracle_tape_checksum(const uint64_t* tape, uint64_t n, uint64_t first_index, uint64_t* s1,

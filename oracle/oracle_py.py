@@ -38,6 +38,8 @@ def lib() -> C.CDLL:
         h.oracle_sse_read_growing.restype = C.c_int
         h.oracle_sse_read_growing.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(_u64p), _u64p]
         h.oracle_free.restype, h.oracle_free.argtypes = None, [C.c_void_p]
+        h.oracle_sse_read_mt.restype = C.c_int
+        h.oracle_sse_read_mt.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, _u64p]
         h.oracle_tape_checksum.restype = None
         h.oracle_tape_checksum.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, _u64p, _u64p]
         h.oracle_synth_fill.restype = None
@@ -97,6 +99,15 @@ def sse_read_growing_timed(a: np.ndarray):
     assert rc == 0
     lib().oracle_free(p)
     return n.value, dt
+
+
+def sse_read_mt(data, threads: int) -> np.ndarray:
+    a = aligned_copy(data)
+    out = np.zeros(a.size + 2, dtype=np.uint64)
+    n = C.c_uint64()
+    rc = lib().oracle_sse_read_mt(a.ctypes.data, a.size, threads, out.ctypes.data, out.size, C.byref(n))
+    assert rc == 0
+    return out[: n.value].copy()
 
 
 def shard_descriptor(data):

@@ -125,3 +125,14 @@ def test_synth_shapes(oracle, pkg):
     d = oracle.synth(0, 200 * cols * (width + 1), cols, width, seed, q)
     assert (d == 0x22).sum() > 0 and (d == 0x22).sum() % 2 == 0
     assert ((d == 0x2C) | (d == 0x0A)).sum() > oracle.scalar_read(d).size - 1
+
+
+def test_mt_flavour_equals_scalar(oracle):
+    # the multi-threaded baseline (not a reference behaviour) must produce the same tape
+    rng = np.random.default_rng(77)
+    for n in (64, 1000, 100_003):
+        for pq in (0.0, 0.05):
+            d = random_csvish(rng, n, pq)
+            want = oracle.scalar_read(d)
+            for threads in (1, 2, 3, 8):
+                assert np.array_equal(oracle.sse_read_mt(d, threads), want), (n, pq, threads)
