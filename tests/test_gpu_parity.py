@@ -453,3 +453,32 @@ def test_native_rccl_sharded_step_single_rank(ctx, torch_cuda, pkg, oracle):
             assert np.array_equal(dtape[: r.count].cpu().numpy().view(np.uint64), want)
     finally:
         comm.close()
+
+
+def test_config4_q10_shard_with_carried_state(ctx, torch_cuda, pkg, oracle):
+    # the quoted variant of config 4 (SURVEY §8d "64x31_q10 exercises the parity stitch"): a 2 GiB
+    # shard cut mid-row (+777) out of the middle of the file, entered with whatever state the
+    # preceding bytes leave, checked against the oracle by count, state and order-sensitive checksum
+    torch = torch_cuda
+    cols, width, seed, q = pkg.WORKLOADS["64x31_q10"]
+    shard = 2 << 30
+    lo = 5 * shard + 777
+    dbuf = torch.empty(shard, dtype=torch.uint8, device="cuda:0")
+    pkg.synth_fill_device(dbuf.data_ptr(), lo, shard, cols, width, seed, q)
+    host = dbuf.cpu().numpy()
+    cap = shard // 24
+    dtape = torch.empty(cap, dtype=torch.int64, device="cuda:0")
+    for inq in (0, 1):
+        want, q_out = oracle.scalar_index(host, base_off=lo, in_quote_in=inq)
+        r = ctx.stage1_index_device(dbuf.data_ptr(), shard, lo, inq, dtape.data_ptr(), cap)
+        assert (r.count, r.in_quote_out, r.error) == (want.size, q_out, 0)
+        p, c0, c1 = oracle.shard_descriptor(host)
+        assert (r.quote_parity, r.count_enter_outside, r.count_enter_inside) == (p, c0, c1)
+        out = torch.zeros(2, dtype=torch.int64, device="cuda:0")
+        pkg.tape_checksum_device(dtape.data_ptr(), r.count, 1, out.data_ptr())
+        assert tuple(int(x) & (2**64 - 1) for x in out.cpu().tolist()) == oracle.tape_checksum(want, 1)
+        t = dtape[: r.count]
+        assert bool((t[1:] > t[:-1]).all())
+        head = 1 << 20
+        assert np.array_equal(t[:head].cpu().numpy().view(np.uint64), want[:head])
+        assert np.array_equal(t[-head:].cpu().numpy().view(np.uint64), want[-head:])
