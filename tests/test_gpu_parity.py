@@ -482,3 +482,25 @@ def test_config4_q10_shard_with_carried_state(ctx, torch_cuda, pkg, oracle):
         head = 1 << 20
         assert np.array_equal(t[:head].cpu().numpy().view(np.uint64), want[:head])
         assert np.array_equal(t[-head:].cpu().numpy().view(np.uint64), want[-head:])
+
+
+def test_fuzz_many_shapes(ctx, torch_cuda, pkg, oracle):
+    # randomized sizes (0 .. ~5 tiles), alignments, entering states, offsets and quote densities
+    torch = torch_cuda
+    rng = np.random.default_rng(20261003)
+    T = pkg.tile_bytes()
+    for case in range(120):
+        n = int(rng.choice([rng.integers(0, 300), rng.integers(300, 70000), rng.integers(T - 70, T + 70),
+                            rng.integers(T, 5 * T)]))
+        pq = float(rng.choice([0.0, 0.0005, 0.01, 0.2, 0.5]))
+        d = random_csvish(rng, n, pq)
+        if n and rng.random() < 0.3:   # long runs of one byte class
+            a, b = sorted(rng.integers(0, n + 1, size=2))
+            d[a:b] = rng.choice(np.frombuffer(b',"\na', dtype=np.uint8))
+        mis = int(rng.integers(0, 16))
+        inq = int(rng.integers(0, 2))
+        base = int(rng.integers(0, 2**40))
+        got, r = gpu_index(ctx, torch, d, base_off=base, in_quote_in=inq, misalign=mis)
+        want, q = oracle.scalar_index(d, base_off=base, in_quote_in=inq)
+        assert (r.count, r.in_quote_out, r.error) == (want.size, q, 0), (case, n, pq, mis, inq)
+        assert np.array_equal(got, want), (case, n, pq, mis, inq)

@@ -78,3 +78,25 @@ def test_header_without_following_byte_is_invalid_state(pkg):
     with pytest.raises(pkg.StructureError) as e:
         pkg.Tape.from_index(np.frombuffer(b"a,b,c", dtype=np.uint8), np.array([0, 1, 3], dtype=np.uint64))
     assert e.value.code == pkg.ERR_INVALID_STATE
+
+
+def test_header_quirks_are_mirrored(pkg):
+    # Header::new decides CRLF by looking at the byte AFTER the first line end (src/tape.rs:235-238):
+    # an LF file whose second line is empty is therefore taken for CRLF — mirrored, not fixed.
+    data = np.frombuffer(b"a,b\n\nx,y\n" + b"p" * 64, dtype=np.uint8)
+    idx = np.array([0, 1, 3, 4, 6, 8], dtype=np.uint64)     # ',', LF, LF, ',', LF
+    with pytest.raises(pkg.StructureError) as e:           # jump = 3 (CRLF), 5 % 3 != 0
+        pkg.Tape.from_index(data, idx)
+    assert e.value.code == pkg.ERR_INVALID_CSV_FORMAT
+    # names are trimmed, the delimiter is a plain ',' even inside quotes (src/tape.rs:259-262)
+    data = np.frombuffer(b'  x , "a,b" ,z\n1,2,3,4\n' + b"p" * 64, dtype=np.uint8)
+    idx = np.array([0, 4, 8, 12, 14, 16, 18, 20, 22], dtype=np.uint64)   # hand-made: every ',' and LF
+    t = pkg.Tape.from_index(data, idx)
+    assert t.header() == ["x", '"a', 'b"', "z"] and t.field_cnt == 4 and t.record_cnt == 2
+    assert t.seek_field(0, 3) == b"4" and t.seek_record(0) == b"1,2,3,4" and t.seek_record(1) is None
+    # BOM skipping takes ANY leading run of ef/bb/bf bytes (src/tape.rs:241-249)
+    data = np.frombuffer(b"\xbf\xef\xbbn,m\r\n1,2\r\n" + b"p" * 64, dtype=np.uint8)
+    idx = np.array([0, 4, 6, 7, 9, 11, 12], dtype=np.uint64)
+    t = pkg.Tape.from_index(data, idx)
+    assert t.header() == ["n", "m"] and t.new_line == "CRLF" and t.record_jump_size == 3 and t.record_cnt == 2
+    assert t.seek_field(0, 1) == b"2"
