@@ -10,7 +10,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ inline void nt_store(uint4 v, uint4* p) { u32x4 x = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(x, reinterpret_cast<u32x4*>(p)); }
 
 // each block streams tiles of 128 KiB: 256 threads x 8 rounds x 4 x 16 B (the stage-1 geometry)
-template <int WRITE_DIV, int LD_AUX, bool NT_STORE, bool DYN>
+template <int WRITE_DIV, int LD_AUX, bool NT_STORE, bool DYN, int DEPTH = 1, bool ILV = false>
 __global__ __launch_bounds__(256) void stream(const uint8_t* __restrict__ in, uint4* __restrict__ out, uint64_t n,
                                               uint32_t* ticket, uint32_t num_tiles) {
     __shared__ uint32_t s_tile;
@@ -24,18 +24,24 @@ __global__ __launch_bounds__(256) void stream(const uint8_t* __restrict__ in, ui
         const rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(in) + tile0, 0, 131072, 0x00020000);
         uint4 acc = make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            uint4 v[4];
+        for (int r0 = 0; r0 < 8; r0 += DEPTH) {
+          uint4 vv[DEPTH][4];
+#pragma unroll
+          for (int d = 0; d < DEPTH; ++d)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const auto x = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(w * 32768 + r * 4096 + j * 1024 + lane * 16), 0, LD_AUX);
-                v[j] = make_uint4(x[0], x[1], x[2], x[3]);
+                const auto x = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((ILV ? ((r0 + d) * 4 + w) * 4096 : w * 32768 + (r0 + d) * 4096) + j * 1024 + lane * 16), 0, LD_AUX);
+                vv[d][j] = make_uint4(x[0], x[1], x[2], x[3]);
             }
+#pragma unroll
+          for (int d = 0; d < DEPTH; ++d) {
+            const int r = r0 + d;
+            uint4* v = vv[d];
             uint4 o;
             o.x = v[0].x ^ v[1].x ^ v[2].x ^ v[3].x; o.y = v[0].y ^ v[1].y ^ v[2].y ^ v[3].y;
             o.z = v[0].z ^ v[1].z ^ v[2].z ^ v[3].z; o.w = v[0].w ^ v[1].w ^ v[2].w ^ v[3].w;
             if (WRITE_DIV == 4) {
-                uint4* dst = out + (tile0 / 64) + (w * 32768 + r * 4096) / 64 + lane;
+                uint4* dst = out + (tile0 / 64) + (ILV ? (r * 4 + w) * 4096 : w * 32768 + r * 4096) / 64 + lane;
                 if (NT_STORE) nt_store(o, dst); else *dst = o;
             } else if (WRITE_DIV == 1) {
 #pragma unroll
@@ -46,12 +52,13 @@ __global__ __launch_bounds__(256) void stream(const uint8_t* __restrict__ in, ui
             } else {
                 acc.x ^= o.x; acc.y ^= o.y; acc.z ^= o.z; acc.w ^= o.w;
             }
+          }
         }
         if (WRITE_DIV == 0 && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) out[0] = acc;
     }
 }
 
-template <int WRITE_DIV, int LD_AUX, bool NT_STORE, bool DYN>
+template <int WRITE_DIV, int LD_AUX, bool NT_STORE, bool DYN, int DEPTH = 1, bool ILV = false>
 int run(const char* name, const uint8_t* in, uint4* out, uint64_t n, uint32_t* ticket, int bpc) {
     const uint32_t tiles = (uint32_t)(n / 131072);
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -59,7 +66,7 @@ int run(const char* name, const uint8_t* in, uint4* out, uint64_t n, uint32_t* t
     for (int rep = 0; rep < 6; ++rep) {
         CHECK(hipMemsetAsync(ticket, 0, 4));
         CHECK(hipEventRecord(e0));
-        hipLaunchKernelGGL((stream<WRITE_DIV, LD_AUX, NT_STORE, DYN>), dim3(256 * bpc), dim3(256), 0, 0, in, out, n, ticket, tiles);
+        hipLaunchKernelGGL((stream<WRITE_DIV, LD_AUX, NT_STORE, DYN, DEPTH, ILV>), dim3(256 * bpc), dim3(256), 0, 0, in, out, n, ticket, tiles);
         CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (rep > 0 && ms < best) best = ms;
     }
@@ -73,6 +80,13 @@ int main() {
     uint8_t* in; uint4* out; uint32_t* ticket;
     CHECK(hipMalloc(&in, n)); CHECK(hipMalloc(&out, n)); CHECK(hipMalloc(&ticket, 64));
     CHECK(hipMemset(in, 0x61, n)); CHECK(hipMemset(out, 0, n));
+    for (int bpc : {2, 4, 8}) {
+        run<4, 2, true, true, 2>("read nt + write 1/4 nt, ticket, depth 2", in, out, n, ticket, bpc);
+        run<4, 2, true, true, 4>("read nt + write 1/4 nt, ticket, depth 4", in, out, n, ticket, bpc);
+        run<0, 2, false, true, 4>("read only nt, ticket, depth 4", in, out, n, ticket, bpc);
+        run<4, 2, true, true, 2, true>("INTERLEAVED rounds: read nt + write 1/4 nt, depth 2", in, out, n, ticket, bpc);
+        run<0, 2, false, true, 2, true>("INTERLEAVED rounds: read only nt, depth 2", in, out, n, ticket, bpc);
+    }
     for (int bpc : {4, 8}) {
         run<0, 0, false, false>("read only, static", in, out, n, ticket, bpc);
         run<0, 0, false, true>("read only, ticket", in, out, n, ticket, bpc);
