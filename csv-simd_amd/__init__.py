@@ -46,10 +46,24 @@ class ShardResult(C.Structure):
         ("quote_parity", C.c_uint32),
         ("in_quote_out", C.c_uint32),
         ("error", C.c_uint32),
-        ("reserved0", C.c_uint32),
+        ("escape_out", C.c_uint32),
         ("written", C.c_uint64),
         ("reserved1", C.c_uint64 * 2),
     ]
+
+
+class Dialect(C.Structure):
+    """csvsimd_dialect — extension beyond the reference (which hard-wires ',' and '"',
+    src/avx/stage1.rs:392-394).  quote / escape 0 = off."""
+    _fields_ = [("delimiter", C.c_uint8), ("quote", C.c_uint8), ("escape", C.c_uint8), ("escape_in", C.c_uint8),
+                ("reserved", C.c_uint32)]
+
+    def __init__(self, delimiter=",", quote='"', escape=None, escape_in: int = 0):
+        def byte(v):
+            if v is None:
+                return 0
+            return v if isinstance(v, int) else ord(v)
+        super().__init__(byte(delimiter), byte(quote), byte(escape), 1 if escape_in else 0, 0)
 
 
 class Stitch(C.Structure):
@@ -85,6 +99,12 @@ _PROTOTYPES = {
                                                     C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "csvsimd_stage1_index_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32,
                                               C.c_void_p, C.c_uint64, C.POINTER(ShardResult), C.c_void_p]),
+    "csvsimd_dialect_init": (C.c_int, [C.POINTER(Dialect)]),
+    "csvsimd_stage1_index_device_dialect_async": (C.c_int, [C.c_void_p, C.POINTER(Dialect), C.c_void_p, C.c_uint64,
+                                                            C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64,
+                                                            C.c_void_p, C.c_void_p]),
+    "csvsimd_stage1_index_dialect": (C.c_int, [C.c_void_p, C.POINTER(Dialect), C.c_void_p, C.c_uint64, C.c_void_p,
+                                               C.c_uint64, _u64p, C.POINTER(C.c_uint32)]),
     "csvsimd_stage1_bound": (C.c_int, [C.c_uint64, _u64p]),
     "csvsimd_stage1_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, _u64p,
                                        C.POINTER(C.c_uint32)]),
@@ -198,6 +218,13 @@ class Context:
         _check(lib().csvsimd_stage1_index_device_async(self._h, dbuf, length, base_off, in_quote_in,
                                                        dtape or None, tape_cap, d_result, stream or None))
 
+    def stage1_index_device_dialect_async(self, dialect: Dialect, dbuf: int, length: int, base_off: int,
+                                          in_quote_in: int, dtape: int, tape_cap: int, d_result: int,
+                                          stream: int = 0) -> None:
+        _check(lib().csvsimd_stage1_index_device_dialect_async(self._h, C.byref(dialect), dbuf, length, base_off,
+                                                               in_quote_in, dtape or None, tape_cap, d_result,
+                                                               stream or None))
+
     def stage1_time_device(self, dbuf: int, length: int, dtape: int, tape_cap: int, d_result: int,
                            stream: int = 0, warmup: int = 2, iters: int = 10) -> float:
         ms = C.c_float()
@@ -219,6 +246,21 @@ class Context:
         if rc == ERR_TAPE_CAPACITY:
             out = np.empty(n.value, dtype=np.uint64)
             rc = lib().csvsimd_stage1_index(self._h, ptr, a.size, out.ctypes.data, out.size, C.byref(n), None)
+        _check(rc)
+        return out[: n.value].copy()
+
+    def read_dialect(self, data, dialect: Dialect) -> np.ndarray:
+        """read() for another delimiter / quote / escape byte (extension, see include/csvsimd.h)."""
+        a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        n = C.c_uint64()
+        ptr = a.ctypes.data if a.size else None
+        out = np.empty(a.size // 8 + 64, dtype=np.uint64)
+        fn = lib().csvsimd_stage1_index_dialect
+        rc = fn(self._h, C.byref(dialect), ptr, a.size, out.ctypes.data, out.size, C.byref(n), None)
+        if rc == ERR_TAPE_CAPACITY:
+            out = np.empty(n.value, dtype=np.uint64)
+            rc = fn(self._h, C.byref(dialect), ptr, a.size, out.ctypes.data, out.size, C.byref(n), None)
         _check(rc)
         return out[: n.value].copy()
 

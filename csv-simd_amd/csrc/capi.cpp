@@ -145,12 +145,23 @@ int csvsimd_ctx_reserve(csvsimd_ctx* ctx, uint64_t max_len) {
     return CSVSIMD_OK;
 }
 
-int csvsimd_stage1_index_device_async(csvsimd_ctx* ctx, const void* dbuf, uint64_t len, uint64_t base_off,
-                                      uint32_t in_quote_in, void* dtape, uint64_t tape_cap, void* d_result,
-                                      void* hip_stream) {
+// dialect == nullptr: the reference's hard-wired dialect (',' '"', no escape byte)
+static int dialect_check(const csvsimd_dialect* d) {
+    if (!d) return CSVSIMD_OK;
+    const uint8_t dl = d->delimiter, q = d->quote, e = d->escape;
+    if (dl == 0 || dl == 0x0a || dl == 0x0d) return CSVSIMD_ERR_INVALID_ARG;
+    if (q && (q == dl || q == 0x0a || q == 0x0d)) return CSVSIMD_ERR_INVALID_ARG;
+    if (e && (e == dl || e == q || e == 0x0a || e == 0x0d)) return CSVSIMD_ERR_INVALID_ARG;
+    return CSVSIMD_OK;
+}
+
+static int stage1_async_impl(csvsimd_ctx* ctx, const csvsimd_dialect* dialect, const void* dbuf, uint64_t len,
+                             uint64_t base_off, uint32_t in_quote_in, void* dtape, uint64_t tape_cap, void* d_result,
+                             void* hip_stream) {
     if (!ctx || !d_result || (len && !dbuf) || (!dtape && tape_cap)) return CSVSIMD_ERR_INVALID_ARG;
     if (len >= (1ull << 60)) return CSVSIMD_ERR_INVALID_ARG;
     if (((uintptr_t)dtape & 7) || ((uintptr_t)d_result & 15)) return CSVSIMD_ERR_INVALID_ARG;
+    if (dialect_check(dialect) != CSVSIMD_OK) return CSVSIMD_ERR_INVALID_ARG;
     if (csvsimd::Stage1Launch::scratch_bytes_for(len) > ctx->scratch_bytes) {
         const int rc = csvsimd_ctx_reserve(ctx, len);  // allocates + synchronises: not capturable
         if (rc != CSVSIMD_OK) return rc;
@@ -165,8 +176,35 @@ int csvsimd_stage1_index_device_async(csvsimd_ctx* ctx, const void* dbuf, uint64
     L.d_result = (csvsimd_shard_result*)d_result;
     L.bind_scratch(ctx->scratch);
     L.max_blocks = ctx->max_blocks;
+    if (dialect) {
+        L.delimiter = dialect->delimiter;
+        L.quote = dialect->quote;
+        L.escape = dialect->escape;
+        L.escape_in = dialect->escape_in ? 1u : 0u;
+    }
     HIP_TRY(csvsimd::launch_stage1(L, (hipStream_t)hip_stream));
     return CSVSIMD_OK;
+}
+
+int csvsimd_stage1_index_device_async(csvsimd_ctx* ctx, const void* dbuf, uint64_t len, uint64_t base_off,
+                                      uint32_t in_quote_in, void* dtape, uint64_t tape_cap, void* d_result,
+                                      void* hip_stream) {
+    return stage1_async_impl(ctx, nullptr, dbuf, len, base_off, in_quote_in, dtape, tape_cap, d_result, hip_stream);
+}
+
+int csvsimd_dialect_init(csvsimd_dialect* d) {
+    if (!d) return CSVSIMD_ERR_INVALID_ARG;
+    memset(d, 0, sizeof(*d));
+    d->delimiter = ',';
+    d->quote = '"';
+    return CSVSIMD_OK;
+}
+
+int csvsimd_stage1_index_device_dialect_async(csvsimd_ctx* ctx, const csvsimd_dialect* dialect, const void* dbuf,
+                                              uint64_t len, uint64_t base_off, uint32_t in_quote_in, void* dtape,
+                                              uint64_t tape_cap, void* d_result, void* hip_stream) {
+    if (!dialect) return CSVSIMD_ERR_INVALID_ARG;
+    return stage1_async_impl(ctx, dialect, dbuf, len, base_off, in_quote_in, dtape, tape_cap, d_result, hip_stream);
 }
 
 int csvsimd_stage1_index_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len, uint64_t base_off,
@@ -231,9 +269,13 @@ static int pipe_ensure_out(csvsimd_ctx* ctx, int k, uint64_t entries) {
     return CSVSIMD_OK;
 }
 
-int csvsimd_stage1_index(csvsimd_ctx* ctx, const uint8_t* buf, uint64_t len, uint64_t* tape, uint64_t tape_cap,
-                         uint64_t* tape_len, uint32_t* in_quote_out) {
+static int stage1_index_host_impl(csvsimd_ctx* ctx, const csvsimd_dialect* dialect, const uint8_t* buf, uint64_t len,
+                                  uint64_t* tape, uint64_t tape_cap, uint64_t* tape_len, uint32_t* in_quote_out) {
     if (!ctx || (len && !buf) || (!tape && tape_cap) || !tape_len) return CSVSIMD_ERR_INVALID_ARG;
+    if (dialect_check(dialect) != CSVSIMD_OK) return CSVSIMD_ERR_INVALID_ARG;
+    csvsimd_dialect dia;  // per-chunk copy: escape_in is carried from chunk to chunk like the quote state
+    if (dialect) dia = *dialect;
+    const csvsimd_dialect* dp = dialect ? &dia : nullptr;
     HIP_TRY(hipSetDevice(ctx->device));
     int rc = pipe_setup(ctx);
     if (rc != CSVSIMD_OK) return rc;
@@ -267,8 +309,8 @@ int csvsimd_stage1_index(csvsimd_ctx* ctx, const uint8_t* buf, uint64_t len, uin
             if (rc != CSVSIMD_OK) return rc;
             cap = ctx->d_tape_entries[k];
         }
-        rc = csvsimd_stage1_index_device_async(ctx, ctx->d_in[k], clen, off, inq, tape ? ctx->d_tape[k] : nullptr, cap,
-                                               ctx->d_res[k], st);
+        rc = stage1_async_impl(ctx, dp, ctx->d_in[k], clen, off, inq, tape ? ctx->d_tape[k] : nullptr, cap, ctx->d_res[k],
+                               st);
         if (rc != CSVSIMD_OK) return rc;
         HIP_TRY(hipMemcpyAsync(&ctx->h_res[k], ctx->d_res[k], sizeof(csvsimd_shard_result), hipMemcpyDeviceToHost, st));
         // while chunk i is in flight: stage chunk i+1, unload the tape of chunk i-1
@@ -281,8 +323,8 @@ int csvsimd_stage1_index(csvsimd_ctx* ctx, const uint8_t* buf, uint64_t len, uin
         if (tape && r.count > cap) {  // denser than guessed: exact capacity, run the chunk again
             rc = pipe_ensure_tape(ctx, k, r.count);
             if (rc != CSVSIMD_OK) return rc;
-            rc = csvsimd_stage1_index_device_async(ctx, ctx->d_in[k], clen, off, inq, ctx->d_tape[k],
-                                                   ctx->d_tape_entries[k], ctx->d_res[k], st);
+            rc = stage1_async_impl(ctx, dp, ctx->d_in[k], clen, off, inq, ctx->d_tape[k], ctx->d_tape_entries[k],
+                                   ctx->d_res[k], st);
             if (rc != CSVSIMD_OK) return rc;
             HIP_TRY(hipStreamSynchronize(st));
         }
@@ -298,6 +340,7 @@ int csvsimd_stage1_index(csvsimd_ctx* ctx, const uint8_t* buf, uint64_t len, uin
         }
         n += r.count;
         inq = r.in_quote_out;
+        dia.escape_in = (uint8_t)r.escape_out;
     }
     rc = unload(0);
     if (rc != CSVSIMD_OK) return rc;
@@ -307,6 +350,17 @@ int csvsimd_stage1_index(csvsimd_ctx* ctx, const uint8_t* buf, uint64_t len, uin
     if (in_quote_out) *in_quote_out = inq;
     if (tape && n > tape_cap) return CSVSIMD_ERR_TAPE_CAPACITY;
     return CSVSIMD_OK;
+}
+
+int csvsimd_stage1_index(csvsimd_ctx* ctx, const uint8_t* buf, uint64_t len, uint64_t* tape, uint64_t tape_cap,
+                         uint64_t* tape_len, uint32_t* in_quote_out) {
+    return stage1_index_host_impl(ctx, nullptr, buf, len, tape, tape_cap, tape_len, in_quote_out);
+}
+
+int csvsimd_stage1_index_dialect(csvsimd_ctx* ctx, const csvsimd_dialect* dialect, const uint8_t* buf, uint64_t len,
+                                 uint64_t* tape, uint64_t tape_cap, uint64_t* tape_len, uint32_t* in_quote_out) {
+    if (!dialect) return CSVSIMD_ERR_INVALID_ARG;
+    return stage1_index_host_impl(ctx, dialect, buf, len, tape, tape_cap, tape_len, in_quote_out);
 }
 
 int csvsimd_stitch_shards(const csvsimd_shard_result* results, uint32_t n_shards, uint32_t rank,
@@ -564,6 +618,14 @@ int csvsimd_stage1_time_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len,
     if (const char* dbg = getenv("CSVSIMD_PROBE_MODE")) {  // development probes only (scripts/probe.py)
         L.debug_mode = atoi(dbg);
         if (const char* mb = getenv("CSVSIMD_PROBE_BLOCKS_PER_CU")) L.max_blocks = 256u * (uint32_t)atoi(mb);
+    }
+    if (const char* dia = getenv("CSVSIMD_PROBE_DIALECT")) {  // "delimiter,quote,escape" as decimal bytes
+        unsigned d = ',', q = '"', e = 0;
+        if (sscanf(dia, "%u,%u,%u", &d, &q, &e) >= 1) {
+            L.delimiter = (uint8_t)d;
+            L.quote = (uint8_t)q;
+            L.escape = (uint8_t)e;
+        }
     }
     for (int i = 0; i < warmup; ++i) HIP_TRY(csvsimd::launch_stage1(L, s));
     // one event pair per launch, recorded on the launch stream right around the stage-1 kernel

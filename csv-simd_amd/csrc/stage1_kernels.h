@@ -42,6 +42,9 @@ struct Stage1Launch {
     // optional: recorded immediately around the stage-1 kernel itself (bench roofline leg)
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     int debug_mode = 0;  // development probes (see stage1_kernel's DBG); product paths leave it 0
+    // dialect extension (csvsimd_dialect): the defaults are the reference's hard-wired dialect
+    uint8_t delimiter = ',', quote = '"', escape = 0;
+    uint32_t escape_in = 0;
 
     static uint64_t scratch_bytes_for(uint64_t len) {
         // + 1 tile: an unaligned dbuf shifts the data by up to 15 bytes

@@ -48,7 +48,7 @@ static constexpr int kRows = 4;                         // 1-KiB rows (dwordx4 w
 static constexpr int kRoundBytes = kRows * 1024;        // 4 KiB per wave per round = 64 stripes of 64 B
 static constexpr int kRounds = CSVSIMD_ROUNDS;          // rounds per wave per tile
 static constexpr int kSpanBytes = kRounds * kRoundBytes;  // 32 KiB contiguous per wave
-static constexpr int kTileBytes = kWaves * kSpanBytes;    // 128 KiB per workgroup tile
+static constexpr int kTileBytes = kWaves * kSpanBytes;    // 256 KiB per workgroup tile
 static constexpr int kCompCap = 2048;                   // u16 entries per wave compaction window (aliases the stage image)
 // every input byte is read exactly once and every tape byte written exactly once: non-temporal
 // on both sides (measured on the same traffic mix: +11 % over default-policy loads and stores)
@@ -133,6 +133,84 @@ __device__ __forceinline__ void classify16(uint4 v, u32& st16, u32& q16) {
     // acc = 128 * (8-bit mask)
     st16 = (s_lo >> 7) | (s_hi << 1);
     q16 = (q_lo >> 7) | (q_hi << 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dialect extension (NOT reference behaviour: the reference hard-wires ','
+// and '"', src/avx/stage1.rs:392-394, and lists escapes as a TODO, README.md:32).  Any delimiter /
+// quote / escape byte: no hash of arbitrary bytes into the 8 LUT slots is guaranteed to be
+// collision free, so these variants compare against each special byte directly (xor + v_lerp_u8
+// zero test per special): 13 VALU per dword without, 16 with an escape byte, instead of 10.
+//   DIALECT 0 = the reference dialect above (the only one the headline numbers are quoted on)
+//   DIALECT 1 = runtime delimiter and quote byte (quote_mask 0 switches quoting off)
+//   DIALECT 2 = DIALECT 1 + an escape byte: the byte after an unescaped escape byte is literal
+// ---------------------------------------------------------------------------------------------
+struct DialectRegs {
+    u32 delim, quote, esc;  // the byte replicated into all four lanes of a dword
+    u32 qmask;              // 0x80808080, or 0 when the dialect has no quote byte
+};
+
+template <int DIALECT>
+__device__ __forceinline__ void classify_dword_d(u32 x, u32 w, const DialectRegs& dr, u32& acc_s, u32& acc_q,
+                                                 u32& acc_e) {
+    const u32 nzd = __builtin_amdgcn_lerp(x ^ dr.delim, 0xffffffffu, 0u);
+    const u32 nzc = __builtin_amdgcn_lerp(x ^ 0x0d0d0d0du, 0xffffffffu, 0u);
+    const u32 nzl = __builtin_amdgcn_lerp(x ^ 0x0a0a0a0au, 0xffffffffu, 0u);
+    const u32 nzq = __builtin_amdgcn_lerp(x ^ dr.quote, 0xffffffffu, 0u);
+    const u32 fs = ~(nzd & nzc & nzl) & 0x80808080u;
+    const u32 fq = ~nzq & dr.qmask;
+    acc_s = __builtin_amdgcn_udot4(fs, w, acc_s, false);
+    acc_q = __builtin_amdgcn_udot4(fq, w, acc_q, false);
+    if (DIALECT == 2) {
+        const u32 nze = __builtin_amdgcn_lerp(x ^ dr.esc, 0xffffffffu, 0u);
+        acc_e = __builtin_amdgcn_udot4(~nze & 0x80808080u, w, acc_e, false);
+    }
+}
+
+template <int DIALECT>
+__device__ __forceinline__ void classify16_d(uint4 v, const DialectRegs& dr, u32& st16, u32& q16, u32& e16) {
+    u32 s_lo = 0, q_lo = 0, e_lo = 0, s_hi = 0, q_hi = 0, e_hi = 0;
+    classify_dword_d<DIALECT>(v.x, 0x08040201u, dr, s_lo, q_lo, e_lo);
+    classify_dword_d<DIALECT>(v.y, 0x80402010u, dr, s_lo, q_lo, e_lo);
+    classify_dword_d<DIALECT>(v.z, 0x08040201u, dr, s_hi, q_hi, e_hi);
+    classify_dword_d<DIALECT>(v.w, 0x80402010u, dr, s_hi, q_hi, e_hi);
+    st16 = (s_lo >> 7) | (s_hi << 1);
+    q16 = (q_lo >> 7) | (q_hi << 1);
+    e16 = (e_lo >> 7) | (e_hi << 1);
+}
+
+// Escaped-byte mask of one 64-byte stripe from its escape-byte mask `bs` and `in` (= byte 0 is
+// escaped).  Same carry-propagating-add idea simdjson uses for JSON backslashes: a run of escape
+// bytes escapes the byte after it iff its length is odd; runs are separated by parity of their
+// start position and resolved with one 64-bit add.
+__device__ __forceinline__ u64 escaped_mask(u64 bs, u32 in) {
+    constexpr u64 kEven = 0x5555555555555555ull;
+    const u64 b1 = bs & ~(u64)in;
+    const u64 follows = (b1 << 1) | (u64)in;
+    const u64 odd_starts = b1 & ~kEven & ~follows;
+    const u64 inv = (odd_starts + b1) << 1;
+    return (kEven ^ inv) & follows;
+}
+
+// Parity of the run of escape bytes that ends right before abase[pos] (valid bytes are
+// abase[lo, hi)); a run that reaches the shard start continues into esc_in.  Whole wave, uniform.
+__device__ __forceinline__ u32 escape_run_parity(const uint8_t* abase, u64 lo, u64 hi, u64 pos, u32 esc_byte,
+                                                 u32 esc_in, u32 lane) {
+    u32 total = 0;
+    for (;;) {
+        // lane k looks at byte pos - 1 - k
+        const bool inside = pos >= lo + 1 + lane && pos - 1 - lane < hi;
+        bool is = false;
+        if (inside) is = abase[pos - 1 - lane] == (uint8_t)esc_byte;
+        const u64 nb = ~__ballot(is);
+        const u32 run = nb ? (u32)__builtin_ctzll(nb) : 64u;
+        total += run;
+        if (run < 64u) {
+            const bool reached_lo = pos < lo + 1 + run;  // the run was ended by the shard start
+            return (total & 1u) ^ (reached_lo ? esc_in : 0u);
+        }
+        pos -= 64;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -329,10 +407,12 @@ struct EdgeKeep {
     u32 back_round;  // round index of this lane's partially valid last stripe, or 0xff
     u64 back_keep;   // bits to keep in that round
     u64 front_keep;  // bits to keep in round 0 (all ones unless this lane holds stripe 0 and lo > 0)
+    u64 front_esc;   // escape dialect only: a synthetic escape byte right before a misaligned shard start
 };
 
-__device__ __forceinline__ EdgeKeep edge_keep_of_tile(u32 lane, u32 w, u32 lo_rel, u32 hi_rel) {
+__device__ __forceinline__ EdgeKeep edge_keep_of_tile(u32 lane, u32 w, u32 lo_rel, u32 hi_rel, u32 esc_in = 0) {
     EdgeKeep e;
+    e.front_esc = 0;
     e.back_round = 0xffu;
     e.back_keep = ~0ull;
     e.front_keep = ~0ull;
@@ -344,7 +424,11 @@ __device__ __forceinline__ EdgeKeep edge_keep_of_tile(u32 lane, u32 w, u32 lo_re
             e.back_keep = (1ull << (hi_rel & 63u)) - 1ull;
         }
     }
-    if (lo_rel != 0u && w == 0 && lane == 0) e.front_keep = ~((1ull << lo_rel) - 1ull);  // lo_rel < 16
+    if (lo_rel != 0u && w == 0 && lane == 0) {
+        e.front_keep = ~((1ull << lo_rel) - 1ull);  // lo_rel < 16
+        // "the first valid byte is escaped" = an unescaped escape byte in the dropped slot before it
+        if (esc_in) e.front_esc = 1ull << (lo_rel - 1u);
+    }
     return e;
 }
 
@@ -381,9 +465,11 @@ __device__ __forceinline__ void dma_round(rsrc_t rsrc, u32 voff, uint4* stage) {
 // basic block and must not be duplicated under a branch: with control flow around it LLVM
 // hoists/sinks the classification across all eight rounds (128+ live VGPRs).  The sched_barriers
 // keep the machine scheduler from doing the same and the opaque asm anchors each round's results.
+template <int DIALECT>
 __device__ __forceinline__ void count_phase(rsrc_t rsrc, u32 lane, u32 w, const EdgeKeep& ek, uint4* stage0,
                                             uint4* stage1, const StageAddr sa, RoundMasks (&m)[kRounds],
-                                            u32& carry, u32& cnt_a, u32& cnt_t) {
+                                            u32& carry, u32& cnt_a, u32& cnt_t, const DialectRegs& dr,
+                                            u32 esc_carry) {
     // two images per wave: rounds r+1 and r+2 stream in (8 KiB per wave in flight, no VGPRs) while
     // round r is classified
     u32 voff = w * (u32)kSpanBytes + sa.src;  // one running VGPR, advanced per round
@@ -414,13 +500,38 @@ __device__ __forceinline__ void count_phase(rsrc_t rsrc, u32 lane, u32 w, const 
             dma_round(rsrc, voff, stage);
         }
         __builtin_amdgcn_sched_barrier(0);
-        u32 st16[kRows], q16[kRows];
+        u32 st16[kRows], q16[kRows], e16[kRows];
 #pragma unroll
-        for (int k = 0; k < kRows; ++k) classify16(stripe[k], st16[k], q16[k]);
+        for (int k = 0; k < kRows; ++k) {
+            if (DIALECT == 0)
+                classify16(stripe[k], st16[k], q16[k]);
+            else
+                classify16_d<DIALECT>(stripe[k], dr, st16[k], q16[k], e16[k]);
+        }
         u64 keep = ek.back_round == (u32)r ? ek.back_keep : ~0ull;
         if (r == 0) keep &= ek.front_keep;
-        const u64 st = ((u64)(st16[0] | (st16[1] << 16)) | ((u64)(st16[2] | (st16[3] << 16)) << 32)) & keep;
+        u64 st = ((u64)(st16[0] | (st16[1] << 16)) | ((u64)(st16[2] | (st16[3] << 16)) << 32)) & keep;
         u64 x = ((u64)(q16[0] | (q16[1] << 16)) | ((u64)(q16[2] | (q16[3] << 16)) << 32)) & keep;
+        if (DIALECT == 2) {
+            u64 bs = ((u64)(e16[0] | (e16[1] << 16)) | ((u64)(e16[2] | (e16[3] << 16)) << 32)) & keep;
+            if (r == 0) bs |= ek.front_esc;
+            // does this stripe END inside an odd run of escape bytes (O), or is it one whole run (A)?
+            // The carry into every lane is then the carry chain of the scalar add (O|A) + O + carry-in:
+            // O generates, A propagates.
+            const u64 nb = ~bs;
+            const u32 lead = nb ? (u32)__builtin_clzll(nb) : 64u;
+            const u64 gen = __ballot(lead < 64u && (lead & 1u));
+            const u64 prop = __ballot(lead == 64u);
+            const u64 a = gen | prop;
+            const u64 s1 = a + gen;
+            const u64 s2 = s1 + esc_carry;
+            const u64 into = s2 ^ prop;  // bit l = the first byte of lane l's stripe is escaped
+            esc_carry = (u32)__builtin_amdgcn_readfirstlane((int)((u32)(s1 < a) | (u32)(s2 < s1)));
+            const u64 escaped = escaped_mask(bs, (u32)(into >> lane) & 1u);
+            st &= ~escaped;
+            x &= ~escaped;
+            asm volatile("" : "+s"(esc_carry));
+        }
         // inclusive prefix-xor over the stripe's 64 bits (src/avx/stage1.rs:342-361 does this
         // with one PCLMULQDQ; CDNA has no carry-less multiply)
         x ^= x << 1;
@@ -455,6 +566,9 @@ struct KernelArgs {
     u32* ticket;    // zeroed
     u64* tot_struct;  // 64 sharded counters, zeroed: total comma/CR/LF bytes
     csvsimd_shard_result* result;
+    // dialect variants only (DIALECT != 0)
+    u32 delim, quote, escape;  // bytes; quote / escape 0 = feature off
+    u32 escape_in;             // the first byte of the shard is escaped
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -596,7 +710,7 @@ __device__ __forceinline__ void wg_barrier() {
 #else
 #define CSVSIMD_LAUNCH_BOUNDS __launch_bounds__(kThreads)
 #endif
-template <bool EMIT, int DBG = 0>
+template <bool EMIT, int DBG = 0, int DIALECT = 0>
 __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
     __shared__ u32 s_tile;
     __shared__ u32 s_wdesc[kWaves][3];
@@ -654,7 +768,23 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
 
             // ---- count phase: masks for the whole span stay in registers ---------------------
             u32 carry = 0, cnt_a = 0, cnt_t = 0;
-            const EdgeKeep ek = edge_keep_of_tile(lane, w, lo_rel, hi_rel);
+            const EdgeKeep ek = edge_keep_of_tile(lane, w, lo_rel, hi_rel, DIALECT == 2 ? args.escape_in : 0u);
+            DialectRegs dr = {0, 0, 0, 0};
+            u32 esc_carry = 0;
+            if (DIALECT != 0) {
+                dr.delim = args.delim * 0x01010101u;
+                dr.quote = args.quote * 0x01010101u;
+                dr.esc = args.escape * 0x01010101u;
+                dr.qmask = args.quote ? 0x80808080u : 0u;
+            }
+            if (DIALECT == 2) {
+                // escape state entering this wave span: parity of the escape run that ends right
+                // before it (one 64-byte peek; a misaligned shard start is handled by ek.front_esc)
+                const u64 span0 = tile0 + (u64)w * kSpanBytes;
+                if (span0 > args.lo || lo_rel == 0u)
+                    esc_carry = (u32)__builtin_amdgcn_readfirstlane(
+                        (int)escape_run_parity(args.abase, args.lo, args.hi, span0, args.escape, args.escape_in, lane));
+            }
             if (DBG & 1) {
                 uint4 v[kRows];
                 u32 acc = 0;
@@ -668,7 +798,8 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
                 }
                 cnt_a = acc & 1u;
             } else {
-                count_phase(rsrc, lane, w, ek, s_stage[w], s_stage_b[w], sa, m, carry, cnt_a, cnt_t);
+                count_phase<DIALECT>(rsrc, lane, w, ek, s_stage[w], s_stage_b[w], sa, m, carry, cnt_a, cnt_t, dr,
+                                     esc_carry);
             }
             const u32 wave_a = wave_sum(cnt_a);
             const u32 wave_t = wave_sum(cnt_t);
@@ -757,8 +888,10 @@ __global__ void zero_kernel(uint4* a, u32 a_vec16, uint4* b, u32 b_vec16) {
 
 // sums the sharded structural-byte counters into the result (tiny, 1 wave)
 __global__ void finalize_kernel(const u64* tot_struct, csvsimd_shard_result* result, u32 in_quote_in,
-                                u32 num_tiles) {
+                                u32 num_tiles, const uint8_t* abase, u64 lo, u64 hi, u32 escape, u32 escape_in) {
     const u32 lane = threadIdx.x;
+    // escape dialect: is the byte after the shard escaped? (chains into the next shard's escape_in)
+    const u32 esc_out = escape ? escape_run_parity(abase, lo, hi, hi, escape, escape_in, lane) : 0u;
     u64 v = lane < 8 ? tot_struct[lane] : 0;  // 8 sharded counters; [8..] are timing-probe slots
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -778,6 +911,7 @@ __global__ void finalize_kernel(const u64* tot_struct, csvsimd_shard_result* res
         // total = count_enter_outside + count_enter_inside, whichever hypothesis was run
         result->count_enter_outside = in_quote_in ? total - count : count;
         result->count_enter_inside = in_quote_in ? count : total - count;
+        result->escape_out = esc_out;
     }
 }
 
@@ -951,6 +1085,12 @@ hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream) {
     a.ticket = L.scratch_ticket;
     a.tot_struct = L.scratch_tot;
     a.result = L.d_result;
+    a.delim = L.delimiter;
+    a.quote = L.quote;
+    a.escape = L.escape;
+    a.escape_in = (L.escape && L.escape_in) ? 1u : 0u;
+    // 0 = the reference dialect (the tuned LUT classification), 1 = other delimiter / quote, 2 = + escape
+    const int dialect = L.escape ? 2 : (L.delimiter != ',' || L.quote != '"') ? 1 : 0;
 
     hipError_t e;
     // one launch zeroes ticket + sharded totals + descriptors (contiguous, 16-byte granular) and
@@ -979,6 +1119,14 @@ hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream) {
             hipLaunchKernelGGL((stage1_kernel<true, 8>), dim3(grid), dim3(kThreads), 0, stream, a);
         else if (L.debug_mode == 8)
             hipLaunchKernelGGL((stage1_kernel<false, 8>), dim3(grid), dim3(kThreads), 0, stream, a);
+        else if (dialect == 2 && a.tape)
+            hipLaunchKernelGGL((stage1_kernel<true, 0, 2>), dim3(grid), dim3(kThreads), 0, stream, a);
+        else if (dialect == 2)
+            hipLaunchKernelGGL((stage1_kernel<false, 0, 2>), dim3(grid), dim3(kThreads), 0, stream, a);
+        else if (dialect == 1 && a.tape)
+            hipLaunchKernelGGL((stage1_kernel<true, 0, 1>), dim3(grid), dim3(kThreads), 0, stream, a);
+        else if (dialect == 1)
+            hipLaunchKernelGGL((stage1_kernel<false, 0, 1>), dim3(grid), dim3(kThreads), 0, stream, a);
         else if (a.tape)
             hipLaunchKernelGGL((stage1_kernel<true, 0>), dim3(grid), dim3(kThreads), 0, stream, a);
         else
@@ -988,7 +1136,7 @@ hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream) {
         if (L.ev_end && (e = hipEventRecord(L.ev_end, stream)) != hipSuccess) return e;
     }
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, stream, a.tot_struct, a.result,
-                       a.in_quote_in, a.num_tiles);
+                       a.in_quote_in, a.num_tiles, a.abase, a.lo, a.hi, a.escape, a.escape_in);
     return hipGetLastError();
 }
 

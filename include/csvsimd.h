@@ -65,7 +65,7 @@ typedef struct csvsimd_shard_result {
     uint32_t quote_parity;        /* number of '"' bytes in the shard, mod 2                  */
     uint32_t in_quote_out;        /* in_quote_in ^ quote_parity                               */
     uint32_t error;               /* 0, or CSVSIMD_ERR_INTERNAL's in-kernel flag              */
-    uint32_t reserved0;
+    uint32_t escape_out;          /* escape dialects only: the byte after the shard is escaped */
     uint64_t written;             /* min(count, tape_cap): entries actually stored            */
     uint64_t reserved1[2];
 } csvsimd_shard_result;
@@ -105,6 +105,34 @@ int csvsimd_stage1_index_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len
 int csvsimd_stage1_bound(uint64_t len, uint64_t* max_entries);
 int csvsimd_stage1_index(csvsimd_ctx* ctx, const uint8_t* buf, uint64_t len, uint64_t* tape,
                          uint64_t tape_cap, uint64_t* tape_len, uint32_t* in_quote_out);
+
+/* ---- dialect extension -------------------------------------------------
+ * NOT reference behaviour: the reference hard-wires ',' and '"' (src/avx/stage1.rs:392-394);
+ * its class table already knows backslash and space (src/stage1.rs:41-48) but nothing uses them
+ * and escapes are a README TODO (README.md:32).  The entry points above never take this path, so
+ * the default stays bit-exact with reader::read.  Semantics (checked against
+ * oracle_dialect_index): the byte after an unescaped `escape` byte is literal; an unescaped
+ * `quote` byte toggles the in-string state; an unescaped `delimiter`, CR or LF outside a string
+ * is structural.  quote = 0 / escape = 0 switch that feature off.  delimiter must be non-zero and
+ * all special bytes pairwise distinct (CSVSIMD_ERR_INVALID_ARG otherwise).
+ * Shards: escape_in = "the first byte of this buffer is escaped" (the buffer before it ended in an
+ * odd run of escape bytes = that shard's result.escape_out).  Unlike the quote state it cannot be
+ * speculated away, but it is known from one byte run at the shard boundary before launching. */
+typedef struct csvsimd_dialect {
+    uint8_t delimiter; /* ',' */
+    uint8_t quote;     /* '"', 0 = no quoting */
+    uint8_t escape;    /* 0 = none (reference), e.g. '\\' */
+    uint8_t escape_in; /* 0 / 1 */
+    uint32_t reserved; /* 0 */
+} csvsimd_dialect;
+int csvsimd_dialect_init(csvsimd_dialect* d); /* fills in the reference dialect */
+int csvsimd_stage1_index_device_dialect_async(csvsimd_ctx* ctx, const csvsimd_dialect* dialect,
+                                              const void* dbuf, uint64_t len, uint64_t base_off,
+                                              uint32_t in_quote_in, void* dtape, uint64_t tape_cap,
+                                              void* d_result, void* hip_stream);
+int csvsimd_stage1_index_dialect(csvsimd_ctx* ctx, const csvsimd_dialect* dialect, const uint8_t* buf,
+                                 uint64_t len, uint64_t* tape, uint64_t tape_cap, uint64_t* tape_len,
+                                 uint32_t* in_quote_out);
 
 /* ---- multi-GPU stitch (host arithmetic; the exchange itself is one all-gather of these
  * descriptors over RCCL, done by the caller's communicator) -----------------------------------

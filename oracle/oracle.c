@@ -84,6 +84,29 @@ void oracle_shard_descriptor(const uint8_t* buf, uint64_t len, uint32_t* parity,
     *cnt_enter_inside = c1;
 }
 
+int oracle_dialect_index(const uint8_t* buf, uint64_t len, uint64_t base_off, uint8_t delimiter,
+                         uint8_t quote, uint8_t escape, uint32_t in_quote_in, uint32_t escape_in,
+                         uint64_t* tape, uint64_t cap, uint64_t* n_out, uint32_t* in_quote_out,
+                         uint32_t* escape_out) {
+    /* extension, see oracle.h: no reference counterpart beyond the default dialect */
+    uint64_t n = 0;
+    uint32_t inq = in_quote_in ? 1u : 0u, esc = escape_in ? 1u : 0u;
+    for (uint64_t i = 0; i < len; ++i) {
+        const uint8_t b = buf[i];
+        if (esc) { esc = 0; continue; }                    /* escaped byte: literal */
+        if (escape && b == escape) { esc = 1; continue; }
+        if (quote && b == quote) { inq ^= 1u; continue; }
+        if (!inq && (b == delimiter || b == 0x0a || b == 0x0d)) {
+            if (n < cap && tape) tape[n] = base_off + i;
+            ++n;
+        }
+    }
+    if (n_out) *n_out = n;
+    if (in_quote_out) *in_quote_out = inq;
+    if (escape_out) *escape_out = esc;
+    return (tape && n > cap) ? ORACLE_ERR_CAPACITY : 0;
+}
+
 /* ------------------------------------------------------------------------------------------
  * SSE restatement (4 x __m128i per 64-byte block)
  * ---------------------------------------------------------------------------------------- */

@@ -24,6 +24,18 @@ int oracle_scalar_read(const uint8_t* buf, uint64_t len, uint64_t* tape, uint64_
 void oracle_shard_descriptor(const uint8_t* buf, uint64_t len, uint32_t* parity,
                              uint64_t* cnt_enter_outside, uint64_t* cnt_enter_inside);
 
+/* Dialect extension (NOT a reference behaviour — the reference classifies
+ * space/backslash, src/stage1.rs:41-48, but never uses them and hard-wires ',' and '"',
+ * src/avx/stage1.rs:392-394).  Scalar definition the GPU dialect kernels are checked against:
+ *   an escaped byte (the one after an unescaped `escape` byte) is literal; `quote` toggles the
+ *   in-string state; `delimiter`, CR and LF outside a string are structural.  quote == 0 / escape == 0
+ *   switch that feature off.  escape_in: the byte at offset 0 is escaped.
+ * With (',', '"', 0) this is oracle_scalar_index. */
+int oracle_dialect_index(const uint8_t* buf, uint64_t len, uint64_t base_off, uint8_t delimiter,
+                         uint8_t quote, uint8_t escape, uint32_t in_quote_in, uint32_t escape_in,
+                         uint64_t* tape, uint64_t cap, uint64_t* n_out, uint32_t* in_quote_out,
+                         uint32_t* escape_out);
+
 /* faithful SSE restatement of reader::read (src/reader.rs:150-306); cap >= n + 64 */
 int oracle_sse_read(const uint8_t* buf, uint64_t len, uint64_t* tape, uint64_t cap,
                     uint64_t* n_out);

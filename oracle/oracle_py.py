@@ -29,6 +29,10 @@ def lib() -> C.CDLL:
         h.oracle_scalar_index.restype = C.c_int
         h.oracle_scalar_index.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64,
                                           _u64p, C.POINTER(C.c_uint32)]
+        h.oracle_dialect_index.restype = C.c_int
+        h.oracle_dialect_index.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint8, C.c_uint8, C.c_uint8,
+                                           C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, _u64p,
+                                           C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         h.oracle_scalar_read.restype = C.c_int
         h.oracle_scalar_read.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, _u64p]
         h.oracle_shard_descriptor.restype = None
@@ -78,6 +82,19 @@ def scalar_index(data, base_off: int = 0, in_quote_in: int = 0):
                                    C.byref(n), C.byref(q))
     assert rc == 0
     return out[: n.value].copy(), q.value
+
+
+def dialect_index(data, delimiter=0x2c, quote=0x22, escape=0, base_off: int = 0, in_quote_in: int = 0,
+                  escape_in: int = 0):
+    """Dialect extension (no reference counterpart) -> (entries uint64[], in_quote_out, escape_out)."""
+    a = data if isinstance(data, np.ndarray) else np.frombuffer(bytes(data), dtype=np.uint8)
+    a = np.ascontiguousarray(a)
+    out = np.zeros(a.size + 1, dtype=np.uint64)
+    n, q, e = C.c_uint64(), C.c_uint32(), C.c_uint32()
+    rc = lib().oracle_dialect_index(a.ctypes.data, a.size, base_off, delimiter, quote, escape, in_quote_in,
+                                    escape_in, out.ctypes.data, out.size, C.byref(n), C.byref(q), C.byref(e))
+    assert rc == 0
+    return out[: n.value].copy(), q.value, e.value
 
 
 def sse_read(data, head: int = 0) -> np.ndarray:

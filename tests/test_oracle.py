@@ -136,3 +136,57 @@ def test_mt_flavour_equals_scalar(oracle):
             want = oracle.scalar_read(d)
             for threads in (1, 2, 3, 8):
                 assert np.array_equal(oracle.sse_read_mt(d, threads), want), (n, pq, threads)
+
+
+def test_dialect_default_equals_reference_definition(oracle):
+    # the extension's scalar definition with (',', '"', no escape) is the reference's semantics
+    rng = np.random.default_rng(99)
+    for n in (0, 1, 64, 1000, 50000):
+        d = random_csvish(rng, n, 0.1)
+        for inq in (0, 1):
+            a, qa = oracle.scalar_index(d, base_off=5, in_quote_in=inq)
+            b, qb, e = oracle.dialect_index(d, base_off=5, in_quote_in=inq)
+            assert np.array_equal(a, b) and qa == qb and e == 0
+
+
+def test_dialect_against_python_csv_module(oracle):
+    # independent check of the extension's semantics: files written by Python's csv module in a
+    # ';' / "'" / backslash dialect; every record the csv module reads back must contribute
+    # exactly len(row) structural bytes (one per field end), and the fields must sit between them
+    import csv
+    import io
+    rng = np.random.default_rng(7)
+    pool = ["a", "bc", ";", "'", "\\", "x;y", "it's", "", " ", "q\\r", "1;2;3", "''"]
+    for quoting in (csv.QUOTE_MINIMAL, csv.QUOTE_NONE, csv.QUOTE_ALL):
+        rows = [[pool[i] + (pool[j] if k % 3 == 0 else "")
+                 for k, (i, j) in enumerate(rng.integers(0, len(pool), size=(int(rng.integers(1, 9)), 2)))]
+                for _ in range(300)]
+        buf = io.StringIO()
+        kw = dict(delimiter=";", quotechar="'", escapechar="\\", doublequote=False, lineterminator="\n",
+                  quoting=quoting)
+        csv.writer(buf, **kw).writerows(rows)
+        text = buf.getvalue()
+        back = list(csv.reader(io.StringIO(text), **kw))
+        assert back == rows                      # the csv module agrees with itself
+        data = text.encode()
+        idx, inq, esc = oracle.dialect_index(data, ord(";"), ord("'"), ord("\\"))
+        assert (inq, esc) == (0, 0)
+        assert idx.size == sum(len(r) for r in rows)
+        # rows end where the csv module says they end
+        ends = [i for i in idx.tolist() if data[i] == 0x0A]
+        assert len(ends) == len(rows) and ends[-1] == len(data) - 1
+        # and the raw text of each field, un-escaped and un-quoted, is the field
+        prev = -1
+        flat = [f for r in rows for f in r]
+        for pos, want in zip(idx.tolist(), flat):
+            raw = data[prev + 1: pos].decode()
+            if raw[:1] == "'" and quoting != csv.QUOTE_NONE:
+                raw = raw[1:-1]
+            out, k = [], 0
+            while k < len(raw):
+                if raw[k] == "\\":
+                    k += 1
+                out.append(raw[k])
+                k += 1
+            assert "".join(out) == want
+            prev = pos
