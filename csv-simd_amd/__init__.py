@@ -66,6 +66,14 @@ class Dialect(C.Structure):
         super().__init__(byte(delimiter), byte(quote), byte(escape), 1 if escape_in else 0, 0)
 
 
+class Utf8Result(C.Structure):
+    _fields_ = [("first_invalid", C.c_uint64), ("reserved", C.c_uint64)]
+
+
+TRIM_SPACE, TRIM_QUOTES = 1, 2
+UTF8_VALID = 2**64 - 1
+
+
 class Stitch(C.Structure):
     _fields_ = [
         ("in_quote_in", C.c_uint32),
@@ -105,6 +113,11 @@ _PROTOTYPES = {
                                                             C.c_void_p, C.c_void_p]),
     "csvsimd_stage1_index_dialect": (C.c_int, [C.c_void_p, C.POINTER(Dialect), C.c_void_p, C.c_uint64, C.c_void_p,
                                                C.c_uint64, _u64p, C.POINTER(C.c_uint32)]),
+    "csvsimd_trim_spans_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint8,
+                                            C.c_void_p]),
+    "csvsimd_utf8_validate_device_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "csvsimd_utf8_validate_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Utf8Result),
+                                               C.c_void_p]),
     "csvsimd_stage1_bound": (C.c_int, [C.c_uint64, _u64p]),
     "csvsimd_stage1_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, _u64p,
                                        C.POINTER(C.c_uint32)]),
@@ -224,6 +237,15 @@ class Context:
         _check(lib().csvsimd_stage1_index_device_dialect_async(self._h, C.byref(dialect), dbuf, length, base_off,
                                                                in_quote_in, dtape or None, tape_cap, d_result,
                                                                stream or None))
+
+    def utf8_validate_device(self, dbuf: int, length: int, stream: int = 0) -> Optional[int]:
+        """None if dbuf[0..length) is valid UTF-8, else the offset of the first offending byte."""
+        r = Utf8Result()
+        _check(lib().csvsimd_utf8_validate_device(self._h, dbuf or None, length, C.byref(r), stream or None))
+        return None if r.first_invalid == UTF8_VALID else int(r.first_invalid)
+
+    def utf8_validate_device_async(self, dbuf: int, length: int, d_result: int, stream: int = 0) -> None:
+        _check(lib().csvsimd_utf8_validate_device_async(self._h, dbuf or None, length, d_result, stream or None))
 
     def stage1_time_device(self, dbuf: int, length: int, dtape: int, tape_cap: int, d_result: int,
                            stream: int = 0, warmup: int = 2, iters: int = 10) -> float:
@@ -439,6 +461,11 @@ def gather_fields_device(dbytes: int, d_begin: int, d_end: int, n_records: int, 
 
 
 # ---- device utilities (raw device addresses; torch tensors' .data_ptr() fit) --------------------
+def trim_spans_device(dbytes: int, d_begin: int, d_end: int, n_records: int, flags: int = TRIM_SPACE,
+                      quote: int = 0x22, stream: int = 0) -> None:
+    _check(lib().csvsimd_trim_spans_device(dbytes, d_begin, d_end, n_records, flags, quote, stream or None))
+
+
 def synth_fill_device(dbuf: int, file_off: int, length: int, cols: int, width: int, seed: int,
                       quote_pct: int = 0, stream: int = 0) -> None:
     _check(lib().csvsimd_synth_fill_device(dbuf, file_off, length, cols, width, seed, quote_pct, stream or None))

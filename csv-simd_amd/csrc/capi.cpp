@@ -41,6 +41,7 @@ struct csvsimd_ctx {
     void* scratch = nullptr;
     uint64_t scratch_bytes = 0;
     uint32_t max_blocks = 0;
+    int n_cus = 0;
     csvsimd_shard_result* d_result = nullptr;  // for the synchronous entry points
     // host-buffer path (csvsimd_stage1_index): two-slot pipeline, allocated on first use
     static constexpr uint64_t kChunk = 32ull << 20;  // bytes per slot
@@ -101,6 +102,7 @@ int csvsimd_ctx_create(int device, csvsimd_ctx** out) {
     std::unique_ptr<csvsimd_ctx> ctx(new (std::nothrow) csvsimd_ctx);
     if (!ctx) return CSVSIMD_ERR_INVALID_STATE;
     ctx->device = device;
+    ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const int per_cu = csvsimd::stage1_max_blocks_per_cu();
     ctx->max_blocks = (uint32_t)(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256) * (uint32_t)per_cu;
     HIP_TRY(hipMalloc((void**)&ctx->d_result, sizeof(csvsimd_shard_result)));
@@ -574,6 +576,33 @@ int csvsimd_gather_fields_device(const void* dbytes, const void* d_begin, const 
     if (csvsimd_device_count() <= 0) return CSVSIMD_ERR_NO_DEVICE;
     HIP_TRY(csvsimd::launch_gather_fields(dbytes, d_begin, d_end, n_records, d_dst, stride, d_len,
                                           (hipStream_t)hip_stream));
+    return CSVSIMD_OK;
+}
+
+int csvsimd_trim_spans_device(const void* dbytes, void* d_begin, void* d_end, uint64_t n_records, uint32_t flags,
+                              uint8_t quote, void* hip_stream) {
+    if (n_records && (!dbytes || !d_begin || !d_end)) return CSVSIMD_ERR_INVALID_ARG;
+    if (flags & ~(CSVSIMD_TRIM_SPACE | CSVSIMD_TRIM_QUOTES)) return CSVSIMD_ERR_INVALID_ARG;
+    if (csvsimd_device_count() <= 0) return CSVSIMD_ERR_NO_DEVICE;
+    HIP_TRY(csvsimd::launch_trim_spans(dbytes, d_begin, d_end, n_records, flags, quote, (hipStream_t)hip_stream));
+    return CSVSIMD_OK;
+}
+
+int csvsimd_utf8_validate_device_async(csvsimd_ctx* ctx, const void* dbuf, uint64_t len, void* d_result,
+                                       void* hip_stream) {
+    if (!ctx || !d_result || (len && !dbuf) || ((uintptr_t)d_result & 7)) return CSVSIMD_ERR_INVALID_ARG;
+    HIP_TRY(csvsimd::launch_utf8_validate(dbuf, len, d_result, ctx->n_cus, (hipStream_t)hip_stream));
+    return CSVSIMD_OK;
+}
+
+int csvsimd_utf8_validate_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len, csvsimd_utf8_result* result,
+                                 void* hip_stream) {
+    if (!ctx || !result) return CSVSIMD_ERR_INVALID_ARG;
+    static_assert(sizeof(csvsimd_utf8_result) <= sizeof(csvsimd_shard_result), "reuses the context's result slot");
+    const int rc = csvsimd_utf8_validate_device_async(ctx, dbuf, len, ctx->d_result, hip_stream);
+    if (rc != CSVSIMD_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(result, ctx->d_result, sizeof(*result), hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
     return CSVSIMD_OK;
 }
 

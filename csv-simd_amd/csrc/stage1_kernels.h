@@ -72,6 +72,10 @@ hipError_t launch_field_spans(const void* dindex, uint64_t row_size, uint32_t fi
                               uint64_t n_records, void* d_begin, void* d_end, hipStream_t stream);
 hipError_t launch_gather_fields(const void* dbytes, const void* d_begin, const void* d_end, uint64_t n_records,
                                 void* d_dst, uint32_t stride, void* d_len, hipStream_t stream);
+// text_kernels.hip
+hipError_t launch_utf8_validate(const void* dbuf, uint64_t len, void* d_result, int n_cus, hipStream_t stream);
+hipError_t launch_trim_spans(const void* dbytes, void* d_begin, void* d_end, uint64_t n, uint32_t flags,
+                             uint32_t quote, hipStream_t stream);
 int stage1_max_blocks_per_cu();
 
 }  // namespace csvsimd

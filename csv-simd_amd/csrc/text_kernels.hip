@@ -1,0 +1,253 @@
+// text_kernels.hip — gfx950 kernels for the dialect-coverage row of SURVEY.md §8f (rank 4) that sit
+// next to stage 1 rather than in it: UTF-8 validation of the raw bytes and space / quote trimming of
+// field spans.  None of this is executed by the reference: its UTF-8 checker is dead code
+// (src/avx/utf8check.rs, never called from reader::read) and "trim" is a todo in its class-table
+// legend (src/stage1.rs:41-48, class 4 = 0x20).  Both stay OFF the default stage-1 path.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "stage1_kernels.h"
+
+namespace csvsimd {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+// ---------------------------------------------------------------------------------------------
+// UTF-8 validation (RFC 3629: shortest form, no surrogates, <= U+10FFFF, no truncated tail).
+//
+// result[0] = offset of the first byte that does not start / continue a well-formed sequence
+// (the position Python's bytes.decode reports as UnicodeDecodeError.start), UINT64_MAX if valid.
+//
+// Pass 1 (utf8_scan_kernel, the streaming pass): branch-free byte-parallel rules that only look
+// BACKWARDS, so a wave needs just the dword before its block as halo and carries no state:
+//   * continuation expected  (byte i-1 >= C0, or i-2 >= E0, or i-3 >= F0)  XOR  byte i is 10xxxxxx
+//   * byte i is C0, C1 or F5..FF
+//   * byte i-1 is E0 / ED / F0 / F4 and byte i is outside that lead's narrowed second-byte range
+// Every violation lies within 3 bytes after the start of the first ill-formed sequence and there
+// are no false positives, so the minimum flagged offset p satisfies  start <= p <= start + 3.
+// Shape: 16 bytes per lane, 4 KiB per wave per iteration in flight; a block that is pure ASCII and
+// does not follow a pending lead (the normal CSV case) costs 5 VALU per 16 bytes and streams at the
+// HBM read rate; any other block runs the rules as SWAR on dwords (flags live in bit 7 of each byte,
+// byte-shifted views via v_alignbyte), ~45 VALU per 4 bytes.
+// Pass 2 (utf8_refine_kernel, one thread): backs up from p to a sequence start (<= 7 bytes) and
+// decodes forward sequentially to the exact offset.
+// ---------------------------------------------------------------------------------------------
+struct Utf8Range {
+    const uint8_t* abase;  // 16-byte aligned
+    u64 lo, hi;            // valid bytes are abase[lo, hi)
+};
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// flag words: only bit 7 of every byte is meaningful
+struct Utf8Flags {
+    u32 ge_c0, ge_e0, ge_f0;      // lead of length >= 2 / >= 3 / >= 4 (or an invalid F8..FF)
+    u32 is_e0, is_ed, is_f0, is_f4;
+};
+
+__device__ __forceinline__ u32 prev_bytes(u32 cur, u32 prev, int n) {
+    // byte i of the result = byte i - n of the stream (prev holds the four bytes before cur)
+    return __builtin_amdgcn_alignbyte(cur, prev, 4 - n);
+}
+
+// classifies dword x; returns its error flags given the flags of the dword before it
+__device__ __forceinline__ u32 utf8_swar(u32 x, Utf8Flags& pf) {
+    const u32 s1 = x << 1, s2 = x << 2, s3 = x << 3, s4 = x << 4, s5 = x << 5, s6 = x << 6, s7 = x << 7;
+    Utf8Flags f;
+    f.ge_c0 = x & s1;                 // 11xxxxxx
+    f.ge_e0 = f.ge_c0 & s2;           // 111xxxxx
+    f.ge_f0 = f.ge_e0 & s3;           // 1111xxxx
+    const u32 ge_f8 = f.ge_f0 & s4;   // 11111xxx: never valid
+    const u32 cont = x & ~s1;         // 10xxxxxx
+    const u32 c0c1 = (f.ge_c0 & ~s2 & ~s3) & (~s4 & ~s5 & ~s6);  // 1100000x: overlong 2-byte forms
+    const u32 f4xx = f.ge_f0 & ~s4 & s5;                         // 111101xx
+    const u32 f5_7 = f4xx & (s6 | s7);                           // F5, F6, F7: > U+10FFFF
+    const u32 low3_zero = ~s5 & ~s6 & ~s7;
+    f.is_e0 = (f.ge_e0 & ~s3 & ~s4) & low3_zero;                 // 11100000
+    f.is_ed = (f.ge_e0 & ~s3 & s4) & (s5 & ~s6 & s7);            // 11101101
+    f.is_f0 = f.ge_f0 & ~s4 & low3_zero;                         // 11110000
+    f.is_f4 = f4xx & ~s6 & ~s7;                                  // 11110100
+    const u32 must = prev_bytes(f.ge_c0, pf.ge_c0, 1) | prev_bytes(f.ge_e0, pf.ge_e0, 2) |
+                     prev_bytes(f.ge_f0, pf.ge_f0, 3);
+    // narrowed second byte: E0 -> A0..BF (bit 5), ED -> 80..9F, F0 -> 90..BF (bit 5 or 4), F4 -> 80..8F
+    const u32 second = (prev_bytes(f.is_e0, pf.is_e0, 1) & ~s2) | (prev_bytes(f.is_ed, pf.is_ed, 1) & s2) |
+                       (prev_bytes(f.is_f0, pf.is_f0, 1) & ~s2 & ~s3) | (prev_bytes(f.is_f4, pf.is_f4, 1) & (s2 | s3));
+    pf = f;
+    return ((must ^ cont) | ge_f8 | c0c1 | f5_7 | second) & 0x80808080u;
+}
+
+// the aligned dword at abase[q, q + 4) with bytes outside [lo, hi) zeroed
+__device__ __forceinline__ u32 masked_dword(const Utf8Range& r, u64 q) {
+    u32 w = *reinterpret_cast<const u32*>(r.abase + q);
+    if (q < r.lo || q + 4 > r.hi) {
+        u32 keep = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (q + (u64)k >= r.lo && q + (u64)k < r.hi) keep |= 0xffu << (8 * k);
+        w &= keep;
+    }
+    return w;
+}
+
+// n_chunks counts one chunk past the end of the buffer (it reads as zeros): that is where a lead in
+// the very last bytes finds its missing continuation
+__global__ __launch_bounds__(256) void utf8_scan_kernel(Utf8Range r, u64 n_chunks, u64 n_real_chunks, u64* result) {
+    const u32 lane = threadIdx.x & 63u;
+    const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const u64 n_waves = ((u64)gridDim.x * blockDim.x) >> 6;
+    const u64 n_blocks = (n_chunks + 255) / 256;  // 4 KiB = 256 chunks of 16 bytes per wave iteration
+    u64 first = ~0ull;
+    for (u64 blk = wave; blk < n_blocks; blk += n_waves) {
+        u32x4 v[4];
+        u32 hib[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u64 c = blk * 256 + (u64)j * 64 + lane;
+            v[j] = u32x4{0, 0, 0, 0};
+            if (c < n_real_chunks) v[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(r.abase) + c);
+        }
+        // the four bytes before the block (same address in every lane: one broadcast transaction)
+        const u32 halo = blk ? masked_dword(r, blk * 4096 - 4) : 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // only the first and the last chunk of the buffer can hold bytes outside [lo, hi): zero them
+            const u64 off = (blk * 256 + (u64)j * 64 + lane) * 16;
+            if (off < r.lo || off + 16 > r.hi) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    u32 keep = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const u64 i = off + (u64)(4 * d + k);
+                        if (i >= r.lo && i < r.hi) keep |= 0xffu << (8 * k);
+                    }
+                    v[j][d] &= keep;
+                }
+            }
+            hib[j] = (v[j][0] | v[j][1] | v[j][2] | v[j][3]) & 0x80808080u;
+        }
+        // pure ASCII and nothing pending from the bytes before the block
+        if (__ballot(((hib[0] | hib[1] | hib[2] | hib[3]) | (halo & 0x80808080u)) != 0u) == 0ull) continue;
+
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // the dword before this lane's chunk: the previous lane's last dword
+            u32 w0 = (u32)__shfl_up((int)v[j][3], 1);
+            const u32 edge = j == 0 ? halo : (u32)__builtin_amdgcn_readlane((int)v[j > 0 ? j - 1 : 0][3], 63);
+            if (lane == 0) w0 = edge;
+            Utf8Flags pf = {0, 0, 0, 0, 0, 0, 0};
+            (void)utf8_swar(w0, pf);  // only its flags matter
+            u32 e[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) e[d] = utf8_swar(v[j][d], pf);
+            if ((e[0] | e[1] | e[2] | e[3]) != 0u) {
+                const u32 d = e[0] ? 0u : e[1] ? 1u : e[2] ? 2u : 3u;
+                const u32 ed = e[0] ? e[0] : e[1] ? e[1] : e[2] ? e[2] : e[3];
+                const u64 i = (blk * 256 + (u64)j * 64 + lane) * 16 + 4 * d + ((u32)__builtin_ctz(ed) >> 3);
+                first = i < first ? i : first;
+            }
+        }
+    }
+    // wave minimum, one atomic per wave that found anything
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const u64 o = ((u64)(u32)__shfl_xor((int)(u32)(first >> 32), d) << 32) | (u32)__shfl_xor((int)(u32)first, d);
+        first = o < first ? o : first;
+    }
+    if (lane == 0 && first != ~0ull) atomicMin((unsigned long long*)result, (unsigned long long)(first - r.lo));
+}
+
+// result[0] = a flagged offset within [start, start + 3] of the first ill-formed sequence (or
+// UINT64_MAX): back up to a sequence start and decode forward to the exact offset.  One thread.
+__global__ void utf8_refine_kernel(const uint8_t* buf, u64 len, u64* result) {
+    const u64 p = result[0];
+    if (p == ~0ull) return;
+    u64 s = p > 3 ? p - 3 : 0;
+    if (s > len) s = len;
+    // everything before the error is valid: at most 3 continuation bytes of a sequence, plus the stray
+    // continuation byte itself when that is the error
+    for (int k = 0; k < 4 && s > 0 && s < len && (buf[s] & 0xC0) == 0x80; ++k) --s;
+    u64 i = s;
+    while (i < len) {
+        const u32 b = buf[i];
+        if (b < 0x80u) { ++i; continue; }
+        u32 need, lo1 = 0x80u, hi1 = 0xBFu;
+        if (b >= 0xC2u && b <= 0xDFu) need = 1;
+        else if (b >= 0xE0u && b <= 0xEFu) { need = 2; if (b == 0xE0u) lo1 = 0xA0u; if (b == 0xEDu) hi1 = 0x9Fu; }
+        else if (b >= 0xF0u && b <= 0xF4u) { need = 3; if (b == 0xF0u) lo1 = 0x90u; if (b == 0xF4u) hi1 = 0x8Fu; }
+        else break;
+        bool ok = true;
+        for (u32 k = 1; k <= need && ok; ++k) {
+            if (i + k >= len) { ok = false; break; }
+            const u32 c = buf[i + k];
+            ok = c >= lo1 && c <= hi1;
+            lo1 = 0x80u;
+            hi1 = 0xBFu;
+        }
+        if (!ok) break;
+        i += need + 1;
+        if (i > p + 4) break;  // cannot happen: pass 1 flagged something at or before p
+    }
+    result[0] = i < len ? i : (p < len ? p : len - 1);
+}
+
+__global__ void utf8_init_kernel(u64* result) {
+    result[0] = ~0ull;
+    result[1] = 0;
+}
+
+hipError_t launch_utf8_validate(const void* dbuf, u64 len, void* d_result, int n_cus, hipStream_t stream) {
+    hipLaunchKernelGGL(utf8_init_kernel, dim3(1), dim3(1), 0, stream, (u64*)d_result);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || len == 0) return e;
+    const uintptr_t addr = (uintptr_t)dbuf;
+    Utf8Range r;
+    r.abase = (const uint8_t*)(addr & ~(uintptr_t)15);
+    r.lo = (u64)(addr & 15);
+    r.hi = r.lo + len;
+    const u64 n_real = (r.hi + 15) / 16;
+    const u64 n_chunks = n_real + 1;
+    const u64 n_blocks = (n_chunks + 255) / 256;          // wave iterations
+    u64 grid = (n_blocks + 3) / 4;                        // 4 waves per workgroup
+    const u64 cap = (u64)(n_cus > 0 ? n_cus : 256) * 8;   // 32 waves per CU: enough loads in flight to stream
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(utf8_scan_kernel, dim3((u32)grid), dim3(256), 0, stream, r, n_chunks, n_real, (u64*)d_result);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(utf8_refine_kernel, dim3(1), dim3(1), 0, stream, (const uint8_t*)dbuf, len, (u64*)d_result);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// span trimming: [begin, end) -> without leading / trailing 0x20 (the reference's class 4,
+// src/stage1.rs:41-48: `todo: trim " xx "`), then optionally without one enclosing quote pair.
+// ---------------------------------------------------------------------------------------------
+__global__ void trim_spans_kernel(const uint8_t* __restrict__ bytes, u64* __restrict__ begin, u64* __restrict__ end,
+                                  u64 n, u32 flags, u32 quote) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        u64 b = begin[i], e = end[i];
+        if (e < b) e = b;  // the empty last field of a CRLF row
+        if (flags & CSVSIMD_TRIM_SPACE) {
+            while (b < e && bytes[b] == 0x20) ++b;
+            while (e > b && bytes[e - 1] == 0x20) --e;
+        }
+        if ((flags & CSVSIMD_TRIM_QUOTES) && e - b >= 2 && bytes[b] == quote && bytes[e - 1] == quote) {
+            ++b;
+            --e;
+        }
+        begin[i] = b;
+        end[i] = e;
+    }
+}
+
+hipError_t launch_trim_spans(const void* dbytes, void* d_begin, void* d_end, u64 n, u32 flags, u32 quote,
+                             hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    u64 blocks = (n + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(trim_spans_kernel, dim3((u32)blocks), dim3(256), 0, stream, (const uint8_t*)dbytes,
+                       (u64*)d_begin, (u64*)d_end, n, flags, quote);
+    return hipGetLastError();
+}
+
+}  // namespace csvsimd

@@ -233,6 +233,32 @@ int csvsimd_gather_fields_device(const void* dbytes, const void* d_begin, const 
                                  uint64_t n_records, void* d_dst, uint32_t stride, void* d_len,
                                  void* hip_stream);
 
+/* Trims every span [d_begin[i], d_end[i]) in place: CSVSIMD_TRIM_SPACE drops leading / trailing
+ * 0x20 bytes — the reference's class 4, whose legend says `todo: trim " xx "`
+ * (src/stage1.rs:41-48; extension) — then CSVSIMD_TRIM_QUOTES drops one
+ * enclosing pair of `quote` bytes.  seek_field itself never trims (src/record_source.rs:106-140),
+ * so without this call the spans stay exactly the reference's. */
+#define CSVSIMD_TRIM_SPACE 1u
+#define CSVSIMD_TRIM_QUOTES 2u
+int csvsimd_trim_spans_device(const void* dbytes, void* d_begin, void* d_end, uint64_t n_records,
+                              uint32_t flags, uint8_t quote, void* hip_stream);
+
+/* ---- UTF-8 validation of device-resident bytes (extension) --------------
+ * The reference carries a UTF-8 checker (src/avx/utf8check.rs) that reader::read never calls;
+ * this is the MI355X counterpart as a separate pass, off the stage-1 path.  RFC 3629 rules
+ * (shortest form, no surrogates, <= U+10FFFF, no truncated tail).  first_invalid = offset of the
+ * first byte that does not start or continue a well-formed sequence (what Python's bytes.decode
+ * reports as UnicodeDecodeError.start), UINT64_MAX if the whole buffer is valid.  d_result is
+ * DEVICE memory, 16 bytes, 8-byte aligned; asynchronous on hip_stream; any dbuf alignment. */
+typedef struct csvsimd_utf8_result {
+    uint64_t first_invalid;
+    uint64_t reserved;
+} csvsimd_utf8_result;
+int csvsimd_utf8_validate_device_async(csvsimd_ctx* ctx, const void* dbuf, uint64_t len, void* d_result,
+                                       void* hip_stream);
+int csvsimd_utf8_validate_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len,
+                                 csvsimd_utf8_result* result, void* hip_stream);
+
 /* ---- utilities used by the bench / tests (device-side, no reference counterpart) ------------- */
 /* Synthetic corpus bytes [file_off, file_off+len) of the cols x width shape. */
 int csvsimd_synth_fill_device(void* dbuf, uint64_t file_off, uint64_t len, uint32_t cols,

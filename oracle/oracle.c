@@ -107,6 +107,41 @@ int oracle_dialect_index(const uint8_t* buf, uint64_t len, uint64_t base_off, ui
     return (tape && n > cap) ? ORACLE_ERR_CAPACITY : 0;
 }
 
+uint64_t oracle_utf8_first_invalid(const uint8_t* buf, uint64_t len) {
+    /* one code point at a time, Unicode table 3-7 (well-formed UTF-8 byte sequences) */
+    uint64_t i = 0;
+    while (i < len) {
+        const uint8_t b = buf[i];
+        if (b < 0x80) { ++i; continue; }
+        uint32_t need;
+        uint8_t lo = 0x80, hi = 0xBF;
+        if (b >= 0xC2 && b <= 0xDF) need = 1;
+        else if (b >= 0xE0 && b <= 0xEF) { need = 2; if (b == 0xE0) lo = 0xA0; if (b == 0xED) hi = 0x9F; }
+        else if (b >= 0xF0 && b <= 0xF4) { need = 3; if (b == 0xF0) lo = 0x90; if (b == 0xF4) hi = 0x8F; }
+        else return i;                                  /* 80..C1, F5..FF cannot start a sequence */
+        for (uint32_t k = 1; k <= need; ++k) {
+            if (i + k >= len) return i;                 /* truncated tail */
+            const uint8_t c = buf[i + k];
+            if (c < lo || c > hi) return i;
+            lo = 0x80; hi = 0xBF;
+        }
+        i += need + 1;
+    }
+    return UINT64_MAX;
+}
+
+void oracle_trim_span(const uint8_t* bytes, uint64_t* begin, uint64_t* end, uint32_t flags, uint8_t quote) {
+    uint64_t b = *begin, e = *end;
+    if (e < b) e = b;
+    if (flags & 1u) {
+        while (b < e && bytes[b] == 0x20) ++b;
+        while (e > b && bytes[e - 1] == 0x20) --e;
+    }
+    if ((flags & 2u) && e - b >= 2 && bytes[b] == quote && bytes[e - 1] == quote) { ++b; --e; }
+    *begin = b;
+    *end = e;
+}
+
 /* ------------------------------------------------------------------------------------------
  * SSE restatement (4 x __m128i per 64-byte block)
  * ---------------------------------------------------------------------------------------- */

@@ -36,6 +36,14 @@ int oracle_dialect_index(const uint8_t* buf, uint64_t len, uint64_t base_off, ui
                          uint64_t* tape, uint64_t cap, uint64_t* n_out, uint32_t* in_quote_out,
                          uint32_t* escape_out);
 
+/* Extensions next to stage 1 (no executed reference counterpart: src/avx/utf8check.rs is dead code,
+ * trimming is a todo in src/stage1.rs:41-48).  Sequential RFC 3629 decoder: offset of the first
+ * byte that does not start / continue a well-formed sequence, UINT64_MAX if valid — pinned in
+ * tests/test_oracle.py against CPython's bytes.decode (UnicodeDecodeError.start). */
+uint64_t oracle_utf8_first_invalid(const uint8_t* buf, uint64_t len);
+/* [*begin, *end) without leading/trailing 0x20 (flag 1) and one enclosing quote pair (flag 2) */
+void oracle_trim_span(const uint8_t* bytes, uint64_t* begin, uint64_t* end, uint32_t flags, uint8_t quote);
+
 /* faithful SSE restatement of reader::read (src/reader.rs:150-306); cap >= n + 64 */
 int oracle_sse_read(const uint8_t* buf, uint64_t len, uint64_t* tape, uint64_t cap,
                     uint64_t* n_out);

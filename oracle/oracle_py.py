@@ -33,6 +33,10 @@ def lib() -> C.CDLL:
         h.oracle_dialect_index.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint8, C.c_uint8, C.c_uint8,
                                            C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, _u64p,
                                            C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        h.oracle_utf8_first_invalid.restype = C.c_uint64
+        h.oracle_utf8_first_invalid.argtypes = [C.c_void_p, C.c_uint64]
+        h.oracle_trim_span.restype = None
+        h.oracle_trim_span.argtypes = [C.c_void_p, _u64p, _u64p, C.c_uint32, C.c_uint8]
         h.oracle_scalar_read.restype = C.c_int
         h.oracle_scalar_read.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, _u64p]
         h.oracle_shard_descriptor.restype = None
@@ -95,6 +99,24 @@ def dialect_index(data, delimiter=0x2c, quote=0x22, escape=0, base_off: int = 0,
                                     escape_in, out.ctypes.data, out.size, C.byref(n), C.byref(q), C.byref(e))
     assert rc == 0
     return out[: n.value].copy(), q.value, e.value
+
+
+def utf8_first_invalid(data):
+    """None if valid UTF-8, else the offset of the first offending byte."""
+    a = data if isinstance(data, np.ndarray) else np.frombuffer(bytes(data), dtype=np.uint8)
+    a = np.ascontiguousarray(a)
+    r = lib().oracle_utf8_first_invalid(a.ctypes.data if a.size else None, a.size)
+    return None if r == 2**64 - 1 else int(r)
+
+
+def trim_spans(data, begin, end, flags: int, quote: int = 0x22):
+    a = np.ascontiguousarray(data if isinstance(data, np.ndarray) else np.frombuffer(bytes(data), dtype=np.uint8))
+    b, e = np.array(begin, dtype=np.uint64), np.array(end, dtype=np.uint64)
+    for i in range(b.size):
+        bb, ee = C.c_uint64(int(b[i])), C.c_uint64(int(e[i]))
+        lib().oracle_trim_span(a.ctypes.data, C.byref(bb), C.byref(ee), flags, quote)
+        b[i], e[i] = bb.value, ee.value
+    return b, e
 
 
 def sse_read(data, head: int = 0) -> np.ndarray:

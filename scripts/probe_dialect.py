@@ -40,6 +40,28 @@ def main():
         torch.cuda.synchronize()
         r = pkg.ShardResult.from_buffer_copy(dres.cpu().numpy().tobytes())
         out[label] = {"kernel_ms": round(ms, 4), "TBps": round(n / ms / 1e9, 3), "entries": r.count}
+    # UTF-8 validation pass over the same (pure ASCII) corpus, then over text with no ASCII at all
+    def time_utf8(buf, nbytes):
+        r = torch.zeros(2, dtype=torch.int64, device=dev)
+        for _ in range(2):
+            ctx.utf8_validate_device_async(buf.data_ptr(), nbytes, r.data_ptr(), s)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            ctx.utf8_validate_device_async(buf.data_ptr(), nbytes, r.data_ptr(), s)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        return {"ms": round(ms, 4), "TBps": round(nbytes / ms / 1e9, 3), "first_invalid": int(r[0].item())}
+
+    out["utf8_ascii"] = time_utf8(dbuf, n)
+    import numpy as np
+    cjk = torch.from_numpy(np.frombuffer("漢字仮名交じり文".encode(), dtype=np.uint8).copy()).to(dev)
+    big = cjk.repeat((1 << 30) // cjk.numel())
+    out["utf8_cjk_1GiB"] = time_utf8(big, big.numel())
+    mixed = torch.from_numpy(np.frombuffer("id,name,città,東京\n".encode(), dtype=np.uint8).copy()).to(dev)
+    big = mixed.repeat((1 << 30) // mixed.numel())
+    out["utf8_mixed_1GiB"] = time_utf8(big, big.numel())
     print(json.dumps(out))
 
 

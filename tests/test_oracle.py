@@ -190,3 +190,46 @@ def test_dialect_against_python_csv_module(oracle):
                 k += 1
             assert "".join(out) == want
             prev = pos
+
+
+def _py_utf8_first_invalid(b: bytes):
+    try:
+        b.decode("utf-8")
+        return None
+    except UnicodeDecodeError as e:
+        return e.start
+
+
+def test_utf8_oracle_against_cpython_decoder(oracle):
+    # pins the extension's UTF-8 oracle on an independent implementation (CPython's decoder)
+    cases = [b"", b"plain ascii, \"quoted\"\n", "héllo,世界,\U0001F600\n".encode(), b"\x80", b"\xbf",
+             b"\xc0\x80", b"\xc1\xbf", b"\xc2", b"a\xc2", b"\xc2\x41", b"\xe0\x80\x80", b"\xe0\x9f\xbf", b"\xe0\xa0\x80",
+             b"\xed\x9f\xbf", b"\xed\xa0\x80", b"\xed\xbf\xbf", b"\xee\x80\x80", b"\xef\xbf\xbf", b"\xe2\x82",
+             b"ab\xe2\x82", b"\xe2\x28\xa1", b"\xe2\x82\x28", b"\xf0\x80\x80\x80", b"\xf0\x8f\xbf\xbf",
+             b"\xf0\x90\x80\x80", b"\xf4\x8f\xbf\xbf", b"\xf4\x90\x80\x80", b"\xf5\x80\x80\x80", b"\xff", b"\xfe",
+             b"a\xf0\x90\x80a", b"\xf0\x90\x80", b"\xf0\x90", b"\xf0", b"\xf1\x80\x80\x80\x80", b"\xc2\x80\x80",
+             b"\xef\xbb\xbfName,Number\r\n"]
+    for c in cases:
+        assert oracle.utf8_first_invalid(c) == _py_utf8_first_invalid(c), c
+    rng = np.random.default_rng(11)
+    pool = np.frombuffer(b"a,\n\"\x7f\x80\x8f\x90\x9f\xa0\xbf\xc0\xc1\xc2\xdf\xe0\xe1\xec\xed\xee\xef\xf0\xf1\xf3\xf4\xf5\xff",
+                         dtype=np.uint8)
+    for _ in range(4000):
+        b = pool[rng.integers(0, pool.size, size=int(rng.integers(0, 12)))].tobytes()
+        assert oracle.utf8_first_invalid(b) == _py_utf8_first_invalid(b), b
+    # valid text with one corrupted byte
+    text = ("naïve,東京,\U0001F680 café\n" * 50).encode()
+    for _ in range(300):
+        m = bytearray(text)
+        m[int(rng.integers(0, len(m)))] = int(rng.integers(0, 256))
+        assert oracle.utf8_first_invalid(bytes(m)) == _py_utf8_first_invalid(bytes(m))
+
+
+def test_trim_span_oracle(oracle):
+    data = b'  "a b"  ,x,   ,"",\' q \''
+    b, e = oracle.trim_spans(data, [0, 10, 12, 16, 19], [9, 11, 15, 18, 24], 3)
+    assert [data[i:j] for i, j in zip(b.tolist(), e.tolist())] == [b"a b", b"x", b"", b"", b"' q '"]
+    b, e = oracle.trim_spans(data, [0, 19], [9, 24], 1)
+    assert [data[i:j] for i, j in zip(b.tolist(), e.tolist())] == [b'"a b"', b"' q '"]
+    b, e = oracle.trim_spans(data, [19], [24], 2, quote=0x27)
+    assert data[int(b[0]):int(e[0])] == b" q "
