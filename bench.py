@@ -103,13 +103,16 @@ def time_steps(step, steps, warmup, device, dist_on):
     return dt
 
 
-def load_traffic(workload):
-    """HBM bytes per launch from the committed PMC profile (separate --pmc passes), if present."""
+def load_traffic(workload, launch_bytes):
+    """HBM bytes per launch from the committed PMC profile (separate --pmc passes), if it was taken
+    on this workload at this size; None otherwise."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(p):
         try:
             with open(p) as f:
-                return json.load(f).get(workload)
+                e = json.load(f).get(workload)
+            if e and e.get("launch_bytes") == launch_bytes:
+                return e.get("hbm_bytes")
         except Exception:
             return None
     return None
@@ -161,11 +164,17 @@ def main():
         build_if_needed()
     # under torch.distributed.run the collective path is exercised even with a single rank
     dist_on = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("CSVSIMD_BENCH_FORCE_DIST") == "1"
-    device = torch.device("cuda", local_rank)
+    # rehearsal of the N > 1 control flow on a ONE-GPU box (dev only, never used by the driver): all
+    # ranks share cuda:0 and the records travel over gloo through the host instead of RCCL
+    rehearsal = os.environ.get("CSVSIMD_BENCH_REHEARSAL") == "1"
+    device = torch.device("cuda", 0 if rehearsal else local_rank)
     torch.cuda.set_device(device)
     if dist_on:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
         dist.barrier()
     pkg = graft.load_package()
     from csv_simd_amd import sharded
@@ -187,6 +196,15 @@ def main():
                                        torch.cuda.current_stream(device).cuda_stream)
             sb.check(r)
             state["count"], state["re"], state["total_entries"] = st.count, bool(st.in_quote_in), st.total_entries
+        elif dist_on and rehearsal:
+            def launch_via_host(inq):
+                sb.launch(inq)
+                sb.h_result.copy_(sb.d_result, non_blocking=True)
+                torch.cuda.current_stream(device).synchronize()
+            st, final, re = sharded.index_sharded(launch_via_host, sb.h_result)
+            sb.check(final)
+            state["count"], state["re"] = st.count, re
+            state["total_entries"] = st.total_entries
         elif dist_on:
             st, final, re = sharded.index_sharded(sb.launch, sb.d_result)
             sb.check(final)
@@ -209,7 +227,7 @@ def main():
     entries = state["count"]
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": load_traffic(args.workload),
+        "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": load_traffic(args.workload, sb.n),
         "kernel": "csvsimd::stage1_kernel<true>", "kernel_ms": round(kern_ms, 4),
         "algorithmic_bytes_per_launch": sb.n,
         "read_plus_tape_write_GBps": round((sb.n + 8 * entries) / (kern_ms * 1e-3) / 1e9, 1),
@@ -224,7 +242,8 @@ def main():
                                f"{sb.n / 2**30:.3f} GiB per GPU (BASELINE config 4's per-GPU shard shape)",
                    "bytes_per_gpu": sb.n, "total_bytes": total_bytes, "tape_entries": int(state["total_entries"]),
                    "parallelism": f"chunk-sharded x{world}, one all-gather of shard descriptors"
-                                  + (" (native RCCL from the C ABI)" if comm is not None else "")},
+                                  + (" (native RCCL from the C ABI)" if comm is not None else "")
+                                  + (" [REHEARSAL: all ranks on one GPU, gloo]" if rehearsal else "")},
         "rows_indexed_per_s": round(rows * args.steps / dt, 1),
         "gib_per_s_per_gpu": round(gib_s / world, 3),
         "roofline": roofline,

@@ -45,13 +45,14 @@ def result_from_words(h) -> ShardResult:
     r.quote_parity = h[3] & 0xFFFFFFFF
     r.in_quote_out = (h[3] >> 32) & 0xFFFFFFFF
     r.error = h[4] & 0xFFFFFFFF
+    r.escape_out = (h[4] >> 32) & 0xFFFFFFFF
     r.written = h[5]
     return r
 
 
 def words_from_result(r: ShardResult) -> List[int]:
     return [r.count, r.count_enter_outside, r.count_enter_inside, r.quote_parity | (r.in_quote_out << 32),
-            r.error, r.written, 0, 0]
+            r.error | (r.escape_out << 32), r.written, 0, 0]
 
 
 def index_sharded(launch: Callable[[int], None], d_result: torch.Tensor, group=None,
