@@ -225,12 +225,24 @@ def main():
                                         warmup=2, iters=max(5, min(args.steps, 50)))
     achieved = sb.n / (kern_ms * 1e-3) / 1e9
     entries = state["count"]
+    # what this GPU's HBM actually streams with the same traffic shape and no work at all (the tape
+    # shard doubles as the probe's output buffer: it is rewritten by the next launch anyway)
+    probed = None
+    if rank == 0 and sb.cap * 8 >= sb.n // 4:
+        s_ = torch.cuda.current_stream(device).cuda_stream
+        ms_r = sb.ctx.hbm_probe_device(sb.dbuf.data_ptr(), sb.n, sb.dtape.data_ptr(), 0, s_, 1, 5)
+        ms_rw = sb.ctx.hbm_probe_device(sb.dbuf.data_ptr(), sb.n, sb.dtape.data_ptr(), 4, s_, 1, 5)
+        probed = {"read_only_GBps": round(sb.n / (ms_r * 1e-3) / 1e9, 1),
+                  "read_with_quarter_written_GBps": round(sb.n / (ms_rw * 1e-3) / 1e9, 1),
+                  "note": "bare nt stream of the same buffer, 16 waves/CU (csvsimd_hbm_probe_device); "
+                          "the 64x31 corpus writes 8 B of tape per 32 B read"}
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": load_traffic(args.workload, sb.n),
         "kernel": "csvsimd::stage1_kernel<true>", "kernel_ms": round(kern_ms, 4),
         "algorithmic_bytes_per_launch": sb.n,
         "read_plus_tape_write_GBps": round((sb.n + 8 * entries) / (kern_ms * 1e-3) / 1e9, 1),
+        "probed_stream": probed,
     }
 
     out = {

@@ -118,6 +118,8 @@ _PROTOTYPES = {
     "csvsimd_utf8_validate_device_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "csvsimd_utf8_validate_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Utf8Result),
                                                C.c_void_p]),
+    "csvsimd_hbm_probe_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p,
+                                           C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "csvsimd_stage1_bound": (C.c_int, [C.c_uint64, _u64p]),
     "csvsimd_stage1_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, _u64p,
                                        C.POINTER(C.c_uint32)]),
@@ -237,6 +239,14 @@ class Context:
         _check(lib().csvsimd_stage1_index_device_dialect_async(self._h, C.byref(dialect), dbuf, length, base_off,
                                                                in_quote_in, dtape or None, tape_cap, d_result,
                                                                stream or None))
+
+    def hbm_probe_device(self, dbuf: int, length: int, dout: int, write_div: int = 0, stream: int = 0,
+                         warmup: int = 2, iters: int = 10) -> float:
+        """ms per pass of the bare HBM stream (read only, or read + 1/4 written)."""
+        ms = C.c_float()
+        _check(lib().csvsimd_hbm_probe_device(self._h, dbuf, length, dout, write_div, stream or None, warmup, iters,
+                                              C.byref(ms)))
+        return float(ms.value)
 
     def utf8_validate_device(self, dbuf: int, length: int, stream: int = 0) -> Optional[int]:
         """None if dbuf[0..length) is valid UTF-8, else the offset of the first offending byte."""

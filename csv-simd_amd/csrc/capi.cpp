@@ -8,12 +8,15 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../host/csv_simd.hpp"
@@ -34,6 +37,84 @@ int fail_hip(hipError_t e, const char* what) {
         if (_e != hipSuccess) return fail_hip(_e, #expr);     \
     } while (0)
 
+// Host-side copies of the ingest pipeline (user buffer -> pinned staging, pinned tape -> user tape).
+// One thread moves ~10-20 GB/s, less than the PCIe link it feeds, so the copies are sliced over a few
+// persistent workers (measured on the MI355X host: 22 -> 39 GiB/s host buffer to tape).
+class CopyPool {
+public:
+    explicit CopyPool(int workers) {
+        for (int i = 0; i < workers; ++i) threads_.emplace_back([this] { run(); });
+    }
+    ~CopyPool() {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+        }
+        cv_work_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+    // synchronous: returns when all n bytes are in place
+    void copy(void* dst, const void* src, size_t n) {
+        constexpr size_t kMinSlice = 2u << 20;
+        const size_t parts = std::min<size_t>(threads_.size() + 1, std::max<size_t>(1, n / kMinSlice));
+        if (parts <= 1) {
+            memcpy(dst, src, n);
+            return;
+        }
+        const size_t slice = ((n / parts) + 4095) & ~(size_t)4095;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            for (size_t off = slice; off < n; off += slice) {
+                jobs_.push_back({(char*)dst + off, (const char*)src + off, std::min(slice, n - off)});
+                ++pending_;
+            }
+        }
+        cv_work_.notify_all();
+        memcpy(dst, src, std::min(slice, n));  // the calling thread takes the first slice
+        std::unique_lock<std::mutex> g(m_);
+        cv_done_.wait(g, [this] { return pending_ == 0; });
+    }
+
+private:
+    struct Job {
+        char* dst;
+        const char* src;
+        size_t n;
+    };
+    void run() {
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_work_.wait(g, [this] { return stop_ || !jobs_.empty(); });
+                if (jobs_.empty()) return;  // stop requested and nothing left
+                j = jobs_.back();
+                jobs_.pop_back();
+            }
+            memcpy(j.dst, j.src, j.n);
+            {
+                std::lock_guard<std::mutex> g(m_);
+                if (--pending_ == 0) cv_done_.notify_all();
+            }
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex m_;
+    std::condition_variable cv_work_, cv_done_;
+    std::vector<Job> jobs_;
+    size_t pending_ = 0;
+    bool stop_ = false;
+};
+
+int ingest_workers() {
+    if (const char* e = getenv("CSVSIMD_INGEST_THREADS")) {
+        const int n = atoi(e);
+        return std::min(std::max(n, 1), 32) - 1;  // the calling thread is one of them
+    }
+    const unsigned hw = std::thread::hardware_concurrency();
+    return (int)std::min<unsigned>(std::max<unsigned>(hw / 4, 2), 6) - 1;  // 2..6 copying threads, caller included
+}
+
 }  // namespace
 
 struct csvsimd_ctx {
@@ -45,7 +126,10 @@ struct csvsimd_ctx {
     csvsimd_shard_result* d_result = nullptr;  // for the synchronous entry points
     // host-buffer path (csvsimd_stage1_index): two-slot pipeline, allocated on first use
     static constexpr uint64_t kChunk = 32ull << 20;  // bytes per slot
-    hipStream_t pipe_stream = nullptr;
+    hipStream_t pipe_stream = nullptr;         // kernels + result records
+    hipStream_t in_stream = nullptr;           // H2D of input chunks (runs one chunk ahead of the kernels)
+    hipStream_t out_stream = nullptr;          // D2H of finished tape chunks
+    hipEvent_t ev_in[2] = {nullptr, nullptr};  // chunk has landed in d_in[k]
     void* pin_in[2] = {nullptr, nullptr};     // pinned staging of the input chunk
     void* d_in[2] = {nullptr, nullptr};
     uint64_t* d_tape[2] = {nullptr, nullptr};  // device tape of a chunk (grown on demand)
@@ -55,6 +139,7 @@ struct csvsimd_ctx {
     csvsimd_shard_result* d_res[2] = {nullptr, nullptr};
     csvsimd_shard_result* h_res = nullptr;     // pinned, 2 records
     hipEvent_t ev[2] = {nullptr, nullptr};
+    std::unique_ptr<CopyPool> copier;         // host-side slices of the staging copies
 };
 
 extern "C" {
@@ -127,7 +212,10 @@ void csvsimd_ctx_destroy(csvsimd_ctx* ctx) {
         if (ctx->d_tape[k]) (void)hipFree(ctx->d_tape[k]);
         if (ctx->d_res[k]) (void)hipFree(ctx->d_res[k]);
         if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
+        if (ctx->ev_in[k]) (void)hipEventDestroy(ctx->ev_in[k]);
     }
+    if (ctx->in_stream) (void)hipStreamDestroy(ctx->in_stream);
+    if (ctx->out_stream) (void)hipStreamDestroy(ctx->out_stream);
     if (ctx->h_res) (void)hipHostFree(ctx->h_res);
     if (ctx->pipe_stream) (void)hipStreamDestroy(ctx->pipe_stream);
     delete ctx;
@@ -233,26 +321,31 @@ int csvsimd_stage1_bound(uint64_t len, uint64_t* max_entries) {
 }
 
 // Host-buffer drop-in for reader::read (ingest).  The file is streamed through
-// the GPU in 32-MiB chunks over a two-slot pipeline on a private stream: while chunk i travels
-// (pinned staging -> H2D -> stage-1 kernel -> D2H of exactly its entries) the host thread stages
-// chunk i+1 and unloads the tape of chunk i-1.  The two loop-carried values of the reference
-// (inside_str, array_idx: src/reader.rs:217-218) are carried between chunks on the host.  This path
-// is PCIe / host-memcpy bound by construction; the HBM-resident entry points are the timed ones.
+// the GPU in 32-MiB chunks over a two-slot pipeline on three private streams (H2D, kernels, D2H):
+// while the kernel of chunk i runs, chunk i+1 is staged (sliced over a few host threads) and already
+// copied to the device, and the tape of chunk i-1 (exactly its entries) travels back and is unloaded.
+// The two loop-carried values of the reference (inside_str, array_idx: src/reader.rs:217-218) are
+// carried between chunks on the host.  This path is PCIe bound by construction; the HBM-resident
+// entry points are the timed ones.
 static int pipe_setup(csvsimd_ctx* ctx) {
     if (ctx->pipe_stream) return CSVSIMD_OK;
+    if (!ctx->copier) ctx->copier.reset(new CopyPool(ingest_workers()));
     HIP_TRY(hipStreamCreateWithFlags(&ctx->pipe_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->in_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->out_stream, hipStreamNonBlocking));
     HIP_TRY(hipHostMalloc((void**)&ctx->h_res, 2 * sizeof(csvsimd_shard_result), hipHostMallocDefault));
     for (int k = 0; k < 2; ++k) {
         HIP_TRY(hipHostMalloc(&ctx->pin_in[k], csvsimd_ctx::kChunk, hipHostMallocDefault));
         HIP_TRY(hipMalloc(&ctx->d_in[k], csvsimd_ctx::kChunk));
         HIP_TRY(hipMalloc((void**)&ctx->d_res[k], sizeof(csvsimd_shard_result)));
         HIP_TRY(hipEventCreateWithFlags(&ctx->ev[k], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ctx->ev_in[k], hipEventDisableTiming));
     }
     return CSVSIMD_OK;
 }
 static int pipe_ensure_tape(csvsimd_ctx* ctx, int k, uint64_t entries) {
     if (ctx->d_tape_entries[k] >= entries) return CSVSIMD_OK;
-    HIP_TRY(hipStreamSynchronize(ctx->pipe_stream));
+    HIP_TRY(hipDeviceSynchronize());
     if (ctx->d_tape[k]) HIP_TRY(hipFree(ctx->d_tape[k]));
     ctx->d_tape[k] = nullptr;
     ctx->d_tape_entries[k] = 0;
@@ -262,7 +355,7 @@ static int pipe_ensure_tape(csvsimd_ctx* ctx, int k, uint64_t entries) {
 }
 static int pipe_ensure_out(csvsimd_ctx* ctx, int k, uint64_t entries) {
     if (ctx->pin_out_entries[k] >= entries) return CSVSIMD_OK;
-    HIP_TRY(hipStreamSynchronize(ctx->pipe_stream));
+    HIP_TRY(hipDeviceSynchronize());
     if (ctx->pin_out[k]) HIP_TRY(hipHostFree(ctx->pin_out[k]));
     ctx->pin_out[k] = nullptr;
     ctx->pin_out_entries[k] = 0;
@@ -294,16 +387,25 @@ static int stage1_index_host_impl(csvsimd_ctx* ctx, const csvsimd_dialect* diale
     auto unload = [&](int k) -> int {  // waits for the slot's D2H, then copies to the user's tape
         if (!pend[k].valid) return CSVSIMD_OK;
         HIP_TRY(hipEventSynchronize(ctx->ev[k]));
-        if (pend[k].ncopy) memcpy(tape + pend[k].at, ctx->pin_out[k], pend[k].ncopy * 8);
+        if (pend[k].ncopy) ctx->copier->copy(tape + pend[k].at, ctx->pin_out[k], pend[k].ncopy * 8);
         pend[k].valid = false;
         return CSVSIMD_OK;
     };
 
-    if (nchunks) memcpy(ctx->pin_in[0], buf, std::min<uint64_t>(kChunk, len));
+    // stages chunk j into its slot and starts its H2D copy on the input stream
+    auto feed = [&](uint64_t j) -> int {
+        const int kj = (int)(j & 1);
+        const uint64_t offj = j * kChunk, lenj = std::min<uint64_t>(kChunk, len - offj);
+        ctx->copier->copy(ctx->pin_in[kj], buf + offj, lenj);
+        HIP_TRY(hipMemcpyAsync(ctx->d_in[kj], ctx->pin_in[kj], lenj, hipMemcpyHostToDevice, ctx->in_stream));
+        HIP_TRY(hipEventRecord(ctx->ev_in[kj], ctx->in_stream));
+        return CSVSIMD_OK;
+    };
+    if (nchunks && (rc = feed(0)) != CSVSIMD_OK) return rc;
     for (uint64_t i = 0; i < nchunks; ++i) {
         const int k = (int)(i & 1);
         const uint64_t off = i * kChunk, clen = std::min<uint64_t>(kChunk, len - off);
-        HIP_TRY(hipMemcpyAsync(ctx->d_in[k], ctx->pin_in[k], clen, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamWaitEvent(st, ctx->ev_in[k], 0));
         // first guess: one entry per 4 bytes; exact retry below if the chunk is denser
         uint64_t cap = 0;
         if (tape) {
@@ -315,8 +417,9 @@ static int stage1_index_host_impl(csvsimd_ctx* ctx, const csvsimd_dialect* diale
                                st);
         if (rc != CSVSIMD_OK) return rc;
         HIP_TRY(hipMemcpyAsync(&ctx->h_res[k], ctx->d_res[k], sizeof(csvsimd_shard_result), hipMemcpyDeviceToHost, st));
-        // while chunk i is in flight: stage chunk i+1, unload the tape of chunk i-1
-        if (i + 1 < nchunks) memcpy(ctx->pin_in[k ^ 1], buf + off + kChunk, std::min<uint64_t>(kChunk, len - off - kChunk));
+        // while chunk i is in flight: stage chunk i+1 and start its H2D copy (slot k^1 is free: the
+        // kernel of chunk i-1 has been waited for), unload the tape of chunk i-1
+        if (i + 1 < nchunks && (rc = feed(i + 1)) != CSVSIMD_OK) return rc;
         rc = unload(k ^ 1);
         if (rc != CSVSIMD_OK) return rc;
         HIP_TRY(hipStreamSynchronize(st));
@@ -335,8 +438,11 @@ static int stage1_index_host_impl(csvsimd_ctx* ctx, const csvsimd_dialect* diale
             if (ncopy) {
                 rc = pipe_ensure_out(ctx, k, std::max<uint64_t>(ncopy, 4096));
                 if (rc != CSVSIMD_OK) return rc;
-                HIP_TRY(hipMemcpyAsync(ctx->pin_out[k], ctx->d_tape[k], ncopy * 8, hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipEventRecord(ctx->ev[k], st));
+                // the kernel has finished (its result record was waited for): the tape chunk leaves on
+                // its own stream, next to the H2D of the following chunk (PCIe is full duplex)
+                HIP_TRY(hipMemcpyAsync(ctx->pin_out[k], ctx->d_tape[k], ncopy * 8, hipMemcpyDeviceToHost,
+                                       ctx->out_stream));
+                HIP_TRY(hipEventRecord(ctx->ev[k], ctx->out_stream));
                 pend[k] = {true, n, ncopy};
             }
         }
@@ -386,6 +492,33 @@ int csvsimd_stitch_shards(const csvsimd_shard_result* results, uint32_t n_shards
 }
 
 /* ---- tape --------------------------------------------------------------------------------- */
+
+int csvsimd_hbm_probe_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len, void* dout, int write_div,
+                             void* hip_stream, int warmup, int iters, float* avg_ms) {
+    if (!ctx || !dbuf || !avg_ms || iters <= 0 || iters > 4096 || ((uintptr_t)dbuf & 15)) return CSVSIMD_ERR_INVALID_ARG;
+    if (write_div != 0 && write_div != 4) return CSVSIMD_ERR_INVALID_ARG;
+    if (!dout || ((uintptr_t)dout & 15) || len < 131072) return CSVSIMD_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)hip_stream;
+    int rc = csvsimd_ctx_reserve(ctx, 1 << 20);  // the ticket lives in the context scratch
+    if (rc != CSVSIMD_OK) return rc;
+    const uint32_t blocks = (uint32_t)ctx->n_cus * 4u;  // 16 waves per CU, like the stage-1 kernel
+    for (int i = 0; i < warmup; ++i)
+        HIP_TRY(csvsimd::launch_hbm_probe(dbuf, len, dout, write_div, (uint32_t*)ctx->scratch, blocks, s));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i)
+        HIP_TRY(csvsimd::launch_hbm_probe(dbuf, len, dout, write_div, (uint32_t*)ctx->scratch, blocks, s));
+    HIP_TRY(hipEventRecord(e1, s));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_ms = ms / (float)iters;
+    return CSVSIMD_OK;
+}
 
 }  // extern "C"
 
@@ -525,14 +658,6 @@ int csvsimd_create(csvsimd_ctx* ctx, const char* filename, csvsimd_tape** out) {
 }
 
 /* ---- utilities ------------------------------------------------------------------------------ */
-
-// development aid (not part of include/csvsimd.h): copies the look-back scratch block to the host
-int csvsimd_debug_copy_scratch(csvsimd_ctx* ctx, void* dst, uint64_t bytes) {
-    if (!ctx || !dst || bytes > ctx->scratch_bytes) return CSVSIMD_ERR_INVALID_ARG;
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(dst, ctx->scratch, bytes, hipMemcpyDeviceToHost));
-    return CSVSIMD_OK;
-}
 
 int csvsimd_synth_fill_device(void* dbuf, uint64_t file_off, uint64_t len, uint32_t cols, uint32_t width,
                               uint64_t seed, uint32_t quote_pct, void* hip_stream) {

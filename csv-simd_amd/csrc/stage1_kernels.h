@@ -68,6 +68,8 @@ hipError_t launch_synth(void* dbuf, uint64_t file_off, uint64_t len, uint32_t co
 hipError_t launch_checksum(const void* dtape, uint64_t n, uint64_t first_index, void* d_out,
                            hipStream_t stream);
 hipError_t launch_selftest(uint32_t* d_out, hipStream_t stream);
+hipError_t launch_hbm_probe(const void* din, uint64_t len, void* dout, int write_div, uint32_t* ticket,
+                            uint32_t blocks, hipStream_t stream);
 hipError_t launch_field_spans(const void* dindex, uint64_t row_size, uint32_t field_idx, uint64_t first_record,
                               uint64_t n_records, void* d_begin, void* d_end, hipStream_t stream);
 hipError_t launch_gather_fields(const void* dbytes, const void* d_begin, const void* d_end, uint64_t n_records,

@@ -978,6 +978,54 @@ __global__ void checksum_kernel(const u64* tape, u64 n, u64 first_index, u64* ou
     }
 }
 
+// HBM streaming probe with the stage-1 traffic shape and none of its work: the achievable ceiling
+// the roofline fraction can be read against (bench.py reports it next to the 8 TB/s spec peak).
+// 128-KiB tiles from an atomic ticket, 4 waves x 8 rounds x 4 KiB, non-temporal both ways; WRITE_DIV 0
+// = read only, 4 = one byte written per four read (the 64x31 corpus writes 8 B per 32 B).
+template <int WRITE_DIV>
+__global__ __launch_bounds__(256) void hbm_probe_kernel(const uint8_t* __restrict__ in, uint4* __restrict__ out,
+                                                        u32* ticket, u32 num_tiles) {
+    __shared__ u32 s_tile;
+    const u32 t = threadIdx.x, lane = t & 63u, w = t >> 6;
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    for (;;) {
+        if (t == 0) s_tile = atomicAdd(ticket, 1u);
+        __syncthreads();
+        const u32 tile = s_tile;
+        __syncthreads();
+        if (tile >= num_tiles) break;
+        const u64 tile0 = (u64)tile * 131072;
+        const rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(in) + tile0, 0, 131072, 0x00020000);
+        for (int r0 = 0; r0 < 8; r0 += 2) {
+            uint4 v[2][4];
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const auto x = __builtin_amdgcn_raw_buffer_load_b128(
+                        rsrc, (int)(w * 32768u + (u32)(r0 + d) * 4096u + (u32)j * 1024u + lane * 16u), 0, kLoadAux);
+                    v[d][j] = make_uint4(x[0], x[1], x[2], x[3]);
+                }
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                uint4 o;
+                o.x = v[d][0].x ^ v[d][1].x ^ v[d][2].x ^ v[d][3].x;
+                o.y = v[d][0].y ^ v[d][1].y ^ v[d][2].y ^ v[d][3].y;
+                o.z = v[d][0].z ^ v[d][1].z ^ v[d][2].z ^ v[d][3].z;
+                o.w = v[d][0].w ^ v[d][1].w ^ v[d][2].w ^ v[d][3].w;
+                if (WRITE_DIV == 4) {
+                    const u32x4 x = {o.x, o.y, o.z, o.w};
+                    __builtin_nontemporal_store(
+                        x, reinterpret_cast<u32x4*>(out + tile0 / 64 + (w * 32768u + (u32)(r0 + d) * 4096u) / 64 + lane));
+                } else {
+                    acc.x ^= o.x; acc.y ^= o.y; acc.z ^= o.z; acc.w ^= o.w;
+                }
+            }
+        }
+    }
+    if (WRITE_DIV == 0 && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) out[0] = acc;  // keeps the loads alive
+}
+
 // self-test of the wavefront primitives against plain loops (one wave); out[0] = failure bits
 __global__ void selftest_kernel(u32* out) {
     __shared__ u32 s_v[64];
@@ -1177,6 +1225,20 @@ hipError_t launch_gather_fields(const void* dbytes, const void* d_begin, const v
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(gather_fields_kernel, dim3((u32)blocks), dim3(256), 0, stream, (const uint8_t*)dbytes,
                        (const u64*)d_begin, (const u64*)d_end, n_records, (uint8_t*)d_dst, stride, (u32*)d_len);
+    return hipGetLastError();
+}
+
+hipError_t launch_hbm_probe(const void* din, u64 len, void* dout, int write_div, u32* ticket, u32 blocks,
+                            hipStream_t stream) {
+    const u32 tiles = (u32)(len / 131072);
+    if (tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(zero_kernel, dim3(1), dim3(64), 0, stream, (uint4*)ticket, 1u, (uint4*)ticket, 0u);
+    if (write_div == 4)
+        hipLaunchKernelGGL(hbm_probe_kernel<4>, dim3(blocks), dim3(256), 0, stream, (const uint8_t*)din, (uint4*)dout,
+                           ticket, tiles);
+    else
+        hipLaunchKernelGGL(hbm_probe_kernel<0>, dim3(blocks), dim3(256), 0, stream, (const uint8_t*)din, (uint4*)dout,
+                           ticket, tiles);
     return hipGetLastError();
 }
 

@@ -275,6 +275,14 @@ int csvsimd_stage1_time_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len,
                                uint64_t tape_cap, void* d_result, void* hip_stream, int warmup,
                                int iters, float* avg_ms);
 
+/* HBM streaming probe: the stage-1 traffic shape with none of its work, so bench.py can report
+ * the ceiling this GPU actually reaches next to the 8 TB/s spec peak.  Reads dbuf[0..len) (16-byte
+ * aligned, len a multiple of 128 KiB is what gets streamed) with non-temporal loads; write_div 0 =
+ * read only, 4 = also writes len / 4 bytes to dout (>= len / 4 bytes, 16-byte aligned).  Average ms
+ * of `iters` launches by hipEvents on hip_stream. */
+int csvsimd_hbm_probe_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len, void* dout, int write_div,
+                             void* hip_stream, int warmup, int iters, float* avg_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,6 +23,8 @@ def test_header_symbols_all_exported(pkg):
     assert len(declared) >= 30
     missing = [s for s in declared if s not in exported]
     assert not missing, missing
+    # nothing is exported behind the header's back
+    assert sorted(exported) == declared, sorted(exported - set(declared))
     # and the Python binding knows each of them
     assert sorted(pkg.EXPORTED_SYMBOLS) == declared
     pkg.lib()  # resolves all prototypes
