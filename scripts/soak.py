@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""dev tool: time-bounded soak of the stage-1 kernel variants — every launch's count and
+order-sensitive tape checksum must equal the first launch's (which is checked against the analytic /
+oracle value by the tests).  Looks for rare scheduling-dependent faults (look-back races)."""
+import collections
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft
+
+pkg = graft.load_package()
+
+
+def main():
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    ctx = pkg.Context(0)
+    dev = torch.device("cuda", 0)
+    cases = []
+    for name, gib in (("16x32_q10", 1.0), ("64x31_q10", 2.0), ("1024x4_dense", 0.5), ("64x31_noquote", 4.0)):
+        cols, width, seed, q = pkg.WORKLOADS[name]
+        n = pkg.workload_len(name, int(gib * 2**30)) - 7      # ragged tail
+        dbuf = torch.empty(n + 16, dtype=torch.uint8, device=dev)
+        pkg.synth_fill_device(dbuf.data_ptr(), 0, n + 16 - (n + 16) % 4, cols, width, seed, q)
+        cap = n // (width + 1) + 64
+        dtape = torch.empty(cap, dtype=torch.int64, device=dev)
+        for dialect in (None, pkg.Dialect(",", '"', "\\"), pkg.Dialect(";", "'")):
+            for mis in (0, 5):
+                cases.append((name, n, dbuf, dtape, cap, dialect, mis))
+    dres = torch.zeros(8, dtype=torch.int64, device=dev)
+    dsum = torch.zeros(2, dtype=torch.int64, device=dev)
+    ref = {}
+    hist = collections.Counter()
+    t_end = time.time() + seconds
+    launches = 0
+    while time.time() < t_end:
+        for ci, (name, n, dbuf, dtape, cap, dialect, mis) in enumerate(cases):
+            inq = launches & 1
+            if dialect is None:
+                ctx.stage1_index_device_async(dbuf.data_ptr() + mis, n, 123, inq, dtape.data_ptr(), cap, dres.data_ptr())
+            else:
+                ctx.stage1_index_device_dialect_async(dialect, dbuf.data_ptr() + mis, n, 123, inq, dtape.data_ptr(), cap,
+                                                      dres.data_ptr())
+            r = pkg.ShardResult.from_buffer_copy(dres.cpu().numpy().tobytes())
+            dsum.zero_()
+            pkg.tape_checksum_device(dtape.data_ptr(), min(r.count, cap), 0, dsum.data_ptr())
+            key = (ci, inq)
+            sig = (r.count, r.in_quote_out, r.error, r.count_enter_outside, r.count_enter_inside, tuple(dsum.tolist()))
+            if key not in ref:
+                ref[key] = sig
+            hist["ok" if sig == ref[key] else f"MISMATCH case {ci} {name} inq {inq}: {sig} != {ref[key]}"] += 1
+            launches += 1
+    print(json.dumps({"seconds": seconds, "launches": launches, "cases": len(cases), "hist": dict(hist)}))
+    return 0 if set(hist) == {"ok"} else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
