@@ -94,20 +94,24 @@ __device__ __forceinline__ u32 masked_dword(const Utf8Range& r, u64 q) {
 // the very last bytes finds its missing continuation
 __global__ __launch_bounds__(256) void utf8_scan_kernel(Utf8Range r, u64 n_chunks, u64 n_real_chunks, u64* result) {
     const u32 lane = threadIdx.x & 63u;
-    const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    // wave-uniform by construction; saying so lets the halo load below be a scalar load
+    const u64 wave = (u64)blockIdx.x * (blockDim.x >> 6) + (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const u64 n_waves = ((u64)gridDim.x * blockDim.x) >> 6;
     const u64 n_blocks = (n_chunks + 255) / 256;  // 4 KiB = 256 chunks of 16 bytes per wave iteration
     u64 first = ~0ull;
     for (u64 blk = wave; blk < n_blocks; blk += n_waves) {
         u32x4 v[4];
         u32 hib[4];
+        // buffer loads with the hardware range check: chunks past the end of the buffer read as zeros,
+        // no branch around the loads (the descriptor is rebuilt per 4-KiB block: its size field is 32 bit)
+        const u64 blk0 = blk * 4096;
+        const u64 avail = n_real_chunks * 16 > blk0 ? n_real_chunks * 16 - blk0 : 0;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint8_t*>(r.abase) + blk0, 0, (int)(avail < 4096 ? avail : 4096), 0x00020000);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const u64 c = blk * 256 + (u64)j * 64 + lane;
-            v[j] = u32x4{0, 0, 0, 0};
-            if (c < n_real_chunks) v[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(r.abase) + c);
-        }
-        // the four bytes before the block (same address in every lane: one broadcast transaction)
+        for (int j = 0; j < 4; ++j)
+            v[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((u32)j * 1024u + lane * 16u), 0, 2 /* nt */);
+        // the four bytes before the block (wave-uniform address: a scalar load)
         const u32 halo = blk ? masked_dword(r, blk * 4096 - 4) : 0u;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
