@@ -239,7 +239,7 @@ def main():
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": load_traffic(args.workload, sb.n),
-        "kernel": "csvsimd::stage1_kernel<true>", "kernel_ms": round(kern_ms, 4),
+        "kernel": "void csvsimd::stage1_kernel<true, 0, 0>(csvsimd::KernelArgs)", "kernel_ms": round(kern_ms, 4),
         "algorithmic_bytes_per_launch": sb.n,
         "read_plus_tape_write_GBps": round((sb.n + 8 * entries) / (kern_ms * 1e-3) / 1e9, 1),
         "probed_stream": probed,
