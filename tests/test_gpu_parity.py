@@ -91,9 +91,10 @@ def test_random_small_all_residues(ctx, torch_cuda, oracle):
             assert np.array_equal(np.concatenate([[0], got]).astype(np.uint64), oracle.sse_read(d)), n
 
 
-def test_misaligned_base_off_and_entering_state(ctx, torch_cuda, oracle):
+def test_misaligned_base_off_and_entering_state(ctx, torch_cuda, pkg, oracle):
     rng = np.random.default_rng(77)
-    for n in (1, 15, 16, 17, 100, 5000, 131072 - 3, 131072 + 5):
+    T = pkg.tile_bytes()
+    for n in (1, 15, 16, 17, 100, 5000, T // 2 - 3, T // 2 + 5, T - 3, T + 5):
         d = random_csvish(rng, n, 0.05)
         for mis in (0, 1, 7, 15):
             for inq in (0, 1):
@@ -104,7 +105,7 @@ def test_misaligned_base_off_and_entering_state(ctx, torch_cuda, oracle):
 
 
 def test_tile_boundaries_and_lookback(ctx, torch_cuda, pkg, oracle):
-    # sizes around multiples of the 128 KiB tile; quotes make the in-string state cross tiles
+    # sizes around multiples of the tile (pkg.tile_bytes(), 256 KiB); quotes make the in-string state cross tiles
     rng = np.random.default_rng(31337)
     T = pkg.tile_bytes()
     for n in (T - 1, T, T + 1, 2 * T - 16, 2 * T + 16, 5 * T + 12345, 37 * T + 1):
