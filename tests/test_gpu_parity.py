@@ -505,3 +505,38 @@ def test_fuzz_many_shapes(ctx, torch_cuda, pkg, oracle):
         want, q = oracle.scalar_index(d, base_off=base, in_quote_in=inq)
         assert (r.count, r.in_quote_out, r.error) == (want.size, q, 0), (case, n, pq, mis, inq)
         assert np.array_equal(got, want), (case, n, pq, mis, inq)
+
+
+def test_more_entries_than_the_reference_u32_index(ctx, torch_cuda, pkg):
+    # Maximum sizes: the reference keeps its tape position in a u32 (`array_idx`, src/reader.rs:218) and
+    # record_cnt in a u32 (src/tape.rs:329), so it stops being defined at 2^32 entries.  This path
+    # counts and indexes in 64 bits: one launch over 21.5 GB of the dense corpus = 2^32 + 1024 entries
+    # (34 GB of tape), every entry checked against the closed form 5 j + 4.
+    torch = torch_cuda
+    free, _ = torch.cuda.mem_get_info()
+    if free < 80 * 2**30:
+        pytest.skip("needs ~60 GB of free HBM")
+    cols, width, seed, q = pkg.WORKLOADS["1024x4_dense"]
+    row = cols * (width + 1)
+    rows = ((2**32 + 1024) * (width + 1) + row - 1) // row
+    n = rows * row
+    S = n // (width + 1)
+    assert S > 2**32
+    dbuf = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    pkg.synth_fill_device(dbuf.data_ptr(), 0, n, cols, width, seed, q)
+    dtape = torch.empty(S + 8, dtype=torch.int64, device="cuda:0")
+    dtape[S:] = -1
+    r = ctx.stage1_index_device(dbuf.data_ptr(), n, 0, 0, dtape.data_ptr(), S)
+    assert (r.count, r.written, r.in_quote_out, r.error) == (S, S, 0, 0)
+    assert r.count_enter_outside == S and r.count_enter_inside == 0   # no quote ever closes a string entered inside
+    assert bool((dtape[S:] == -1).all())
+    step = 1 << 28
+    for lo in range(0, S, step):
+        hi = min(S, lo + step)
+        want = torch.arange(lo, hi, dtype=torch.int64, device="cuda:0") * (width + 1) + width
+        assert torch.equal(dtape[lo:hi], want), lo
+        del want
+    # a shard that starts beyond 2^32 entries of tape: base offsets are 64-bit too
+    r2 = ctx.stage1_index_device(dbuf.data_ptr(), 1 << 20, 2**45 + 5, 0, dtape.data_ptr(), S)
+    assert r2.count == (1 << 20) // (width + 1)
+    assert int(dtape[0]) == 2**45 + 5 + width and int(dtape[r2.count - 1]) == 2**45 + 5 + (r2.count - 1) * 5 + width
