@@ -11,7 +11,7 @@
 use crate::stage1::{CodeUnitPos, StructureIndex};
 use bytemuck::allocation::cast_vec;
 use memmap::Mmap;
-use std::os::raw::{c_int, c_void};
+use std::os::raw::c_int;
 
 #[repr(C)]
 pub struct CsvsimdCtx {
@@ -57,7 +57,6 @@ pub fn read(memmap: &Mmap) -> StructureIndex {
         csvsimd_ctx_destroy(ctx);
         assert_eq!(rc, 0, "csvsimd_stage1_index failed");
         acc.set_len(n as usize); // usize == u64 on every target the crate supports (x86_64)
-        let _ = std::mem::size_of::<c_void>();
         StructureIndex(cast_vec::<usize, CodeUnitPos>(acc))
     }
 }
