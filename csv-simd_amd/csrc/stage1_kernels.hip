@@ -575,28 +575,31 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // Writes window entries comp[0, n) (u16 offsets relative to the span) to tape[run, run + n) as
 // fully coalesced non-temporal stores, 16 bytes (two entries) per lane wherever the address allows.
+template <bool NOSTORE = false>
 __device__ __forceinline__ void flush_window(const KernelArgs& args, const unsigned short* comp, u32 n, u64 run,
                                              u64 span_off, u32 lane) {
     if (n == 0) return;
+    // NOSTORE (development probe): an impossible capacity keeps the loop but drops the stores
     u64* const tape = args.tape;
+    const u64 tape_cap = NOSTORE ? (args.tape_cap & 1ull) : args.tape_cap;
     // entry k sits at byte address tape + 8 (run + k): peel one entry if that is not 16-byte aligned
     const u32 head = (u32)((((uintptr_t)tape >> 3) + run) & 1u);
-    if (head && lane == 0 && run < args.tape_cap) __builtin_nontemporal_store(span_off + comp[0], tape + run);
+    if (head && lane == 0 && run < tape_cap) __builtin_nontemporal_store(span_off + comp[0], tape + run);
     const u32 npairs = (n - head) >> 1;
     for (u32 i = lane; i < npairs; i += 64) {
         const u32 k = head + 2 * i;
         const u64 idx = run + k;
         const u64 e0 = span_off + comp[k], e1 = span_off + comp[k + 1];
-        if (idx + 1 < args.tape_cap) {
+        if (idx + 1 < tape_cap) {
             const u32x4 x = {(u32)e0, (u32)(e0 >> 32), (u32)e1, (u32)(e1 >> 32)};
             __builtin_nontemporal_store(x, reinterpret_cast<u32x4*>(tape + idx));
-        } else if (idx < args.tape_cap) {
+        } else if (idx < tape_cap) {
             __builtin_nontemporal_store(e0, tape + idx);
         }
     }
     if (((n - head) & 1u) && lane == 0) {
         const u64 idx = run + n - 1;
-        if (idx < args.tape_cap) __builtin_nontemporal_store(span_off + comp[n - 1], tape + idx);
+        if (idx < tape_cap) __builtin_nontemporal_store(span_off + comp[n - 1], tape + idx);
     }
 }
 
@@ -628,6 +631,7 @@ __device__ __forceinline__ void scatter_bits(unsigned short* comp, u64 R, u32 p,
 // wave-private LDS window.  Rounds are batched into the window until it is full, so a sparse span
 // (CSV with long fields) leaves as one long run of 16-byte stores.
 //   wstate: absolute in-string state entering the span; run: tape index of the span's first entry
+template <bool NOSTORE = false>
 __device__ __forceinline__ void emit_span(const KernelArgs& args, const RoundMasks (&m)[kRounds], u32 lane, u64 span0,
                                           u32 wstate, u64 run, unsigned short* comp) {
     const u64 flipall = wstate ? ~0ull : 0ull;
@@ -646,7 +650,7 @@ __device__ __forceinline__ void emit_span(const KernelArgs& args, const RoundMas
         const u32 stripe_rel = (u32)r * kRoundBytes + lane * 64u;
         if (fill + n_r > (u32)kCompCap) {
             wave_lds_fence();
-            flush_window(args, comp, fill, run, span_off, lane);
+            flush_window<NOSTORE>(args, comp, fill, run, span_off, lane);
             wave_lds_fence();
             run += fill;
             fill = 0;
@@ -660,7 +664,7 @@ __device__ __forceinline__ void emit_span(const KernelArgs& args, const RoundMas
                 scatter_bits(comp, R, excl - win, stripe_rel);
                 wave_lds_fence();
                 const u32 n_win = (n_r - win) < (u32)kCompCap ? (n_r - win) : (u32)kCompCap;
-                flush_window(args, comp, n_win, run, span_off, lane);
+                flush_window<NOSTORE>(args, comp, n_win, run, span_off, lane);
                 wave_lds_fence();
                 run += n_win;
             }
@@ -670,7 +674,7 @@ __device__ __forceinline__ void emit_span(const KernelArgs& args, const RoundMas
         __builtin_amdgcn_sched_barrier(0);
     }
     wave_lds_fence();
-    flush_window(args, comp, fill, run, span_off, lane);
+    flush_window<NOSTORE>(args, comp, fill, run, span_off, lane);
     wave_lds_fence();
 }
 
@@ -686,7 +690,7 @@ __device__ __forceinline__ void wg_barrier() {
 // DBG (development probes only, never used by the product entry points): 0 = normal,
 // bit 0 = skip classification (loads only), bit 1 = static tiles (no ticket; only without look-back),
 // bit 2 = no look-back, bit 3 = accumulate per-phase s_memrealtime stamps of waves 0 and 1 into
-// tot_struct[8..] (timing build)
+// tot_struct[8..] (timing build), bit 4 = emit phase without its global stores
 //
 // One iteration of the workgroup loop (three barriers):
 //   ticket -> [T] -> count phase of tile_i (masks -> registers) -> [A] -> wave 0: publish the
@@ -855,7 +859,7 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
             const u32 wstate = pin ^ held_before.p;
             const u64 run = s_base + (pin ? held_before.b : held_before.a);
             const u64 span0 = (u64)held_tile * kTileBytes + (u64)w * kSpanBytes;
-            emit_span(args, held, lane, span0, wstate, run, reinterpret_cast<unsigned short*>(s_stage[w]));
+            emit_span<(DBG & 16) != 0>(args, held, lane, span0, wstate, run, reinterpret_cast<unsigned short*>(s_stage[w]));
         }
         // the tile counted in this iteration becomes the held one
         have_held = have_cur;
@@ -1163,6 +1167,8 @@ hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream) {
             hipLaunchKernelGGL((stage1_kernel<false, 6>), dim3(grid), dim3(kThreads), 0, stream, a);
         else if (L.debug_mode == 7)
             hipLaunchKernelGGL((stage1_kernel<false, 7>), dim3(grid), dim3(kThreads), 0, stream, a);
+        else if (L.debug_mode == 16 && a.tape)
+            hipLaunchKernelGGL((stage1_kernel<true, 16>), dim3(grid), dim3(kThreads), 0, stream, a);
         else if (L.debug_mode == 8 && a.tape)
             hipLaunchKernelGGL((stage1_kernel<true, 8>), dim3(grid), dim3(kThreads), 0, stream, a);
         else if (L.debug_mode == 8)
