@@ -126,6 +126,7 @@ struct csvsimd_ctx {
     csvsimd_shard_result* d_result = nullptr;  // for the synchronous entry points
     // host-buffer path (csvsimd_stage1_index): two-slot pipeline, allocated on first use
     static constexpr uint64_t kChunk = 32ull << 20;  // bytes per slot
+    bool pipe_ready = false;                   // every resource below exists
     hipStream_t pipe_stream = nullptr;         // kernels + result records
     hipStream_t in_stream = nullptr;           // H2D of input chunks (runs one chunk ahead of the kernels)
     hipStream_t out_stream = nullptr;          // D2H of finished tape chunks
@@ -203,6 +204,7 @@ int csvsimd_ctx_create(int device, csvsimd_ctx** out) {
 void csvsimd_ctx_destroy(csvsimd_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();  // nothing of this context may still be in flight
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->d_result) (void)hipFree(ctx->d_result);
     for (int k = 0; k < 2; ++k) {
@@ -328,19 +330,22 @@ int csvsimd_stage1_bound(uint64_t len, uint64_t* max_entries) {
 // carried between chunks on the host.  This path is PCIe bound by construction; the HBM-resident
 // entry points are the timed ones.
 static int pipe_setup(csvsimd_ctx* ctx) {
-    if (ctx->pipe_stream) return CSVSIMD_OK;
+    if (ctx->pipe_ready) return CSVSIMD_OK;
+    // a previous attempt may have failed half way (out of memory): only create what is still missing
     if (!ctx->copier) ctx->copier.reset(new CopyPool(ingest_workers()));
-    HIP_TRY(hipStreamCreateWithFlags(&ctx->pipe_stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&ctx->in_stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&ctx->out_stream, hipStreamNonBlocking));
-    HIP_TRY(hipHostMalloc((void**)&ctx->h_res, 2 * sizeof(csvsimd_shard_result), hipHostMallocDefault));
+    if (!ctx->pipe_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->pipe_stream, hipStreamNonBlocking));
+    if (!ctx->in_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->in_stream, hipStreamNonBlocking));
+    if (!ctx->out_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->out_stream, hipStreamNonBlocking));
+    if (!ctx->h_res)
+        HIP_TRY(hipHostMalloc((void**)&ctx->h_res, 2 * sizeof(csvsimd_shard_result), hipHostMallocDefault));
     for (int k = 0; k < 2; ++k) {
-        HIP_TRY(hipHostMalloc(&ctx->pin_in[k], csvsimd_ctx::kChunk, hipHostMallocDefault));
-        HIP_TRY(hipMalloc(&ctx->d_in[k], csvsimd_ctx::kChunk));
-        HIP_TRY(hipMalloc((void**)&ctx->d_res[k], sizeof(csvsimd_shard_result)));
-        HIP_TRY(hipEventCreateWithFlags(&ctx->ev[k], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&ctx->ev_in[k], hipEventDisableTiming));
+        if (!ctx->pin_in[k]) HIP_TRY(hipHostMalloc(&ctx->pin_in[k], csvsimd_ctx::kChunk, hipHostMallocDefault));
+        if (!ctx->d_in[k]) HIP_TRY(hipMalloc(&ctx->d_in[k], csvsimd_ctx::kChunk));
+        if (!ctx->d_res[k]) HIP_TRY(hipMalloc((void**)&ctx->d_res[k], sizeof(csvsimd_shard_result)));
+        if (!ctx->ev[k]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev[k], hipEventDisableTiming));
+        if (!ctx->ev_in[k]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_in[k], hipEventDisableTiming));
     }
+    ctx->pipe_ready = true;
     return CSVSIMD_OK;
 }
 static int pipe_ensure_tape(csvsimd_ctx* ctx, int k, uint64_t entries) {
@@ -492,33 +497,6 @@ int csvsimd_stitch_shards(const csvsimd_shard_result* results, uint32_t n_shards
 }
 
 /* ---- tape --------------------------------------------------------------------------------- */
-
-int csvsimd_hbm_probe_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len, void* dout, int write_div,
-                             void* hip_stream, int warmup, int iters, float* avg_ms) {
-    if (!ctx || !dbuf || !avg_ms || iters <= 0 || iters > 4096 || ((uintptr_t)dbuf & 15)) return CSVSIMD_ERR_INVALID_ARG;
-    if (write_div != 0 && write_div != 4) return CSVSIMD_ERR_INVALID_ARG;
-    if (!dout || ((uintptr_t)dout & 15) || len < 131072) return CSVSIMD_ERR_INVALID_ARG;
-    hipStream_t s = (hipStream_t)hip_stream;
-    int rc = csvsimd_ctx_reserve(ctx, 1 << 20);  // the ticket lives in the context scratch
-    if (rc != CSVSIMD_OK) return rc;
-    const uint32_t blocks = (uint32_t)ctx->n_cus * 4u;  // 16 waves per CU, like the stage-1 kernel
-    for (int i = 0; i < warmup; ++i)
-        HIP_TRY(csvsimd::launch_hbm_probe(dbuf, len, dout, write_div, (uint32_t*)ctx->scratch, blocks, s));
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, s));
-    for (int i = 0; i < iters; ++i)
-        HIP_TRY(csvsimd::launch_hbm_probe(dbuf, len, dout, write_div, (uint32_t*)ctx->scratch, blocks, s));
-    HIP_TRY(hipEventRecord(e1, s));
-    HIP_TRY(hipEventSynchronize(e1));
-    float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    *avg_ms = ms / (float)iters;
-    return CSVSIMD_OK;
-}
 
 }  // extern "C"
 
@@ -813,6 +791,33 @@ int csvsimd_stage1_time_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len,
                 fprintf(stderr, "PROF wave%d %-16s %.2f us per workgroup (sum over its tiles)\n", wv, names[k],
                         (double)h[8 + wv * 8 + k] / nwg / 100.0);
     }
+    return CSVSIMD_OK;
+}
+
+int csvsimd_hbm_probe_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len, void* dout, int write_div,
+                             void* hip_stream, int warmup, int iters, float* avg_ms) {
+    if (!ctx || !dbuf || !avg_ms || iters <= 0 || iters > 4096 || ((uintptr_t)dbuf & 15)) return CSVSIMD_ERR_INVALID_ARG;
+    if (write_div != 0 && write_div != 4) return CSVSIMD_ERR_INVALID_ARG;
+    if (!dout || ((uintptr_t)dout & 15) || len < 131072) return CSVSIMD_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)hip_stream;
+    int rc = csvsimd_ctx_reserve(ctx, 1 << 20);  // the ticket lives in the context scratch
+    if (rc != CSVSIMD_OK) return rc;
+    const uint32_t blocks = (uint32_t)ctx->n_cus * 4u;  // 16 waves per CU, like the stage-1 kernel
+    for (int i = 0; i < warmup; ++i)
+        HIP_TRY(csvsimd::launch_hbm_probe(dbuf, len, dout, write_div, (uint32_t*)ctx->scratch, blocks, s));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i)
+        HIP_TRY(csvsimd::launch_hbm_probe(dbuf, len, dout, write_div, (uint32_t*)ctx->scratch, blocks, s));
+    HIP_TRY(hipEventRecord(e1, s));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_ms = ms / (float)iters;
     return CSVSIMD_OK;
 }
 
