@@ -24,7 +24,11 @@ int oracle_scalar_read(const uint8_t* buf, uint64_t len, uint64_t* tape, uint64_
 void oracle_shard_descriptor(const uint8_t* buf, uint64_t len, uint32_t* parity,
                              uint64_t* cnt_enter_outside, uint64_t* cnt_enter_inside);
 
-/* Dialect extension (NOT a reference behaviour — the reference classifies
+/* PARITY UNPINNED against the reference for everything marked "extension" below: the reference never
+ * executes such behaviour, so these definitions are pinned on independent implementations instead
+ * (Python's csv module, CPython's UTF-8 decoder — tests/test_oracle.py).
+ *
+ * Dialect extension (NOT a reference behaviour — the reference classifies
  * space/backslash, src/stage1.rs:41-48, but never uses them and hard-wires ',' and '"',
  * src/avx/stage1.rs:392-394).  Scalar definition the GPU dialect kernels are checked against:
  *   an escaped byte (the one after an unescaped `escape` byte) is literal; `quote` toggles the
