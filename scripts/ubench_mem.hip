@@ -8,9 +8,19 @@
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ inline void nt_store(uint4 v, uint4* p) { u32x4 x = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(x, reinterpret_cast<u32x4*>(p)); }
+template <int POL>
+__device__ inline void pol_store(uint4 v, uint4* p) {
+    u32x4 x = {v.x, v.y, v.z, v.w};
+    if (POL == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(p), "v"(x) : "memory");
+    else if (POL == 3) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(p), "v"(x) : "memory");
+    else if (POL == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" :: "v"(p), "v"(x) : "memory");
+    else if (POL == 5) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(x) : "memory");
+    else if (POL == 1) __builtin_nontemporal_store(x, reinterpret_cast<u32x4*>(p));
+    else *reinterpret_cast<u32x4*>(p) = x;
+}
 
 // each block streams tiles of 128 KiB: 256 threads x 8 rounds x 4 x 16 B (the stage-1 geometry)
-template <int WRITE_DIV, int LD_AUX, bool NT_STORE, bool DYN, int DEPTH = 1, bool ILV = false>
+template <int WRITE_DIV, int LD_AUX, int NT_STORE, bool DYN, int DEPTH = 1, bool ILV = false>
 __global__ __launch_bounds__(256) void stream(const uint8_t* __restrict__ in, uint4* __restrict__ out, uint64_t n,
                                               uint32_t* ticket, uint32_t num_tiles) {
     __shared__ uint32_t s_tile;
@@ -42,12 +52,12 @@ __global__ __launch_bounds__(256) void stream(const uint8_t* __restrict__ in, ui
             o.z = v[0].z ^ v[1].z ^ v[2].z ^ v[3].z; o.w = v[0].w ^ v[1].w ^ v[2].w ^ v[3].w;
             if (WRITE_DIV == 4) {
                 uint4* dst = out + (tile0 / 64) + (ILV ? (r * 4 + w) * 4096 : w * 32768 + r * 4096) / 64 + lane;
-                if (NT_STORE) nt_store(o, dst); else *dst = o;
+                pol_store<NT_STORE>(o, dst);
             } else if (WRITE_DIV == 1) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     uint4* dst = out + (tile0 / 16) + (w * 32768 + r * 4096 + j * 1024) / 16 + lane;
-                    if (NT_STORE) nt_store(v[j], dst); else *dst = v[j];
+                    pol_store<NT_STORE>(v[j], dst);
                 }
             } else {
                 acc.x ^= o.x; acc.y ^= o.y; acc.z ^= o.z; acc.w ^= o.w;
@@ -58,7 +68,7 @@ __global__ __launch_bounds__(256) void stream(const uint8_t* __restrict__ in, ui
     }
 }
 
-template <int WRITE_DIV, int LD_AUX, bool NT_STORE, bool DYN, int DEPTH = 1, bool ILV = false>
+template <int WRITE_DIV, int LD_AUX, int NT_STORE, bool DYN, int DEPTH = 1, bool ILV = false>
 int run(const char* name, const uint8_t* in, uint4* out, uint64_t n, uint32_t* ticket, int bpc) {
     const uint32_t tiles = (uint32_t)(n / 131072);
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -86,6 +96,19 @@ int main() {
         run<0, 2, false, true, 4>("read only nt, ticket, depth 4", in, out, n, ticket, bpc);
         run<4, 2, true, true, 2, true>("INTERLEAVED rounds: read nt + write 1/4 nt, depth 2", in, out, n, ticket, bpc);
         run<0, 2, false, true, 2, true>("INTERLEAVED rounds: read only nt, depth 2", in, out, n, ticket, bpc);
+    }
+    {
+        const int bpc = 4;
+        run<4, 2, 1, true, 2>("POLICY ld nt(2)      st nt", in, out, n, ticket, bpc);
+        run<4, 2, 2, true, 2>("POLICY ld nt(2)      st sc0 sc1 nt", in, out, n, ticket, bpc);
+        run<4, 2, 3, true, 2>("POLICY ld nt(2)      st sc1 nt", in, out, n, ticket, bpc);
+        run<4, 2, 4, true, 2>("POLICY ld nt(2)      st sc0 nt", in, out, n, ticket, bpc);
+        run<4, 2, 5, true, 2>("POLICY ld nt(2)      st sc0 sc1", in, out, n, ticket, bpc);
+        run<4, 3, 1, true, 2>("POLICY ld sc0 nt(3)  st nt", in, out, n, ticket, bpc);
+        run<4, 18, 1, true, 2>("POLICY ld sc1 nt(18) st nt", in, out, n, ticket, bpc);
+        run<4, 19, 1, true, 2>("POLICY ld sc0 sc1 nt(19) st nt", in, out, n, ticket, bpc);
+        run<4, 17, 1, true, 2>("POLICY ld sc0 sc1(17) st nt", in, out, n, ticket, bpc);
+        run<4, 19, 2, true, 2>("POLICY ld 19 st sc0 sc1 nt", in, out, n, ticket, bpc);
     }
     for (int bpc : {4, 8}) {
         run<0, 0, false, false>("read only, static", in, out, n, ticket, bpc);
