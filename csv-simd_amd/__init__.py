@@ -120,6 +120,8 @@ _PROTOTYPES = {
                                                C.c_void_p]),
     "csvsimd_hbm_probe_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p,
                                            C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "csvsimd_tape_record_spans_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint64,
+                                                   C.c_uint64, C.c_void_p, C.c_void_p, _u64p, C.c_void_p]),
     "csvsimd_stage1_bound": (C.c_int, [C.c_uint64, _u64p]),
     "csvsimd_stage1_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, _u64p,
                                        C.POINTER(C.c_uint32)]),
@@ -461,6 +463,17 @@ def tape_field_spans_device(dindex: int, index_len: int, field_cnt: int, new_lin
                                                  NEWLINE_CRLF if new_line == "CRLF" else NEWLINE_LF, field_idx,
                                                  first_record, n_records, d_begin or None, d_end or None,
                                                  C.byref(n), stream or None))
+    return n.value
+
+
+def tape_record_spans_device(dindex: int, index_len: int, field_cnt: int, new_line: str, first_record: int,
+                             n_records: int, d_begin: int, d_end: int, stream: int = 0) -> int:
+    """Bulk seek_record on the GPU; returns how many of the requested records exist."""
+    n = C.c_uint64()
+    _check(lib().csvsimd_tape_record_spans_device(dindex, index_len, field_cnt,
+                                                  NEWLINE_CRLF if new_line == "CRLF" else NEWLINE_LF, first_record,
+                                                  n_records, d_begin or None, d_end or None, C.byref(n),
+                                                  stream or None))
     return n.value
 
 

@@ -667,7 +667,25 @@ int csvsimd_tape_field_spans_device(const void* dindex, uint64_t index_len, uint
     // seek_field: Ok(None) when record_idx + 1 >= record_cnt or field_idx >= field_cnt
     if (field_idx >= field_cnt || first_record + 1 >= record_cnt) return CSVSIMD_OK;
     const uint64_t n = std::min<uint64_t>(n_records, record_cnt - 1 - first_record);
-    HIP_TRY(csvsimd::launch_field_spans(dindex, row_size, field_idx, first_record, n, d_begin, d_end,
+    HIP_TRY(csvsimd::launch_field_spans(dindex, row_size, field_idx, 1, first_record, n, d_begin, d_end,
+                                        (hipStream_t)hip_stream));
+    *n_valid = n;
+    return CSVSIMD_OK;
+}
+
+int csvsimd_tape_record_spans_device(const void* dindex, uint64_t index_len, uint32_t field_cnt, int new_line,
+                                     uint64_t first_record, uint64_t n_records, void* d_begin, void* d_end,
+                                     uint64_t* n_valid, void* hip_stream) {
+    if (!dindex || !n_valid || field_cnt == 0 || (n_records && (!d_begin || !d_end))) return CSVSIMD_ERR_INVALID_ARG;
+    if (csvsimd_device_count() <= 0) return CSVSIMD_ERR_NO_DEVICE;
+    const uint64_t row_size = (uint64_t)field_cnt + (new_line == CSVSIMD_NEWLINE_CRLF ? 1 : 0);  // = record jump size
+    if (index_len == 0) return CSVSIMD_ERR_INVALID_STATE;
+    if ((index_len - 1) % row_size != 0) return CSVSIMD_ERR_INVALID_CSV_FORMAT;
+    const uint64_t record_cnt = (index_len - 1) / row_size;
+    *n_valid = 0;
+    if (first_record + 1 >= record_cnt) return CSVSIMD_OK;  // seek_record: Ok(None)
+    const uint64_t n = std::min<uint64_t>(n_records, record_cnt - 1 - first_record);
+    HIP_TRY(csvsimd::launch_field_spans(dindex, row_size, 0, field_cnt, first_record, n, d_begin, d_end,
                                         (hipStream_t)hip_stream));
     *n_valid = n;
     return CSVSIMD_OK;

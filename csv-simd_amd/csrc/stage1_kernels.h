@@ -70,8 +70,9 @@ hipError_t launch_checksum(const void* dtape, uint64_t n, uint64_t first_index, 
 hipError_t launch_selftest(uint32_t* d_out, hipStream_t stream);
 hipError_t launch_hbm_probe(const void* din, uint64_t len, void* dout, int write_div, uint32_t* ticket,
                             uint32_t blocks, hipStream_t stream);
-hipError_t launch_field_spans(const void* dindex, uint64_t row_size, uint32_t field_idx, uint64_t first_record,
-                              uint64_t n_records, void* d_begin, void* d_end, hipStream_t stream);
+hipError_t launch_field_spans(const void* dindex, uint64_t row_size, uint32_t field_idx, uint32_t fields,
+                              uint64_t first_record, uint64_t n_records, void* d_begin, void* d_end,
+                              hipStream_t stream);
 hipError_t launch_gather_fields(const void* dbytes, const void* d_begin, const void* d_end, uint64_t n_records,
                                 void* d_dst, uint32_t stride, void* d_len, hipStream_t stream);
 // text_kernels.hip

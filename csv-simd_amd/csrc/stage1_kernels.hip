@@ -1094,12 +1094,14 @@ __global__ void selftest_kernel(u32* out) {
 // index = the tape WITH its sentinel (index[0] == 0); row_size = field_cnt (+1 for CRLF files,
 // src/record_source.rs:124-127); record r (0 = first data row) field f:
 //   idx = (r + 1) * row_size + f;  text = bytes[index[idx] + 1 .. index[idx + 1])
-__global__ void field_spans_kernel(const u64* __restrict__ index, u64 row_size, u32 field_idx, u64 first_record,
-                                   u64 n_records, u64* __restrict__ begin, u64* __restrict__ end) {
+// seek_record (src/record_source.rs:70-104) is the same walk over `fields` = field_cnt entries from
+// field 0: text = bytes[index[(r + 1) * row_size] + 1 .. index[(r + 1) * row_size + field_cnt])
+__global__ void field_spans_kernel(const u64* __restrict__ index, u64 row_size, u32 field_idx, u32 fields,
+                                   u64 first_record, u64 n_records, u64* __restrict__ begin, u64* __restrict__ end) {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_records; i += (u64)gridDim.x * blockDim.x) {
         const u64 idx = (first_record + i + 1) * row_size + field_idx;
         begin[i] = index[idx] + 1;
-        end[i] = index[idx + 1];
+        end[i] = index[idx + fields];
     }
 }
 
@@ -1214,13 +1216,13 @@ hipError_t launch_checksum(const void* dtape, u64 n, u64 first_index, void* d_ou
     return hipGetLastError();
 }
 
-hipError_t launch_field_spans(const void* dindex, u64 row_size, u32 field_idx, u64 first_record, u64 n_records,
-                              void* d_begin, void* d_end, hipStream_t stream) {
+hipError_t launch_field_spans(const void* dindex, u64 row_size, u32 field_idx, u32 fields, u64 first_record,
+                              u64 n_records, void* d_begin, void* d_end, hipStream_t stream) {
     if (n_records == 0) return hipSuccess;
     u64 blocks = (n_records + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(field_spans_kernel, dim3((u32)blocks), dim3(256), 0, stream, (const u64*)dindex, row_size,
-                       field_idx, first_record, n_records, (u64*)d_begin, (u64*)d_end);
+                       field_idx, fields, first_record, n_records, (u64*)d_begin, (u64*)d_end);
     return hipGetLastError();
 }
 

@@ -226,6 +226,11 @@ const uint8_t* csvsimd_tape_bytes(const csvsimd_tape* t, uint64_t* len);
 int csvsimd_tape_field_spans_device(const void* dindex, uint64_t index_len, uint32_t field_cnt, int new_line,
                                     uint32_t field_idx, uint64_t first_record, uint64_t n_records,
                                     void* d_begin, void* d_end, uint64_t* n_valid, void* hip_stream);
+/* RecordSource::seek_record (src/record_source.rs:70-104) for a range of records: bytes[begin..end)
+ * is the whole row without its line end — the pair csvsimd_tape_seek_record returns. */
+int csvsimd_tape_record_spans_device(const void* dindex, uint64_t index_len, uint32_t field_cnt, int new_line,
+                                     uint64_t first_record, uint64_t n_records, void* d_begin, void* d_end,
+                                     uint64_t* n_valid, void* hip_stream);
 /* Copies the text of each span into row i of d_dst (n_records x stride bytes, truncated to stride,
  * zero padded); d_len[i] (uint32, may be NULL) = untruncated length.  The column-gather step of
  * the reference's stated goal "frequency counts, and function search" (design_notes_1.md:1-4). */

@@ -415,6 +415,17 @@ def test_device_field_spans_and_gather(ctx, torch_cuda, pkg, golden, oracle):
                 assert lh[rec] == len(want)
                 row = bytes(dh[rec][: min(len(want), stride)])
                 assert row == want[:stride] and not dh[rec][len(want):].any()
+        # whole records: seek_record for all rows at once
+        rb = torch.full((nrec + 2,), -1, dtype=torch.int64, device="cuda:0")
+        re_ = torch.full((nrec + 2,), -1, dtype=torch.int64, device="cuda:0")
+        assert pkg.tape_record_spans_device(dindex.data_ptr(), host_index.size, t.field_cnt, t.new_line, 0, nrec + 2,
+                                            rb.data_ptr(), re_.data_ptr()) == nrec
+        assert bool((rb[nrec:] == -1).all())
+        rbh, reh = rb.cpu().tolist(), re_.cpu().tolist()
+        for rec in list(range(0, nrec, max(1, nrec // 300))) + [nrec - 1]:
+            assert data[rbh[rec]: reh[rec]] == t.seek_record(rec), rec
+        assert pkg.tape_record_spans_device(dindex.data_ptr(), host_index.size, t.field_cnt, t.new_line, nrec, 3,
+                                            rb.data_ptr(), re_.data_ptr()) == 0
         # the Ok(None) cases of seek_field
         assert pkg.tape_field_spans_device(dindex.data_ptr(), host_index.size, t.field_cnt, t.new_line, t.field_cnt, 0, 5, b.data_ptr(), e.data_ptr()) == 0
         assert pkg.tape_field_spans_device(dindex.data_ptr(), host_index.size, t.field_cnt, t.new_line, 0, nrec, 5, b.data_ptr(), e.data_ptr()) == 0
