@@ -49,7 +49,10 @@ static constexpr int kRoundBytes = kRows * 1024;        // 4 KiB per wave per ro
 static constexpr int kRounds = CSVSIMD_ROUNDS;          // rounds per wave per tile
 static constexpr int kSpanBytes = kRounds * kRoundBytes;  // 32 KiB contiguous per wave
 static constexpr int kTileBytes = kWaves * kSpanBytes;    // 256 KiB per workgroup tile
-static constexpr int kCompCap = 2048;                   // u16 entries per wave compaction window (aliases the stage image)
+#ifndef CSVSIMD_COMP_CAP
+#define CSVSIMD_COMP_CAP 2048
+#endif
+static constexpr int kCompCap = CSVSIMD_COMP_CAP;                   // u16 entries per wave compaction window (aliases the stage image)
 // every input byte is read exactly once and every tape byte written exactly once: non-temporal
 // on both sides (measured on the same traffic mix: +11 % over default-policy loads and stores)
 static constexpr int kLoadAux = 2;                      // buffer-load cache policy bits: nt
@@ -473,6 +476,7 @@ __device__ __forceinline__ void count_phase(rsrc_t rsrc, u32 lane, u32 w, const 
     // two images per wave: rounds r+1 and r+2 stream in (8 KiB per wave in flight, no VGPRs) while
     // round r is classified
     u32 voff = w * (u32)kSpanBytes + sa.src;  // one running VGPR, advanced per round
+    u32 rslot = sa.rslot;
     dma_round(rsrc, voff, stage0);
     voff += (u32)kRoundBytes;
     asm volatile("" : "+v"(voff));
@@ -489,8 +493,12 @@ __device__ __forceinline__ void count_phase(rsrc_t rsrc, u32 lane, u32 w, const 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         uint4 stripe[kRows];  // lane l: the 64 contiguous bytes of stripe l of this round
+        // opaque: the eight read addresses (4 chunks x 2 images) are cheap to rebuild (one v_xad each) but,
+        // hoisted out of the tile loop, they are what hipcc spills — and a scratch reload in here
+        // waits for vmcnt(0), i.e. for the LDS-DMA prefetch of the next rounds (measured: -9 %)
+        asm volatile("" : "+v"(rslot));
 #pragma unroll
-        for (int k = 0; k < kRows; ++k) stripe[k] = stage[sa.rslot ^ (u32)k];
+        for (int k = 0; k < kRows; ++k) stripe[k] = stage[rslot ^ (u32)k];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         // the image is free again: request round r+2 into it
@@ -582,9 +590,14 @@ __device__ __forceinline__ void flush_window(const KernelArgs& args, const unsig
     // NOSTORE (development probe): an impossible capacity keeps the loop but drops the stores
     u64* const tape = args.tape;
     const u64 tape_cap = NOSTORE ? (args.tape_cap & 1ull) : args.tape_cap;
-    // entry k sits at byte address tape + 8 (run + k): peel one entry if that is not 16-byte aligned
-    const u32 head = (u32)((((uintptr_t)tape >> 3) + run) & 1u);
-    if (head && lane == 0 && run < tape_cap) __builtin_nontemporal_store(span_off + comp[0], tape + run);
+    // Entry k sits at byte address tape + 8 (run + k).  Up to 7 head entries are peeled so that the
+    // main loop's wave stores start on a 64-byte line: each then covers 16 whole lines.  Measured
+    // (scripts/ubench_mem.hip, scripts/exp_width.py): wave stores that straddle lines cost 4 % of the
+    // whole stream at a 20 % write share and 13 % on the dense corpus, whose tape offsets are not a
+    // multiple of 8 entries.
+    u32 head = (0u - (u32)(((uintptr_t)tape >> 3) + run)) & 7u;
+    head = head < n ? head : n;
+    if (lane < head && run + lane < tape_cap) __builtin_nontemporal_store(span_off + comp[lane], tape + run + lane);
     const u32 npairs = (n - head) >> 1;
     for (u32 i = lane; i < npairs; i += 64) {
         const u32 k = head + 2 * i;
