@@ -47,8 +47,8 @@ struct Stage1Launch {
     uint32_t escape_in = 0;
 
     static uint64_t scratch_bytes_for(uint64_t len) {
-        // + 1 tile: an unaligned dbuf shifts the data by up to 15 bytes
-        const uint64_t tiles = (len + 15 + CSVSIMD_TILE_BYTES - 1) / CSVSIMD_TILE_BYTES + 1;
+        // + 1 tile: an unaligned dbuf shifts the data by up to 127 bytes
+        const uint64_t tiles = (len + 127 + CSVSIMD_TILE_BYTES - 1) / CSVSIMD_TILE_BYTES + 1;
         return 528 + 8 * tiles + 16;
     }
     uint64_t scratch_zero_bytes(uint32_t num_tiles) const {

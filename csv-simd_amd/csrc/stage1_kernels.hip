@@ -52,7 +52,11 @@ static constexpr int kTileBytes = kWaves * kSpanBytes;    // 256 KiB per workgro
 #ifndef CSVSIMD_COMP_CAP
 #define CSVSIMD_COMP_CAP 2048
 #endif
-static constexpr int kCompCap = CSVSIMD_COMP_CAP;                   // u16 entries per wave compaction window (aliases the stage image)
+static constexpr int kCompCap = CSVSIMD_COMP_CAP;
+#ifndef CSVSIMD_STORE_ALIGN
+#define CSVSIMD_STORE_ALIGN 128
+#endif
+static constexpr int kStoreAlignEntries = CSVSIMD_STORE_ALIGN / 8;  // tape entries per aligned store unit                   // u16 entries per wave compaction window (aliases the stage image)
 // every input byte is read exactly once and every tape byte written exactly once: non-temporal
 // on both sides (measured on the same traffic mix: +11 % over default-policy loads and stores)
 static constexpr int kLoadAux = 2;                      // buffer-load cache policy bits: nt
@@ -400,7 +404,10 @@ __device__ __forceinline__ void load_round(rsrc_t rsrc, u32 voff, uint4 (&v)[kRo
 }
 
 // A shard whose start is not 16-byte aligned, or whose end is not a multiple of 64, has one
-// partially valid stripe at each end.  Loads always fetch whole 16-byte chunks (a chunk never
+// partially valid stripe at each end.  (Addressing the shard from its 128-byte line instead would
+// save the 1.7 % that line-straddling wave loads cost a misaligned shard, but the two-stripe front
+// edge it needs cost the aligned case 2.3 % in this kernel: measured and not adopted.)
+// Loads always fetch whole 16-byte chunks (a chunk never
 // crosses a page; chunks entirely past the end read as zero through the buffer descriptor — zero
 // bytes are class 0, exactly like the reference's zero padding of its last block,
 // src/avx/stage1.rs:54-92) and the stray bytes of those two stripes are dropped at the bit level
@@ -590,12 +597,12 @@ __device__ __forceinline__ void flush_window(const KernelArgs& args, const unsig
     // NOSTORE (development probe): an impossible capacity keeps the loop but drops the stores
     u64* const tape = args.tape;
     const u64 tape_cap = NOSTORE ? (args.tape_cap & 1ull) : args.tape_cap;
-    // Entry k sits at byte address tape + 8 (run + k).  Up to 7 head entries are peeled so that the
-    // main loop's wave stores start on a 64-byte line: each then covers 16 whole lines.  Measured
-    // (scripts/ubench_mem.hip, scripts/exp_width.py): wave stores that straddle lines cost 4 % of the
-    // whole stream at a 20 % write share and 13 % on the dense corpus, whose tape offsets are not a
-    // multiple of 8 entries.
-    u32 head = (0u - (u32)(((uintptr_t)tape >> 3) + run)) & 7u;
+    // Entry k sits at byte address tape + 8 (run + k).  Head entries are peeled so that the main
+    // loop's wave stores start on a 128-byte boundary (the L2 line): each 1-KiB store then covers
+    // whole lines only.  Measured (scripts/ubench_mem.hip, scripts/exp_width.py): wave stores that
+    // straddle lines cost 4 % of the whole stream at a 20 % write share and 13 % on the dense
+    // corpus, whose tape offsets are not a multiple of the line.
+    u32 head = (0u - (u32)(((uintptr_t)tape >> 3) + run)) & (u32)(kStoreAlignEntries - 1);
     head = head < n ? head : n;
     if (lane < head && run + lane < tape_cap) __builtin_nontemporal_store(span_off + comp[lane], tape + run + lane);
     const u32 npairs = (n - head) >> 1;

@@ -34,7 +34,7 @@ typedef uint64_t u64;
 // decodes forward sequentially to the exact offset.
 // ---------------------------------------------------------------------------------------------
 struct Utf8Range {
-    const uint8_t* abase;  // 16-byte aligned
+    const uint8_t* abase;  // 128-byte aligned
     u64 lo, hi;            // valid bytes are abase[lo, hi)
 };
 
@@ -207,8 +207,8 @@ hipError_t launch_utf8_validate(const void* dbuf, u64 len, void* d_result, int n
     if (e != hipSuccess || len == 0) return e;
     const uintptr_t addr = (uintptr_t)dbuf;
     Utf8Range r;
-    r.abase = (const uint8_t*)(addr & ~(uintptr_t)15);
-    r.lo = (u64)(addr & 15);
+    r.abase = (const uint8_t*)(addr & ~(uintptr_t)127);  // wave loads on whole 128-byte lines
+    r.lo = (u64)(addr & 127);
     r.hi = r.lo + len;
     const u64 n_real = (r.hi + 15) / 16;
     const u64 n_chunks = n_real + 1;

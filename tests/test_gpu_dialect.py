@@ -26,7 +26,7 @@ def torch_cuda():
 
 def gpu_dialect(ctx, pkg, torch, host, dialect, *, base_off=0, in_quote_in=0, misalign=0):
     n = host.size
-    dbuf = torch.zeros(n + 64, dtype=torch.uint8, device="cuda:0")
+    dbuf = torch.zeros(n + 256, dtype=torch.uint8, device="cuda:0")
     if n:
         dbuf[misalign: misalign + n] = torch.from_numpy(host)
     # poison around the payload with bytes that are special in every dialect used here
@@ -85,7 +85,7 @@ def test_other_delimiters_random(ctx, pkg, torch_cuda, oracle):
                     pkg.Dialect(0xFF, 0x00 + 0x61)):
         for n in (0, 1, 63, 64, 65, 4097, T - 1, T + 1, 3 * T + 777):
             d = alphabet[rng.integers(0, alphabet.size, size=n)].astype(np.uint8)
-            for mis, inq in ((0, 0), (5, 1), (15, 0)):
+            for mis, inq in ((0, 0), (5, 1), (15, 0), (64, 1), (100, 0), (127, 1)):
                 check(ctx, pkg, torch_cuda, oracle, d, dialect, base_off=7 + 2**40, in_quote_in=inq, misalign=mis)
 
 
@@ -103,7 +103,7 @@ def test_escape_random_densities(ctx, pkg, torch_cuda, oracle):
     for n in (0, 1, 2, 63, 64, 65, 128, 4096, 4097, 32768 + 1, T, T + 3, 2 * T + 12345):
         for p in (0.02, 0.3, 0.7, 0.97):
             d = escapey(rng, n, p)
-            for mis in (0, 1, 9, 15):
+            for mis in (0, 1, 9, 15, 63, 64, 65, 127):
                 for esc_in in (0, 1):
                     dia = pkg.Dialect(",", '"', "\\", escape_in=esc_in)
                     check(ctx, pkg, torch_cuda, oracle, d, dia, in_quote_in=int(rng.integers(0, 2)), misalign=mis)
@@ -115,7 +115,7 @@ def test_escape_runs_across_every_boundary(ctx, pkg, torch_cuda, oracle):
     rng = np.random.default_rng(4)
     T = pkg.tile_bytes()
     n = 2 * T + 5000
-    for mis in (0, 3):
+    for mis in (0, 3, 67):
         for run_len in (1, 2, 3, 63, 64, 65, 127, 128, 129, 191, 192, 4096, 4097, 32768 + 1):
             d = escapey(rng, n, 0.0)
             d[d == BS] = ord("a")
@@ -136,7 +136,7 @@ def test_escape_whole_buffer_of_escapes(ctx, pkg, torch_cuda, oracle):
     for n in (1, 2, 63, 64, 65, 128, 4096, 40000):
         d = np.full(n, BS, dtype=np.uint8)
         for esc_in in (0, 1):
-            for mis in (0, 7):
+            for mis in (0, 7, 64, 71):
                 dia = pkg.Dialect(",", '"', "\\", escape_in=esc_in)
                 _, r = check(ctx, pkg, torch_cuda, oracle, d, dia, misalign=mis)
                 assert r.escape_out == (n - esc_in) % 2
@@ -151,7 +151,7 @@ def test_escape_split_invariance(ctx, pkg, torch_cuda, oracle):
     for cut in (1, 64, 4095, T - 1, T, T + 17, 2 * T + 333):
         a, ra = gpu_dialect(ctx, pkg, torch_cuda, d[:cut], pkg.Dialect(",", '"', "\\"))
         b, rb = gpu_dialect(ctx, pkg, torch_cuda, d[cut:], pkg.Dialect(",", '"', "\\", escape_in=ra.escape_out),
-                            base_off=cut, in_quote_in=ra.in_quote_out, misalign=cut % 16)
+                            base_off=cut, in_quote_in=ra.in_quote_out, misalign=cut % 128)
         assert np.array_equal(np.concatenate([a, b]), whole), cut
         assert (rb.in_quote_out, rb.escape_out) == (rw.in_quote_out, rw.escape_out)
 

@@ -22,7 +22,7 @@ def gpu_index(ctx, torch, host: np.ndarray, *, base_off=0, in_quote_in=0, misali
     """Runs the device entry point on a copy of `host` placed `misalign` bytes past an aligned
     device address.  Returns (entries uint64[], ShardResult)."""
     n = host.size
-    dbuf = torch.zeros(n + 64, dtype=torch.uint8, device="cuda:0")
+    dbuf = torch.zeros(n + 256, dtype=torch.uint8, device="cuda:0")
     if n:
         dbuf[misalign: misalign + n] = torch.from_numpy(host)
     # poison around the payload: stray reads of neighbouring bytes must not leak into the tape
@@ -96,7 +96,7 @@ def test_misaligned_base_off_and_entering_state(ctx, torch_cuda, pkg, oracle):
     T = pkg.tile_bytes()
     for n in (1, 15, 16, 17, 100, 5000, T // 2 - 3, T // 2 + 5, T - 3, T + 5):
         d = random_csvish(rng, n, 0.05)
-        for mis in (0, 1, 7, 15):
+        for mis in (0, 1, 7, 15, 16, 63, 64, 65, 100, 127):
             for inq in (0, 1):
                 got, r = gpu_index(ctx, torch_cuda, d, base_off=10**12 + 3, in_quote_in=inq, misalign=mis)
                 want, q = oracle.scalar_index(d, base_off=10**12 + 3, in_quote_in=inq)
@@ -509,7 +509,7 @@ def test_fuzz_many_shapes(ctx, torch_cuda, pkg, oracle):
         if n and rng.random() < 0.3:   # long runs of one byte class
             a, b = sorted(rng.integers(0, n + 1, size=2))
             d[a:b] = rng.choice(np.frombuffer(b',"\na', dtype=np.uint8))
-        mis = int(rng.integers(0, 16))
+        mis = int(rng.integers(0, 128))
         inq = int(rng.integers(0, 2))
         base = int(rng.integers(0, 2**40))
         got, r = gpu_index(ctx, torch, d, base_off=base, in_quote_in=inq, misalign=mis)

@@ -23,7 +23,7 @@ def torch_cuda():
 
 def gpu_utf8(ctx, torch, host: np.ndarray, misalign=0, poison=0xFF):
     n = host.size
-    dbuf = torch.full((n + 64,), poison, dtype=torch.uint8, device="cuda:0")
+    dbuf = torch.full((n + 256,), poison, dtype=torch.uint8, device="cuda:0")
     if n:
         dbuf[misalign: misalign + n] = torch.from_numpy(host.copy())
     return ctx.utf8_validate_device(dbuf.data_ptr() + misalign, n)
@@ -33,7 +33,7 @@ def test_utf8_sequences_at_every_boundary(ctx, torch_cuda, oracle):
     # each sequence, valid or not, ending at / straddling 16-byte chunk, 1-KiB wave-load and 4-KiB
     # wave-iteration boundaries, and at the very start / end of the buffer; two poisons around it
     n = 3 * 4096 + 100
-    for mis in (0, 5, 15):
+    for mis in (0, 5, 15, 77, 127):
         for seq in BAD_AND_GOOD:
             s = np.frombuffer(seq, dtype=np.uint8)
             for edge in (0, 16, 1024, 4096, 8192, n):
@@ -55,7 +55,7 @@ def test_utf8_small_and_empty(ctx, torch_cuda, oracle):
     assert gpu_utf8(ctx, torch_cuda, np.zeros(0, dtype=np.uint8)) is None
     for _ in range(400):
         d = pool[rng.integers(0, pool.size, size=int(rng.integers(1, 40)))]
-        assert gpu_utf8(ctx, torch_cuda, d, int(rng.integers(0, 16))) == oracle.utf8_first_invalid(d), d.tobytes()
+        assert gpu_utf8(ctx, torch_cuda, d, int(rng.integers(0, 128))) == oracle.utf8_first_invalid(d), d.tobytes()
 
 
 def test_utf8_multilingual_text_and_corruptions(ctx, torch_cuda, oracle):
@@ -73,7 +73,7 @@ def test_utf8_multilingual_text_and_corruptions(ctx, torch_cuda, oracle):
             d = base.copy()
             for p in rng.integers(0, d.size, size=int(rng.integers(1, 4))):
                 d[p] = rng.integers(0, 256)
-            assert gpu_utf8(ctx, torch_cuda, d, int(rng.integers(0, 16))) == oracle.utf8_first_invalid(d)
+            assert gpu_utf8(ctx, torch_cuda, d, int(rng.integers(0, 128))) == oracle.utf8_first_invalid(d)
 
 
 def test_utf8_large_buffer(ctx, torch_cuda, oracle):
