@@ -20,7 +20,7 @@ __device__ inline void pol_store(uint4 v, uint4* p) {
 }
 
 // each block streams tiles of 128 KiB: 256 threads x 8 rounds x 4 x 16 B (the stage-1 geometry)
-template <int WRITE_DIV, int LD_AUX, int NT_STORE, bool DYN, int DEPTH = 1, bool ILV = false, int SHIFT = 0>
+template <int WRITE_DIV, int LD_AUX, int NT_STORE, bool DYN, int DEPTH = 1, bool ILV = false, int SHIFT = 0, bool BURST = false>
 __global__ __launch_bounds__(256) void stream(const uint8_t* __restrict__ in, uint4* __restrict__ out, uint64_t n,
                                               uint32_t* ticket, uint32_t num_tiles) {
     __shared__ uint32_t s_tile;
@@ -33,6 +33,7 @@ __global__ __launch_bounds__(256) void stream(const uint8_t* __restrict__ in, ui
         const uint64_t tile0 = (uint64_t)tile * 131072;
         const rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(in) + tile0, 0, 131072, 0x00020000);
         uint4 acc = make_uint4(0, 0, 0, 0);
+        uint4 held[8];
 #pragma unroll
         for (int r0 = 0; r0 < 8; r0 += DEPTH) {
           uint4 vv[DEPTH][4];
@@ -50,7 +51,9 @@ __global__ __launch_bounds__(256) void stream(const uint8_t* __restrict__ in, ui
             uint4 o;
             o.x = v[0].x ^ v[1].x ^ v[2].x ^ v[3].x; o.y = v[0].y ^ v[1].y ^ v[2].y ^ v[3].y;
             o.z = v[0].z ^ v[1].z ^ v[2].z ^ v[3].z; o.w = v[0].w ^ v[1].w ^ v[2].w ^ v[3].w;
-            if (WRITE_DIV == 4) {
+            if (WRITE_DIV == 4 && BURST) {
+                held[r] = o;
+            } else if (WRITE_DIV == 4) {
                 uint4* dst = out + (tile0 / 64) + (ILV ? (r * 4 + w) * 4096 : w * 32768 + r * 4096) / 64 + lane + SHIFT;
                 pol_store<NT_STORE>(o, dst);
             } else if (WRITE_DIV == 1) {
@@ -64,11 +67,16 @@ __global__ __launch_bounds__(256) void stream(const uint8_t* __restrict__ in, ui
             }
           }
         }
+        if (WRITE_DIV == 4 && BURST) {
+            // the whole tile's output of this wave leaves in one burst: 8 KiB contiguous
+#pragma unroll
+            for (int r = 0; r < 8; ++r) pol_store<NT_STORE>(held[r], out + (tile0 / 64) + (w * 32768 + r * 4096) / 64 + lane);
+        }
         if (WRITE_DIV == 0 && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) out[0] = acc;
     }
 }
 
-template <int WRITE_DIV, int LD_AUX, int NT_STORE, bool DYN, int DEPTH = 1, bool ILV = false, int SHIFT = 0>
+template <int WRITE_DIV, int LD_AUX, int NT_STORE, bool DYN, int DEPTH = 1, bool ILV = false, int SHIFT = 0, bool BURST = false>
 int run(const char* name, const uint8_t* in, uint4* out, uint64_t n, uint32_t* ticket, int bpc) {
     const uint32_t tiles = (uint32_t)(n / 131072);
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -76,7 +84,7 @@ int run(const char* name, const uint8_t* in, uint4* out, uint64_t n, uint32_t* t
     for (int rep = 0; rep < 6; ++rep) {
         CHECK(hipMemsetAsync(ticket, 0, 4));
         CHECK(hipEventRecord(e0));
-        hipLaunchKernelGGL((stream<WRITE_DIV, LD_AUX, NT_STORE, DYN, DEPTH, ILV, SHIFT>), dim3(256 * bpc), dim3(256), 0, 0, in, out, n, ticket, tiles);
+        hipLaunchKernelGGL((stream<WRITE_DIV, LD_AUX, NT_STORE, DYN, DEPTH, ILV, SHIFT, BURST>), dim3(256 * bpc), dim3(256), 0, 0, in, out, n, ticket, tiles);
         CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (rep > 0 && ms < best) best = ms;
     }
@@ -99,6 +107,8 @@ int main() {
     }
     {
         const int bpc = 4;
+        run<4, 2, 1, true, 2, false, 0, true>("BURST st nt: 8 KiB per wave after the tile's loads", in, out, n, ticket, bpc);
+        run<4, 2, 1, true, 4, false, 0, true>("BURST st nt, depth 4", in, out, n, ticket, bpc);
         run<4, 2, 1, true, 2, false, 0>("ALIGN st nt, 1-KiB wave stores line aligned", in, out, n, ticket, bpc);
         run<4, 2, 1, true, 2, false, 1>("ALIGN st nt, shifted by 16 B", in, out, n, ticket, bpc);
         run<4, 2, 1, true, 2, false, 2>("ALIGN st nt, shifted by 32 B", in, out, n, ticket, bpc);
