@@ -14,7 +14,11 @@ TAPE_BYTES = LAUNCH_BYTES // 32 * 8
 
 
 def main():
+    global LAUNCH_BYTES, TAPE_BYTES
     root, out = sys.argv[1], sys.argv[2]
+    workload = sys.argv[5] if len(sys.argv) > 5 else "64x31_noquote 8 GiB"
+    if len(sys.argv) > 4:  # other workloads: launch bytes and tape bytes per launch
+        LAUNCH_BYTES, TAPE_BYTES = int(sys.argv[3]), int(sys.argv[4])
     per_counter = collections.defaultdict(lambda: collections.defaultdict(float))
     name_seen = set()
     for path in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
@@ -30,7 +34,7 @@ def main():
     counters = {c: {"dispatches": len(v), "avg": sum(v.values()) / len(v)} for c, v in sorted(per_counter.items())}
     d = {"command": "rocprofv3 --pmc <one counter group per pass> --output-format csv -- python3 bench.py --steps 10 "
                     "--warmup 2 --no-extra --no-cpu-baseline",
-         "kernel": sorted(name_seen), "workload": "64x31_noquote 8 GiB", "counters": counters}
+         "kernel": sorted(name_seen), "workload": workload, "counters": counters}
     g = lambda c: counters[c]["avg"] if c in counters else None
     der = {}
     if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
