@@ -551,3 +551,37 @@ def test_more_entries_than_the_reference_u32_index(ctx, torch_cuda, pkg):
     r2 = ctx.stage1_index_device(dbuf.data_ptr(), 1 << 20, 2**45 + 5, 0, dtape.data_ptr(), S)
     assert r2.count == (1 << 20) // (width + 1)
     assert int(dtape[0]) == 2**45 + 5 + width and int(dtape[r2.count - 1]) == 2**45 + 5 + (r2.count - 1) * 5 + width
+
+
+@pytest.mark.parametrize("line_end", ["\n", "\r\n"])
+def test_end_to_end_against_python_csv_module(ctx, pkg, tmp_path, line_end):
+    # An independent parser as the judge of the whole chain: files written by Python's csv module
+    # (RFC 4180 quoting: fields with commas, quotes — doubled — and line breaks inside quotes) go
+    # through csv_simd::create -> seek_field; un-quoted, every field must equal what was written.
+    import csv
+    import io
+    rng = np.random.default_rng(4180)
+    pool = ["plain", "", "with,comma", 'say "hi"', "two\nlines", "cr\rlf\r\n inside", " padded ", "x" * 70, '"', ",",
+            "é世界", "a,b,\"c\"\n,d"]
+    n_fields = 7
+    rows = [[pool[i] for i in rng.integers(0, len(pool), size=n_fields)] for _ in range(5000)]
+    buf = io.StringIO()
+    w = csv.writer(buf, lineterminator=line_end, quoting=csv.QUOTE_MINIMAL)
+    w.writerow([f"col{i}" for i in range(n_fields)])
+    w.writerows(rows)
+    data = buf.getvalue().encode()
+    assert list(csv.reader(io.StringIO(buf.getvalue(), newline="")))[1:] == rows   # the csv module agrees with itself
+    p = tmp_path / "rfc4180.csv"
+    p.write_bytes(data)
+    t = ctx.create(str(p))
+    assert t.field_cnt == n_fields and t.record_cnt == len(rows) + 1
+    assert t.new_line == ("CRLF" if line_end == "\r\n" else "LF")
+    for r in list(range(0, len(rows), 37)) + [len(rows) - 1]:
+        for f in range(n_fields):
+            raw = t.seek_field(r, f).decode()
+            if raw[:1] == '"':
+                assert raw[-1] == '"'
+                raw = raw[1:-1].replace('""', '"')
+            assert raw == rows[r][f], (r, f)
+    # the whole record too
+    assert t.seek_record(0).decode().count(",") >= n_fields - 1
