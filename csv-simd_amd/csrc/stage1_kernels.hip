@@ -503,7 +503,15 @@ __device__ __forceinline__ void count_phase(rsrc_t rsrc, u32 lane, u32 w, const 
         // opaque: the eight read addresses (4 chunks x 2 images) are cheap to rebuild (one v_xad each) but,
         // hoisted out of the tile loop, they are what hipcc spills — and a scratch reload in here
         // waits for vmcnt(0), i.e. for the LDS-DMA prefetch of the next rounds (measured: -9 %)
-        asm volatile("" : "+v"(rslot));
+        if (DIALECT == 2) {
+            // the escape variant is short of registers by its third mask: there even `rslot` gets spilled,
+            // so it is rebuilt from the lane id (always live) behind the same kind of fence
+            u32 l = lane;
+            asm volatile("" : "+v"(l));
+            rslot = l * 4u + ((l >> 2) & 3u);
+        } else {
+            asm volatile("" : "+v"(rslot));
+        }
 #pragma unroll
         for (int k = 0; k < kRows; ++k) stripe[k] = stage[rslot ^ (u32)k];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
