@@ -585,3 +585,38 @@ def test_end_to_end_against_python_csv_module(ctx, pkg, tmp_path, line_end):
             assert raw == rows[r][f], (r, f)
     # the whole record too
     assert t.seek_record(0).decode().count(",") >= n_fields - 1
+
+
+def test_distinct_contexts_on_concurrent_host_threads(pkg, torch_cuda, oracle):
+    # include/csvsimd.h: "thread-safe for distinct contexts".  Four host threads, one context each,
+    # run the host-buffer entry point (private streams, staging pool) and the device entry point at
+    # the same time on the same GPU; every result must equal the oracle's.
+    import threading
+    torch = torch_cuda
+    rng = np.random.default_rng(99)
+    inputs = [random_csvish(rng, int(n), 0.03) for n in (3_000_001, 70_000_000, 1_234_567, 40_000_003)]
+    wants = [oracle.scalar_index(d)[0] for d in inputs]
+    errors = []
+
+    def worker(k):
+        try:
+            c = pkg.Context(0)
+            d, want = inputs[k], wants[k]
+            dbuf = torch.from_numpy(d.copy()).cuda()
+            dtape = torch.empty(want.size + 8, dtype=torch.int64, device="cuda:0")
+            for it in range(6):
+                got = c.read(d)
+                assert got[0] == 0 and np.array_equal(got[1:], want), (k, it, "host path")
+                r = c.stage1_index_device(dbuf.data_ptr(), d.size, 0, 0, dtape.data_ptr(), want.size + 8)
+                assert r.count == want.size, (k, it, "device path")
+                assert np.array_equal(dtape[: r.count].cpu().numpy().view(np.uint64), want), (k, it)
+            c.close()
+        except BaseException as e:  # noqa: BLE001 - reported by the main thread
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(len(inputs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
