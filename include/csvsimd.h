@@ -82,7 +82,9 @@ typedef struct csvsimd_shard_result {
  * (>= sizeof(csvsimd_shard_result), 16-byte aligned), valid once the stream has drained.  No
  * allocation and no synchronisation happens inside as long as the context scratch is large
  * enough for len (grow it up front with csvsimd_ctx_reserve), so the call may be captured
- * into a hipGraph.  Any dbuf alignment is accepted; 16-byte alignment is fastest. */
+ * into a hipGraph.  Any dbuf alignment is accepted; 128-byte alignment (any allocator's) is fastest,
+ * other alignments cost ~2 % (wave loads then straddle L2 lines).  dtape needs 8-byte alignment only:
+ * the kernel aligns its wave stores to 128-byte lines itself. */
 int csvsimd_ctx_reserve(csvsimd_ctx* ctx, uint64_t max_len);
 int csvsimd_stage1_index_device_async(csvsimd_ctx* ctx, const void* dbuf, uint64_t len,
                                       uint64_t base_off, uint32_t in_quote_in, void* dtape,
