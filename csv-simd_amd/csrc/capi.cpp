@@ -379,7 +379,19 @@ static int stage1_index_host_impl(csvsimd_ctx* ctx, const csvsimd_dialect* diale
     HIP_TRY(hipSetDevice(ctx->device));
     int rc = pipe_setup(ctx);
     if (rc != CSVSIMD_OK) return rc;
-    constexpr uint64_t kChunk = csvsimd_ctx::kChunk;
+    // chunk size: the slots hold up to 32 MiB; a mid-size file is cut into ~4 chunks (>= 4 MiB, a multiple
+    // of 1 MiB) so that staging, H2D, kernel and D2H of neighbouring chunks overlap inside it as well.
+    // Every chunk costs ~100 us of host-side launches and waits, so smaller is not better: measured
+    // (scripts/probe_latency.py) 32 MiB file 25 -> 32 GiB/s with 8-MiB chunks, but a 256 MiB file
+    // 45 -> 22 GiB/s with 4-MiB chunks.
+    uint64_t kChunk = csvsimd_ctx::kChunk;
+    if (const char* e = getenv("CSVSIMD_INGEST_CHUNK_MIB")) {
+        const uint64_t v = (uint64_t)atoi(e) << 20;
+        if (v >= (1ull << 20) && v <= csvsimd_ctx::kChunk) kChunk = v;
+    } else if (len < 4 * csvsimd_ctx::kChunk) {
+        const uint64_t target = ((len / 4 + (1ull << 20) - 1) >> 20) << 20;
+        kChunk = std::min<uint64_t>(csvsimd_ctx::kChunk, std::max<uint64_t>(4ull << 20, target));
+    }
     hipStream_t st = ctx->pipe_stream;
     const uint64_t nchunks = (len + kChunk - 1) / kChunk;
 

@@ -156,19 +156,21 @@ def test_escape_split_invariance(ctx, pkg, torch_cuda, oracle):
         assert (rb.in_quote_out, rb.escape_out) == (rw.in_quote_out, rw.escape_out)
 
 
-def test_escape_host_path_chains_chunks(ctx, pkg, oracle):
-    # csvsimd_stage1_index_dialect streams 32-MiB chunks: an escape run straddles the first boundary
+def test_escape_host_path_chains_chunks(ctx, pkg, oracle, monkeypatch):
+    # csvsimd_stage1_index_dialect streams the buffer in chunks (pinned here to 4 MiB): odd escape
+    # runs straddle the first two boundaries, the escape state must carry from chunk to chunk
+    monkeypatch.setenv("CSVSIMD_INGEST_CHUNK_MIB", "4")
     rng = np.random.default_rng(6)
-    n = (32 << 20) + 70000
+    n = (12 << 20) + 70000
     d = escapey(rng, n, 0.05)
-    edge = 32 << 20
-    d[edge - 4] = ord("a")
-    d[edge - 3: edge] = BS
-    d[edge] = ord(",")
+    for edge in (4 << 20, 8 << 20):
+        d[edge - 4] = ord("a")
+        d[edge - 3: edge] = BS
+        d[edge] = ord(",")
     got = ctx.read_dialect(d, pkg.Dialect(",", '"', "\\"))
     want, _, _ = oracle.dialect_index(d, escape=BS)
     assert got[0] == 0 and np.array_equal(got[1:], want)
-    assert not np.isin(np.uint64(edge), got)
+    assert not np.isin(np.array([4 << 20, 8 << 20], dtype=np.uint64), got).any()
 
 
 def test_dialect_argument_checks(ctx, pkg, torch_cuda):

@@ -300,10 +300,11 @@ def test_repeatability_stress(ctx, torch_cuda, pkg):
         assert (r.count, r.count_enter_outside, r.in_quote_out) == (S, S, 0), rep
 
 
-def test_host_ingest_pipeline_multi_chunk(ctx, pkg, oracle, tmp_path):
-    # csvsimd_stage1_index streams the file in 32-MiB chunks over a two-slot pipeline: quoted
-    # regions and tape bases must carry across chunk boundaries; a dense chunk takes the
-    # exact-capacity retry; csvsimd_create runs the same path from a file.
+def test_host_ingest_pipeline_multi_chunk(ctx, pkg, oracle, tmp_path, monkeypatch):
+    # csvsimd_stage1_index streams the file in chunks (pinned here to the 32-MiB maximum; smaller files
+    # use ~len/4) over a two-slot pipeline: quoted regions and tape bases must carry across chunk
+    # boundaries; a dense chunk takes the exact-capacity retry; csvsimd_create runs the same path from a file.
+    monkeypatch.setenv("CSVSIMD_INGEST_CHUNK_MIB", "32")
     rng = np.random.default_rng(4711)
     n = (32 << 20) * 2 + 12345                      # 3 chunks, ragged tail
     d = random_csvish(rng, n, 0.002)                # long quoted stretches cross the boundaries
@@ -320,7 +321,8 @@ def test_host_ingest_pipeline_multi_chunk(ctx, pkg, oracle, tmp_path):
     small = np.zeros(1000, dtype=np.uint64)
     rc, cnt, _ = ctx.read_into(d, small)
     assert rc == pkg.ERR_TAPE_CAPACITY and cnt == want.size and np.array_equal(small, want[:1000])
-    # from a file: a regular 3-column CSV of ~40 MiB
+    # from a file: a regular 3-column CSV of ~40 MiB, adaptive chunk size (about a quarter of the file)
+    monkeypatch.delenv("CSVSIMD_INGEST_CHUNK_MIB")
     rows = 1_500_000
     body = b"Name,Number,Done\n" + b"".join(b"abc%07d,%09d,\"y,n\"\n" % (i, i * 7) for i in range(rows))
     p = tmp_path / "big.csv"
