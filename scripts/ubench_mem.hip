@@ -107,6 +107,9 @@ int main() {
     }
     {
         const int bpc = 4;
+        run<4, 2, 1, true, 2, true, 0, true>("ILV reads (WG-contiguous rounds) + BURST wave-contiguous stores", in, out, n, ticket, bpc);
+        run<4, 2, 1, true, 4, true, 0, true>("ILV reads + BURST stores, depth 4", in, out, n, ticket, bpc);
+        run<0, 2, 0, true, 2, true>("ILV reads only", in, out, n, ticket, bpc);
         run<4, 2, 1, true, 2, false, 0, true>("BURST st nt: 8 KiB per wave after the tile's loads", in, out, n, ticket, bpc);
         run<4, 2, 1, true, 4, false, 0, true>("BURST st nt, depth 4", in, out, n, ticket, bpc);
         run<4, 2, 1, true, 2, false, 0>("ALIGN st nt, 1-KiB wave stores line aligned", in, out, n, ticket, bpc);
