@@ -123,17 +123,17 @@ def cpu_baseline(oracle, sb, sample_bytes):
     n = min(sb.n, sample_bytes)
     host = oracle.aligned_copy(sb.dbuf[:n].cpu().numpy())
     oracle.sse_read_growing_timed(host[: 1 << 24])  # warm the code path / page in
-    best, entries = None, 0
-    reps = 0
+    times, entries = [], 0
     t_total = 0.0
-    while reps < 3 or (t_total < 10.0 and reps < 12):
+    while len(times) < 3 or (t_total < 10.0 and len(times) < 64):   # ~10 s of CPU work
         entries, dt = oracle.sse_read_growing_timed(host)
-        best = dt if best is None else min(best, dt)
+        times.append(dt)
         t_total += dt
-        reps += 1
+    best, median = min(times), sorted(times)[len(times) // 2]
     return {"value": round(n / best / 2**30, 4), "unit": "GiB/s", "cores": 1, "kind": "port",
             "variant": "ref_sse_1t (SSE restatement of reference reader::read, growing Vec, 1 thread)",
-            "sample": f"first {n / 2**30:.2f} GiB of rank 0's shard, best of {reps} passes",
+            "sample": f"first {n / 2**30:.2f} GiB of rank 0's shard, best of {len(times)} passes "
+                      f"({t_total:.1f} s of CPU work; median {n / median / 2**30:.2f} GiB/s)",
             "entries": entries, "host_cpus": os.cpu_count()}
 
 
