@@ -109,6 +109,18 @@ def test_escape_random_densities(ctx, pkg, torch_cuda, oracle):
                     check(ctx, pkg, torch_cuda, oracle, d, dia, in_quote_in=int(rng.integers(0, 2)), misalign=mis)
 
 
+def test_escape_with_other_delimiters_and_without_quoting(ctx, pkg, torch_cuda, oracle):
+    rng = np.random.default_rng(33)
+    T = pkg.tile_bytes()
+    alphabet = np.frombuffer(b",;\t'\"\n\ra ^\\", dtype=np.uint8)
+    for dia in (pkg.Dialect(",", None, "\\"), pkg.Dialect(";", "'", "^"), pkg.Dialect("\t", '"', "\\", escape_in=1),
+                pkg.Dialect("^", None, ";")):
+        for n in (0, 1, 65, 4097, T + 1, 2 * T + 4321):
+            d = alphabet[rng.integers(0, alphabet.size, size=n)].astype(np.uint8)
+            for mis in (0, 13, 100):
+                check(ctx, pkg, torch_cuda, oracle, d, dia, in_quote_in=int(rng.integers(0, 2)), misalign=mis)
+
+
 def test_escape_runs_across_every_boundary(ctx, pkg, torch_cuda, oracle):
     # runs of escape bytes that end at / straddle stripe (64 B), round (4 KiB), wave-span (32 KiB)
     # and tile boundaries, including runs longer than one and two whole stripes
