@@ -37,7 +37,9 @@ extern "C" {
 #define CSVSIMD_ERR_TAPE_CAPACITY (-11) /* tape_cap too small; *tape_len holds the needed size */
 #define CSVSIMD_ERR_HIP (-12)           /* HIP runtime error: csvsimd_last_error() has the text */
 #define CSVSIMD_ERR_NO_DEVICE (-13)
-#define CSVSIMD_ERR_INTERNAL (-14) /* in-kernel look-back spin bound hit (should never happen) */
+#define CSVSIMD_ERR_INTERNAL (-14) /* in-kernel look-back spin bound hit (~1 s without progress of a
+                                      predecessor tile: never seen; conceivable only if the GPU is
+                                      preempted for that long by another process — retry) */
 #define CSVSIMD_ERR_RCCL (-15)     /* librccl missing or a collective failed */
 
 const char* csvsimd_strerror(int code);
