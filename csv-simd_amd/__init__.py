@@ -81,6 +81,8 @@ class Stitch(C.Structure):
         ("count", C.c_uint64),
         ("tape_index_base", C.c_uint64),
         ("total_entries", C.c_uint64),
+        ("error", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 
@@ -127,6 +129,12 @@ _PROTOTYPES = {
                                        C.POINTER(C.c_uint32)]),
     "csvsimd_stitch_shards": (C.c_int, [C.POINTER(ShardResult), C.c_uint32, C.c_uint32, C.c_uint32,
                                         C.POINTER(Stitch)]),
+    "csvsimd_stitch_shards_device_async": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                                     C.c_void_p]),
+    "csvsimd_stage1_reemit_device_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
+                                                     C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "csvsimd_stage1_kernel_name": (C.c_char_p, [C.c_int, C.POINTER(Dialect)]),
+    "csvsimd_build_has_probes": (C.c_uint32, []),
     "csvsimd_comm_unique_id": (C.c_int, [C.c_void_p]),
     "csvsimd_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "csvsimd_comm_destroy": (None, [C.c_void_p]),
@@ -234,6 +242,13 @@ class Context:
                                   tape_cap: int, d_result: int, stream: int = 0) -> None:
         _check(lib().csvsimd_stage1_index_device_async(self._h, dbuf, length, base_off, in_quote_in,
                                                        dtape or None, tape_cap, d_result, stream or None))
+
+    def stage1_reemit_device_async(self, dbuf: int, length: int, base_off: int, d_stitch: int, dtape: int,
+                                   tape_cap: int, d_result: int, stream: int = 0) -> None:
+        """Second launch of a sharded step: indexes the shard again as "entered inside a quoted string" iff the
+        DEVICE word d_stitch->in_quote_in is 1 when the kernel starts; otherwise it returns at once."""
+        _check(lib().csvsimd_stage1_reemit_device_async(self._h, dbuf, length, base_off, d_stitch, dtape or None,
+                                                        tape_cap, d_result, stream or None))
 
     def stage1_index_device_dialect_async(self, dialect: Dialect, dbuf: int, length: int, base_off: int,
                                           in_quote_in: int, dtape: int, tape_cap: int, d_result: int,
@@ -352,6 +367,21 @@ def stitch_shards(results: Sequence[ShardResult], rank: int, file_in_quote_in: i
     out = Stitch()
     _check(lib().csvsimd_stitch_shards(arr, len(results), rank, file_in_quote_in, C.byref(out)))
     return out
+
+
+def stitch_shards_device_async(d_results: int, n_shards: int, rank: int, file_in_quote_in: int, d_stitch: int,
+                               stream: int = 0) -> None:
+    """csvsimd_stitch_shards as a one-lane kernel: device records in, device csvsimd_stitch out."""
+    _check(lib().csvsimd_stitch_shards_device_async(d_results, n_shards, rank, file_in_quote_in, d_stitch,
+                                                    stream or None))
+
+
+def stage1_kernel_name(emit: bool = True, dialect: Optional[Dialect] = None) -> str:
+    return lib().csvsimd_stage1_kernel_name(1 if emit else 0, C.byref(dialect) if dialect is not None else None).decode()
+
+
+def build_has_probes() -> bool:
+    return bool(lib().csvsimd_build_has_probes())
 
 
 def boundaries(task_size: int, job_count: int) -> Optional[List[Tuple[int, int]]]:

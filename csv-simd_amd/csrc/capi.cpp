@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -121,6 +122,8 @@ struct csvsimd_ctx {
     int device = 0;
     void* scratch = nullptr;
     uint64_t scratch_bytes = 0;
+    hipStream_t last_stream = nullptr;  // stream of the most recent launch that used the scratch
+    bool launched = false;
     uint32_t max_blocks = 0;
     int n_cus = 0;
     csvsimd_shard_result* d_result = nullptr;  // for the synchronous entry points
@@ -170,7 +173,7 @@ int csvsimd_device_count(void) {
     return n;
 }
 
-uint32_t csvsimd_abi_version(void) { return 1; }
+uint32_t csvsimd_abi_version(void) { return 2; }
 uint32_t csvsimd_tile_bytes(void) { return CSVSIMD_TILE_BYTES; }
 
 int csvsimd_ctx_create(int device, csvsimd_ctx** out) {
@@ -228,12 +231,22 @@ int csvsimd_ctx_reserve(csvsimd_ctx* ctx, uint64_t max_len) {
     const uint64_t need = csvsimd::Stage1Launch::scratch_bytes_for(max_len);
     if (need <= ctx->scratch_bytes) return CSVSIMD_OK;
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipDeviceSynchronize());
+    // launches of one context are ordered with respect to each other (include/csvsimd.h), so waiting for
+    // the stream of the latest one covers every launch that may still use the old block — no device-wide
+    // synchronisation, other contexts keep running
+    if (ctx->launched && hipStreamSynchronize(ctx->last_stream) != hipSuccess) {
+        (void)hipGetLastError();  // the caller may have destroyed that stream already: wait for everything instead
+        HIP_TRY(hipDeviceSynchronize());
+    }
     if (ctx->scratch) HIP_TRY(hipFree(ctx->scratch));
     ctx->scratch = nullptr;
     ctx->scratch_bytes = 0;
     HIP_TRY(hipMalloc(&ctx->scratch, need));
+    // the only time the block is ever cleared: control words 0, every descriptor "not published"; from
+    // here on each launch leaves it ready for the next (stage1_kernels.hip: struct Control)
+    HIP_TRY(hipMemset(ctx->scratch, 0, need));
     ctx->scratch_bytes = need;
+    ctx->launched = false;
     return CSVSIMD_OK;
 }
 
@@ -249,9 +262,10 @@ static int dialect_check(const csvsimd_dialect* d) {
 
 static int stage1_async_impl(csvsimd_ctx* ctx, const csvsimd_dialect* dialect, const void* dbuf, uint64_t len,
                              uint64_t base_off, uint32_t in_quote_in, void* dtape, uint64_t tape_cap, void* d_result,
-                             void* hip_stream) {
+                             void* hip_stream, const uint32_t* d_state = nullptr) {
     if (!ctx || !d_result || (len && !dbuf) || (!dtape && tape_cap)) return CSVSIMD_ERR_INVALID_ARG;
-    if (len >= (1ull << 60)) return CSVSIMD_ERR_INVALID_ARG;
+    // a shard's entry count must fit the 39-bit field of a look-back word (288 GB of HBM is 2^38.1 bytes)
+    if (len >= (1ull << 39)) return CSVSIMD_ERR_INVALID_ARG;
     if (((uintptr_t)dtape & 7) || ((uintptr_t)d_result & 15)) return CSVSIMD_ERR_INVALID_ARG;
     if (dialect_check(dialect) != CSVSIMD_OK) return CSVSIMD_ERR_INVALID_ARG;
     if (csvsimd::Stage1Launch::scratch_bytes_for(len) > ctx->scratch_bytes) {
@@ -268,12 +282,15 @@ static int stage1_async_impl(csvsimd_ctx* ctx, const csvsimd_dialect* dialect, c
     L.d_result = (csvsimd_shard_result*)d_result;
     L.bind_scratch(ctx->scratch);
     L.max_blocks = ctx->max_blocks;
+    L.d_state = d_state;
     if (dialect) {
         L.delimiter = dialect->delimiter;
         L.quote = dialect->quote;
         L.escape = dialect->escape;
         L.escape_in = dialect->escape_in ? 1u : 0u;
     }
+    ctx->last_stream = (hipStream_t)hip_stream;
+    ctx->launched = true;
     HIP_TRY(csvsimd::launch_stage1(L, (hipStream_t)hip_stream));
     return CSVSIMD_OK;
 }
@@ -282,6 +299,24 @@ int csvsimd_stage1_index_device_async(csvsimd_ctx* ctx, const void* dbuf, uint64
                                       uint32_t in_quote_in, void* dtape, uint64_t tape_cap, void* d_result,
                                       void* hip_stream) {
     return stage1_async_impl(ctx, nullptr, dbuf, len, base_off, in_quote_in, dtape, tape_cap, d_result, hip_stream);
+}
+
+int csvsimd_stage1_reemit_device_async(csvsimd_ctx* ctx, const void* dbuf, uint64_t len, uint64_t base_off,
+                                       const void* d_stitch, void* dtape, uint64_t tape_cap, void* d_result,
+                                       void* hip_stream) {
+    if (!d_stitch || ((uintptr_t)d_stitch & 7)) return CSVSIMD_ERR_INVALID_ARG;
+    static_assert(offsetof(csvsimd_stitch, in_quote_in) == 0, "the re-emit launch reads the stitch record's first word");
+    return stage1_async_impl(ctx, nullptr, dbuf, len, base_off, 1, dtape, tape_cap, d_result, hip_stream,
+                             (const uint32_t*)d_stitch);
+}
+
+int csvsimd_stitch_shards_device_async(const void* d_results, uint32_t n_shards, uint32_t rank,
+                                       uint32_t file_in_quote_in, void* d_stitch, void* hip_stream) {
+    if (!d_results || !d_stitch || rank >= n_shards || ((uintptr_t)d_results & 7) || ((uintptr_t)d_stitch & 7))
+        return CSVSIMD_ERR_INVALID_ARG;
+    if (csvsimd_device_count() <= 0) return CSVSIMD_ERR_NO_DEVICE;
+    HIP_TRY(csvsimd::launch_stitch(d_results, n_shards, rank, file_in_quote_in, d_stitch, (hipStream_t)hip_stream));
+    return CSVSIMD_OK;
 }
 
 int csvsimd_dialect_init(csvsimd_dialect* d) {
@@ -350,7 +385,9 @@ static int pipe_setup(csvsimd_ctx* ctx) {
 }
 static int pipe_ensure_tape(csvsimd_ctx* ctx, int k, uint64_t entries) {
     if (ctx->d_tape_entries[k] >= entries) return CSVSIMD_OK;
-    HIP_TRY(hipDeviceSynchronize());
+    // the slot's device tape is written by kernels on pipe_stream and read by copies on out_stream
+    HIP_TRY(hipStreamSynchronize(ctx->pipe_stream));
+    HIP_TRY(hipStreamSynchronize(ctx->out_stream));
     if (ctx->d_tape[k]) HIP_TRY(hipFree(ctx->d_tape[k]));
     ctx->d_tape[k] = nullptr;
     ctx->d_tape_entries[k] = 0;
@@ -360,7 +397,7 @@ static int pipe_ensure_tape(csvsimd_ctx* ctx, int k, uint64_t entries) {
 }
 static int pipe_ensure_out(csvsimd_ctx* ctx, int k, uint64_t entries) {
     if (ctx->pin_out_entries[k] >= entries) return CSVSIMD_OK;
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipStreamSynchronize(ctx->out_stream));  // only D2H copies on out_stream touch the pinned slot
     if (ctx->pin_out[k]) HIP_TRY(hipHostFree(ctx->pin_out[k]));
     ctx->pin_out[k] = nullptr;
     ctx->pin_out_entries[k] = 0;
@@ -369,7 +406,26 @@ static int pipe_ensure_out(csvsimd_ctx* ctx, int k, uint64_t entries) {
     return CSVSIMD_OK;
 }
 
+static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* dialect, const uint8_t* buf, uint64_t len,
+                                  uint64_t* tape, uint64_t tape_cap, uint64_t* tape_len, uint32_t* in_quote_out);
+
 static int stage1_index_host_impl(csvsimd_ctx* ctx, const csvsimd_dialect* dialect, const uint8_t* buf, uint64_t len,
+                                  uint64_t* tape, uint64_t tape_cap, uint64_t* tape_len, uint32_t* in_quote_out) {
+    const int rc = stage1_index_host_body(ctx, dialect, buf, len, tape, tape_cap, tape_len, in_quote_out);
+    if (rc != CSVSIMD_OK && rc != CSVSIMD_ERR_TAPE_CAPACITY && ctx && ctx->pipe_ready) {
+        // an error exit in mid-pipeline leaves copies in flight on the pinned slots: drain the three
+        // streams so the next call (or the caller freeing `buf` / `tape`) cannot race them
+        const std::string keep = g_last_error;
+        (void)hipStreamSynchronize(ctx->in_stream);
+        (void)hipStreamSynchronize(ctx->pipe_stream);
+        (void)hipStreamSynchronize(ctx->out_stream);
+        (void)hipGetLastError();
+        g_last_error = keep;
+    }
+    return rc;
+}
+
+static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* dialect, const uint8_t* buf, uint64_t len,
                                   uint64_t* tape, uint64_t tape_cap, uint64_t* tape_len, uint32_t* in_quote_out) {
     if (!ctx || (len && !buf) || (!tape && tape_cap) || !tape_len) return CSVSIMD_ERR_INVALID_ARG;
     if (dialect_check(dialect) != CSVSIMD_OK) return CSVSIMD_ERR_INVALID_ARG;
@@ -448,7 +504,11 @@ static int stage1_index_host_impl(csvsimd_ctx* ctx, const csvsimd_dialect* diale
             rc = stage1_async_impl(ctx, dp, ctx->d_in[k], clen, off, inq, ctx->d_tape[k], ctx->d_tape_entries[k],
                                    ctx->d_res[k], st);
             if (rc != CSVSIMD_OK) return rc;
+            HIP_TRY(hipMemcpyAsync(&ctx->h_res[k], ctx->d_res[k], sizeof(csvsimd_shard_result), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
+            r = ctx->h_res[k];  // the second pass's own record: its error flag and count are what count
+            if (r.error) { g_last_error = "stage1 kernel: look-back spin bound hit"; return CSVSIMD_ERR_INTERNAL; }
+            if (r.count > ctx->d_tape_entries[k]) return CSVSIMD_ERR_INTERNAL;
         }
         if (tape && n < tape_cap) {
             const uint64_t ncopy = std::min<uint64_t>(tape_cap - n, r.count);
@@ -491,7 +551,7 @@ int csvsimd_stage1_index_dialect(csvsimd_ctx* ctx, const csvsimd_dialect* dialec
 int csvsimd_stitch_shards(const csvsimd_shard_result* results, uint32_t n_shards, uint32_t rank,
                           uint32_t file_in_quote_in, csvsimd_stitch* out) {
     if (!results || !out || rank >= n_shards) return CSVSIMD_ERR_INVALID_ARG;
-    uint32_t state = file_in_quote_in ? 1u : 0u;
+    uint32_t state = file_in_quote_in ? 1u : 0u, err = 0;
     uint64_t idx = 1;  // the sentinel occupies global index 0
     for (uint32_t i = 0; i < n_shards; ++i) {
         const uint64_t cnt = state ? results[i].count_enter_inside : results[i].count_enter_outside;
@@ -502,9 +562,12 @@ int csvsimd_stitch_shards(const csvsimd_shard_result* results, uint32_t n_shards
         }
         idx += cnt;
         state ^= results[i].quote_parity & 1u;
+        err |= results[i].error;
     }
     out->in_quote_final = state;
     out->total_entries = idx;
+    out->error = err ? 1u : 0u;
+    out->reserved = 0;
     return CSVSIMD_OK;
 }
 
@@ -545,11 +608,13 @@ int csvsimd_tape_create(const uint8_t* bytes, uint64_t len, const uint64_t* inde
 
 void csvsimd_tape_destroy(csvsimd_tape* t) { delete t; }
 
-uint32_t csvsimd_tape_field_cnt(const csvsimd_tape* t) { return t->tape.header.field_cnt; }
-uint32_t csvsimd_tape_record_cnt(const csvsimd_tape* t) { return t->tape.record_cnt_; }
-uint64_t csvsimd_tape_record_jump_size(const csvsimd_tape* t) { return t->tape.record_jump_size_; }
-uint32_t csvsimd_tape_record_offset(const csvsimd_tape* t) { return t->tape.header.record_offset; }
+// a NULL tape reads as an empty one (0 fields, 0 records) — never a crash across the FFI
+uint32_t csvsimd_tape_field_cnt(const csvsimd_tape* t) { return t ? t->tape.header.field_cnt : 0; }
+uint32_t csvsimd_tape_record_cnt(const csvsimd_tape* t) { return t ? t->tape.record_cnt_ : 0; }
+uint64_t csvsimd_tape_record_jump_size(const csvsimd_tape* t) { return t ? t->tape.record_jump_size_ : 0; }
+uint32_t csvsimd_tape_record_offset(const csvsimd_tape* t) { return t ? t->tape.header.record_offset : 0; }
 int csvsimd_tape_new_line(const csvsimd_tape* t) {
+    if (!t) return CSVSIMD_ERR_INVALID_ARG;
     return t->tape.header.new_line == csv_simd::NewLine::CRLF ? CSVSIMD_NEWLINE_CRLF : CSVSIMD_NEWLINE_LF;
 }
 
@@ -601,12 +666,12 @@ int csvsimd_tape_chunks(const csvsimd_tape* t, uint8_t num, csvsimd_chunk* out, 
 }
 
 const uint64_t* csvsimd_tape_index(const csvsimd_tape* t, uint64_t* index_len) {
-    if (index_len) *index_len = t->tape.index().len();
-    return t->tape.index().data;
+    if (index_len) *index_len = t ? t->tape.index().len() : 0;
+    return t ? t->tape.index().data : nullptr;
 }
 const uint8_t* csvsimd_tape_bytes(const csvsimd_tape* t, uint64_t* len) {
-    if (len) *len = t->tape.data_len();
-    return t->tape.data_bytes();
+    if (len) *len = t ? t->tape.data_len() : 0;
+    return t ? t->tape.data_bytes() : nullptr;
 }
 
 // csv_simd::create (src/lib.rs:61-74): open, mmap, Header::new, reader::read (GPU), tape
@@ -761,6 +826,25 @@ int csvsimd_selftest_device(int device) {
     return CSVSIMD_OK;
 }
 
+namespace {
+// owns a batch of timing events: destroyed on every exit path
+struct EventBatch {
+    std::vector<hipEvent_t> ev;
+    ~EventBatch() {
+        for (hipEvent_t e : ev)
+            if (e) (void)hipEventDestroy(e);
+    }
+    hipError_t create(size_t n) {
+        ev.assign(n, nullptr);
+        for (auto& e : ev) {
+            const hipError_t rc = hipEventCreate(&e);
+            if (rc != hipSuccess) return rc;
+        }
+        return hipSuccess;
+    }
+};
+}  // namespace
+
 int csvsimd_stage1_time_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len, void* dtape, uint64_t tape_cap,
                                void* d_result, void* hip_stream, int warmup, int iters, float* avg_ms) {
     if (!ctx || !avg_ms || iters <= 0 || iters > 4096 || !d_result || !len) return CSVSIMD_ERR_INVALID_ARG;
@@ -777,9 +861,15 @@ int csvsimd_stage1_time_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len,
     L.d_result = (csvsimd_shard_result*)d_result;
     L.bind_scratch(ctx->scratch);
     L.max_blocks = ctx->max_blocks;
-    if (const char* dbg = getenv("CSVSIMD_PROBE_MODE")) {  // development probes only (scripts/probe.py)
+#ifdef CSVSIMD_DEV_PROBES
+    // development builds only (libcsvsimd_probes.so for scripts/probe*.py): the product library has neither
+    // these hooks nor the kernel instantiations behind them
+    if (const char* dbg = getenv("CSVSIMD_PROBE_MODE")) {
         L.debug_mode = atoi(dbg);
-        if (const char* mb = getenv("CSVSIMD_PROBE_BLOCKS_PER_CU")) L.max_blocks = 256u * (uint32_t)atoi(mb);
+        if (const char* mb = getenv("CSVSIMD_PROBE_BLOCKS_PER_CU")) {
+            const int n = atoi(mb);
+            if (n >= 1 && n <= 16) L.max_blocks = (uint32_t)ctx->n_cus * (uint32_t)n;
+        }
     }
     if (const char* dia = getenv("CSVSIMD_PROBE_DIALECT")) {  // "delimiter,quote,escape" as decimal bytes
         unsigned d = ',', q = '"', e = 0;
@@ -789,39 +879,57 @@ int csvsimd_stage1_time_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len,
             L.escape = (uint8_t)e;
         }
     }
+    if (L.debug_mode == 8) HIP_TRY(hipMemsetAsync(L.scratch_prof, 0, 17 * 8, s));
+#endif
+    ctx->last_stream = s;
+    ctx->launched = true;
     for (int i = 0; i < warmup; ++i) HIP_TRY(csvsimd::launch_stage1(L, s));
-    // one event pair per launch, recorded on the launch stream right around the stage-1 kernel
-    // (the memsets before it and the 1-wave finalize after it are outside the pair)
-    std::vector<hipEvent_t> ev(2 * (size_t)iters);
-    for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+    // one event pair per launch, recorded on the launch stream right around the stage-1 kernel (a launch
+    // IS that one kernel)
+    EventBatch eb;
+    HIP_TRY(eb.create(2 * (size_t)iters));
     for (int i = 0; i < iters; ++i) {
-        L.ev_begin = ev[2 * i];
-        L.ev_end = ev[2 * i + 1];
+        L.ev_begin = eb.ev[2 * i];
+        L.ev_end = eb.ev[2 * i + 1];
         HIP_TRY(csvsimd::launch_stage1(L, s));
     }
     HIP_TRY(hipStreamSynchronize(s));
     double total = 0;
     for (int i = 0; i < iters; ++i) {
         float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms, eb.ev[2 * i], eb.ev[2 * i + 1]));
         total += ms;
     }
-    for (auto& e : ev) (void)hipEventDestroy(e);
     *avg_ms = (float)(total / iters);
-    if (L.debug_mode == 8) {  // development probe: print the per-phase stamps of the last launch
-        uint64_t h[32];
-        HIP_TRY(hipMemcpy(h, (char*)ctx->scratch + 16, sizeof h, hipMemcpyDeviceToHost));
-        const double nwg = h[24] ? (double)h[24] : 1.0;
-        fprintf(stderr, "PROF grid %u workgroups launched, %llu drew at least one tile (normalising by the latter)\n",
-                (unsigned)std::min<uint64_t>(L.max_blocks, (len + CSVSIMD_TILE_BYTES - 1) / CSVSIMD_TILE_BYTES),
-                (unsigned long long)h[24]);
+#ifdef CSVSIMD_DEV_PROBES
+    if (L.debug_mode == 8) {  // print the per-phase stamps (summed over warm-up + timed launches)
+        uint64_t h[17];
+        HIP_TRY(hipMemcpy(h, L.scratch_prof, sizeof h, hipMemcpyDeviceToHost));
+        const double nwg = h[16] ? (double)h[16] : 1.0;
+        fprintf(stderr, "PROF %llu workgroup runs over %d launches (normalising by the former)\n",
+                (unsigned long long)h[16], warmup + iters);
         static const char* names[6] = {"ticket+barrier T", "count phase", "barrier A", "publish+resolve", "barrier B", "emit"};
         for (int wv = 0; wv < 2; ++wv)
             for (int k = 0; k < 6; ++k)
                 fprintf(stderr, "PROF wave%d %-16s %.2f us per workgroup (sum over its tiles)\n", wv, names[k],
-                        (double)h[8 + wv * 8 + k] / nwg / 100.0);
+                        (double)h[wv * 8 + k] / nwg / 100.0);
     }
+#endif
     return CSVSIMD_OK;
+}
+
+const char* csvsimd_stage1_kernel_name(int emit, const csvsimd_dialect* dialect) {
+    int d = 0;
+    if (dialect) d = dialect->escape ? 2 : (dialect->delimiter != ',' || dialect->quote != '"') ? 1 : 0;
+    return csvsimd::stage1_kernel_name(emit != 0, d);
+}
+
+uint32_t csvsimd_build_has_probes(void) {
+#ifdef CSVSIMD_DEV_PROBES
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 int csvsimd_hbm_probe_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len, void* dout, int write_div,
@@ -830,23 +938,22 @@ int csvsimd_hbm_probe_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len, v
     if (write_div != 0 && write_div != 4) return CSVSIMD_ERR_INVALID_ARG;
     if (!dout || ((uintptr_t)dout & 15) || len < 131072) return CSVSIMD_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)hip_stream;
-    int rc = csvsimd_ctx_reserve(ctx, 1 << 20);  // the ticket lives in the context scratch
+    int rc = csvsimd_ctx_reserve(ctx, 1 << 20);  // the probe's ticket pair lives in the context's control block
+    ctx->last_stream = s;
+    ctx->launched = true;
     if (rc != CSVSIMD_OK) return rc;
     const uint32_t blocks = (uint32_t)ctx->n_cus * 4u;  // 16 waves per CU, like the stage-1 kernel
     for (int i = 0; i < warmup; ++i)
-        HIP_TRY(csvsimd::launch_hbm_probe(dbuf, len, dout, write_div, (uint32_t*)ctx->scratch, blocks, s));
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, s));
+        HIP_TRY(csvsimd::launch_hbm_probe(dbuf, len, dout, write_div, ctx->scratch, blocks, s));
+    EventBatch eb;
+    HIP_TRY(eb.create(2));
+    HIP_TRY(hipEventRecord(eb.ev[0], s));
     for (int i = 0; i < iters; ++i)
-        HIP_TRY(csvsimd::launch_hbm_probe(dbuf, len, dout, write_div, (uint32_t*)ctx->scratch, blocks, s));
-    HIP_TRY(hipEventRecord(e1, s));
-    HIP_TRY(hipEventSynchronize(e1));
+        HIP_TRY(csvsimd::launch_hbm_probe(dbuf, len, dout, write_div, ctx->scratch, blocks, s));
+    HIP_TRY(hipEventRecord(eb.ev[1], s));
+    HIP_TRY(hipEventSynchronize(eb.ev[1]));
     float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    HIP_TRY(hipEventElapsedTime(&ms, eb.ev[0], eb.ev[1]));
     *avg_ms = ms / (float)iters;
     return CSVSIMD_OK;
 }

@@ -4,7 +4,8 @@
 // relative to the reference (single-threaded; its README.md:24 lists "splitting work without first
 // knowing record breaks" as a TODO): the two values the reference carries between 64-byte blocks
 // (`inside_str`, `array_idx`, src/reader.rs:217-218) are carried between GPUs by ONE all-gather of
-// the 64-byte csvsimd_shard_result per rank, then csvsimd_stitch_shards.
+// the 64-byte csvsimd_shard_result per rank, then the stitch on the device (stage1_kernels.hip:
+// stitch_kernel; csvsimd_stitch_shards is its host twin).
 //
 // RCCL is resolved at run time (dlopen): libcsvsimd_hip.so itself has no link-time dependency on it,
 // and inside a PyTorch process it binds to the librccl that torch already loaded.
@@ -60,9 +61,13 @@ RcclApi& rccl() {
 struct csvsimd_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1, device = 0;
-    csvsimd_shard_result* d_mine = nullptr;  // device: this rank's record
+    csvsimd_shard_result* d_mine = nullptr;  // device: this rank's record (speculative, then final)
     csvsimd_shard_result* d_all = nullptr;   // device: world records, rank order
-    csvsimd_shard_result* h_all = nullptr;   // pinned host copy
+    csvsimd_stitch* d_stitch = nullptr;      // device: this rank's stitch (written by stitch_kernel)
+    // pinned host block: [0] = final record of this rank, [1] = a record with only the error flag set
+    // (what a rank whose local launch failed contributes to the all-gather), then the stitch
+    csvsimd_shard_result* h_rec = nullptr;
+    csvsimd_stitch* h_stitch = nullptr;
 };
 
 extern "C" {
@@ -94,11 +99,15 @@ int csvsimd_comm_create(const uint8_t id[CSVSIMD_COMM_ID_BYTES], int rank, int w
     bool ok = api.CommInitRank(&c->comm, world, u, rank) == ncclSuccess;
     ok = ok && hipMalloc((void**)&c->d_mine, sizeof(csvsimd_shard_result)) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->d_all, sizeof(csvsimd_shard_result) * (size_t)world) == hipSuccess;
-    ok = ok && hipHostMalloc((void**)&c->h_all, sizeof(csvsimd_shard_result) * (size_t)world, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->d_stitch, sizeof(csvsimd_stitch)) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&c->h_rec, 2 * sizeof(csvsimd_shard_result), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&c->h_stitch, sizeof(csvsimd_stitch), hipHostMallocDefault) == hipSuccess;
     if (!ok) {
         csvsimd_comm_destroy(c);
         return CSVSIMD_ERR_RCCL;
     }
+    memset(c->h_rec, 0, 2 * sizeof(csvsimd_shard_result));
+    c->h_rec[1].error = 1;
     *out = c;
     return CSVSIMD_OK;
 }
@@ -109,35 +118,48 @@ void csvsimd_comm_destroy(csvsimd_comm* c) {
     if (c->comm) (void)rccl().CommDestroy(c->comm);
     if (c->d_mine) (void)hipFree(c->d_mine);
     if (c->d_all) (void)hipFree(c->d_all);
-    if (c->h_all) (void)hipHostFree(c->h_all);
+    if (c->d_stitch) (void)hipFree(c->d_stitch);
+    if (c->h_rec) (void)hipHostFree(c->h_rec);
+    if (c->h_stitch) (void)hipHostFree(c->h_stitch);
     delete c;
 }
 
-// One sharded step for this rank: speculative pass (entered outside a string) -> all-gather of the
-// result records, device to device -> one copy to the host (the step's only synchronisation) ->
-// stitch -> re-emit only if this shard really starts inside a quoted string.
+// One sharded step for this rank, entirely stream-ordered on the device:
+//   speculative pass (entered outside a string) -> ONE all-gather of the 64-byte result records over
+//   xGMI -> stitch kernel (one lane: this rank's entering state, tape index base, totals, in device
+//   memory) -> re-emit launch that reads the entering state from device memory and returns at once
+//   unless it is 1 -> the final record and the stitch travel to the host; ONE synchronisation at the
+//   very end.  Nothing in between waits for the host, so the whole step can overlap the next one's
+//   speculative pass or be captured into a hipGraph.
+// Every rank reaches the collective whatever happens locally: arguments are checked and the scratch
+// is reserved before anything is enqueued, and a rank whose own launch fails contributes a record
+// with the error flag set, so all ranks return an error instead of hanging in the all-gather.
 int csvsimd_stage1_index_sharded(csvsimd_ctx* ctx, csvsimd_comm* c, const void* dbuf, uint64_t len, uint64_t base_off,
                                  uint32_t file_in_quote_in, void* dtape, uint64_t tape_cap,
                                  csvsimd_shard_result* result, csvsimd_stitch* stitch, void* hip_stream) {
     if (!ctx || !c || !result || !stitch) return CSVSIMD_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)hip_stream;
-    int rc = csvsimd_stage1_index_device_async(ctx, dbuf, len, base_off, 0, dtape, tape_cap, c->d_mine, st);
-    if (rc != CSVSIMD_OK) return rc;
+    int local = csvsimd_ctx_reserve(ctx, len);  // may allocate: never inside the stream-ordered part
+    if (local == CSVSIMD_OK)
+        local = csvsimd_stage1_index_device_async(ctx, dbuf, len, base_off, 0, dtape, tape_cap, c->d_mine, st);
+    if (local != CSVSIMD_OK &&
+        hipMemcpyAsync(c->d_mine, &c->h_rec[1], sizeof(csvsimd_shard_result), hipMemcpyHostToDevice, st) != hipSuccess)
+        return CSVSIMD_ERR_HIP;  // cannot even tell the peers: nothing more to be done here
     if (rccl().AllGather(c->d_mine, c->d_all, sizeof(csvsimd_shard_result), ncclUint8, c->comm, st) != ncclSuccess)
         return CSVSIMD_ERR_RCCL;
-    if (hipMemcpyAsync(c->h_all, c->d_all, sizeof(csvsimd_shard_result) * (size_t)c->world, hipMemcpyDeviceToHost, st) !=
-            hipSuccess ||
+    int rc = csvsimd_stitch_shards_device_async(c->d_all, (uint32_t)c->world, (uint32_t)c->rank, file_in_quote_in,
+                                                c->d_stitch, st);
+    if (rc == CSVSIMD_OK && local == CSVSIMD_OK)
+        rc = csvsimd_stage1_reemit_device_async(ctx, dbuf, len, base_off, c->d_stitch, dtape, tape_cap, c->d_mine, st);
+    if (hipMemcpyAsync(&c->h_rec[0], c->d_mine, sizeof(csvsimd_shard_result), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(c->h_stitch, c->d_stitch, sizeof(csvsimd_stitch), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess)
         return CSVSIMD_ERR_HIP;
-    for (int i = 0; i < c->world; ++i)
-        if (c->h_all[i].error) return CSVSIMD_ERR_INTERNAL;
-    rc = csvsimd_stitch_shards(c->h_all, (uint32_t)c->world, (uint32_t)c->rank, file_in_quote_in, stitch);
+    if (local != CSVSIMD_OK) return local;
     if (rc != CSVSIMD_OK) return rc;
-    *result = c->h_all[c->rank];
-    if (stitch->in_quote_in) {  // the speculation was wrong for this shard: emit again, for real
-        rc = csvsimd_stage1_index_device(ctx, dbuf, len, base_off, 1, dtape, tape_cap, result, st);
-        if (rc != CSVSIMD_OK && rc != CSVSIMD_ERR_TAPE_CAPACITY) return rc;
-    }
+    *result = c->h_rec[0];
+    *stitch = *c->h_stitch;
+    if (stitch->error || result->error) return CSVSIMD_ERR_INTERNAL;  // some rank's pass failed: no rank has a tape
     if (dtape && result->count > tape_cap) return CSVSIMD_ERR_TAPE_CAPACITY;
     return CSVSIMD_OK;
 }

@@ -22,10 +22,12 @@
 
 namespace csvsimd {
 
-// scratch block layout (one hipMemsetAsync zeroes the used prefix before every launch):
-//   [0, 16)            ticket counter (u32) + padding
-//   [16, 16 + 512)     64 sharded u64 counters: total comma/CR/LF bytes
-//   [528, ...)         one u64 look-back descriptor per tile
+// scratch block layout (zeroed ONCE, when it is allocated; every launch leaves it ready for the next):
+//   [0, 64)            control block (stage1_kernels.hip: struct Control): ticket, epoch, done/total, ...
+//   [64, 528)          development builds only: per-phase timing slots
+//   [528, ...)         one u64 look-back descriptor per tile, tagged with the launch epoch
+#define CSVSIMD_SCRATCH_CTL_BYTES 64
+#define CSVSIMD_SCRATCH_DESC_OFFSET 528
 struct Stage1Launch {
     const void* dbuf;
     uint64_t len;
@@ -35,13 +37,14 @@ struct Stage1Launch {
     uint64_t tape_cap;
     csvsimd_shard_result* d_result;
     void* scratch_base;
-    uint32_t* scratch_ticket;
-    uint64_t* scratch_tot;
     uint64_t* scratch_desc;
+    uint64_t* scratch_prof;
     uint32_t max_blocks;
+    // sharded re-emit: device word with the shard's true entering state; the launch is a no-op unless it is 1
+    const uint32_t* d_state = nullptr;
     // optional: recorded immediately around the stage-1 kernel itself (bench roofline leg)
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-    int debug_mode = 0;  // development probes (see stage1_kernel's DBG); product paths leave it 0
+    int debug_mode = 0;  // development probes (-DCSVSIMD_DEV_PROBES builds only; see stage1_kernel's DBG)
     // dialect extension (csvsimd_dialect): the defaults are the reference's hard-wired dialect
     uint8_t delimiter = ',', quote = '"', escape = 0;
     uint32_t escape_in = 0;
@@ -49,16 +52,12 @@ struct Stage1Launch {
     static uint64_t scratch_bytes_for(uint64_t len) {
         // + 1 tile: an unaligned dbuf shifts the data by up to 127 bytes
         const uint64_t tiles = (len + 127 + CSVSIMD_TILE_BYTES - 1) / CSVSIMD_TILE_BYTES + 1;
-        return 528 + 8 * tiles + 16;
-    }
-    uint64_t scratch_zero_bytes(uint32_t num_tiles) const {
-        return (528 + 8 * (uint64_t)num_tiles + 15) & ~15ull;
+        return CSVSIMD_SCRATCH_DESC_OFFSET + 8 * tiles + 16;
     }
     void bind_scratch(void* base) {
         scratch_base = base;
-        scratch_ticket = reinterpret_cast<uint32_t*>(base);
-        scratch_tot = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(base) + 16);
-        scratch_desc = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(base) + 528);
+        scratch_prof = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(base) + CSVSIMD_SCRATCH_CTL_BYTES);
+        scratch_desc = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(base) + CSVSIMD_SCRATCH_DESC_OFFSET);
     }
 };
 
@@ -68,8 +67,12 @@ hipError_t launch_synth(void* dbuf, uint64_t file_off, uint64_t len, uint32_t co
 hipError_t launch_checksum(const void* dtape, uint64_t n, uint64_t first_index, void* d_out,
                            hipStream_t stream);
 hipError_t launch_selftest(uint32_t* d_out, hipStream_t stream);
-hipError_t launch_hbm_probe(const void* din, uint64_t len, void* dout, int write_div, uint32_t* ticket,
+hipError_t launch_hbm_probe(const void* din, uint64_t len, void* dout, int write_div, void* scratch_base,
                             uint32_t blocks, hipStream_t stream);
+// csvsimd_stitch_shards on the device (one wave), so the sharded step needs no host round trip
+hipError_t launch_stitch(const void* d_results, uint32_t n_shards, uint32_t rank, uint32_t file_in_quote_in,
+                         void* d_stitch, hipStream_t stream);
+const char* stage1_kernel_name(bool emit, int dialect);
 hipError_t launch_field_spans(const void* dindex, uint64_t row_size, uint32_t field_idx, uint32_t fields,
                               uint64_t first_record, uint64_t n_records, void* d_begin, void* d_end,
                               hipStream_t stream);

@@ -56,24 +56,37 @@ static constexpr int kCompCap = CSVSIMD_COMP_CAP;
 #ifndef CSVSIMD_STORE_ALIGN
 #define CSVSIMD_STORE_ALIGN 128
 #endif
-static constexpr int kStoreAlignEntries = CSVSIMD_STORE_ALIGN / 8;  // tape entries per aligned store unit                   // u16 entries per wave compaction window (aliases the stage image)
+static constexpr int kStoreAlignEntries = CSVSIMD_STORE_ALIGN / 8;  // tape entries per aligned store unit
 // every input byte is read exactly once and every tape byte written exactly once: non-temporal
 // on both sides (measured on the same traffic mix: +11 % over default-policy loads and stores)
 static constexpr int kLoadAux = 2;                      // buffer-load cache policy bits: nt
 
 static_assert(kTileBytes == CSVSIMD_TILE_BYTES, "tile geometry must match the host header");
 
-// descriptor word = two 32-bit halves, EACH tagged with the 2-bit status in its top bits:
-//   lo = status << 30 | x[29:0]     hi = status << 30 | x[59:30]
-//   aggregate  (status 1): x = P | A << 1 | B << 25          (A, B < 2^24)
-//   inclusive  (status 2): x = state | running_count << 1    (count < 2^59)
-// A word is valid only if both halves carry the same status.  Measured on MI355X: a 64-bit sc1
-// load that races with the aggregate -> inclusive rewrite of the same word can return one half of
-// each (observed as "status = aggregate, payload = an inclusive count", ~1 in 10^5 polls once the
-// look-back polls words while they are being rewritten); the duplicated tag turns that into a
-// harmless "not published yet".
+// descriptor word = two 32-bit halves, EACH tagged with the 2-bit status and the launch epoch:
+//   lo = status << 30 | epoch << 20 | x[19:0]     hi = status << 30 | epoch << 20 | x[39:20]
+//   aggregate  (status 1): x = P | A << 1 | B << 20          (A, B <= kTileBytes < 2^19)
+//   inclusive  (status 2): x = state | running_count << 1    (count < 2^39)
+// A word is valid only if both halves carry the same status AND the epoch of the running launch.
+// Measured on MI355X: a 64-bit sc1 load that races with the aggregate -> inclusive rewrite of the
+// same word can return one half of each (observed as "status = aggregate, payload = an inclusive
+// count", ~1 in 10^5 polls once the look-back polls words while they are being rewritten); the
+// duplicated tag turns that into a harmless "not published yet".
+// The epoch is what replaces the per-launch zeroing of the descriptor array (round 1: a separate
+// zero_kernel, 3.9 us + a kernel boundary): words left behind by earlier launches carry another
+// epoch and read as "not published".  The epoch lives in device memory (control block) and is
+// advanced by the last workgroup of every launch, so a captured hipGraph replays correctly; when
+// it wraps (every 1024 launches) that workgroup zeroes the words used since the last wrap.
 static constexpr u32 kStatusAgg = 1u;
 static constexpr u32 kStatusInc = 2u;
+static constexpr int kEpochBits = 10;
+static constexpr int kHalfBits = 30 - kEpochBits;  // payload bits per 32-bit half
+static constexpr u32 kHalfMask = (1u << kHalfBits) - 1u;
+static constexpr u32 kEpochMask = (1u << kEpochBits) - 1u;
+static constexpr int kAggShiftB = kHalfBits;  // B sits in the high half
+static_assert(kSpanBytes <= 65536, "the compaction window holds span-relative offsets as u16");
+static_assert(kTileBytes < (1 << (kHalfBits - 1)), "tile aggregates A and B must fit their descriptor fields");
+static_assert(kWaves % 4 == 0 && kRows == 4, "the dispatcher reserves ceil(waves / 4) slots on every SIMD; rows are dwordx4 wave loads");
 static constexpr uint32_t kSpinLimit = 1u << 20;  // bounded spins: a protocol bug must end the kernel, not hang the GPU
 
 
@@ -255,16 +268,18 @@ __device__ __forceinline__ Desc wave_compose_ordered(Desc f, u32 lane, u32 m) {
 // single-pass look-back (wave 0 of the workgroup).  Returns entering state and tape base of
 // `tile`, publishes this tile's aggregate and inclusive words.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ u64 encode_desc(u32 status, u64 x) {
-    const u32 lo = (status << 30) | (u32)(x & 0x3fffffffu);
-    const u32 hi = (status << 30) | (u32)((x >> 30) & 0x3fffffffu);
+__device__ __forceinline__ u64 encode_desc(u32 status, u32 epoch, u64 x) {
+    const u32 tag = (status << 30) | (epoch << kHalfBits);
+    const u32 lo = tag | ((u32)x & kHalfMask);
+    const u32 hi = tag | ((u32)(x >> kHalfBits) & kHalfMask);
     return ((u64)hi << 32) | lo;
 }
-// status (0 = not published or torn) and 60-bit payload
-__device__ __forceinline__ u32 decode_desc(u64 d, u64& x) {
+// status (0 = not published, torn, or left behind by an earlier launch) and 40-bit payload
+__device__ __forceinline__ u32 decode_desc(u64 d, u32 epoch, u64& x) {
     const u32 lo = (u32)d, hi = (u32)(d >> 32);
-    x = (u64)(lo & 0x3fffffffu) | ((u64)(hi & 0x3fffffffu) << 30);
-    return (lo >> 30) == (hi >> 30) ? (lo >> 30) : 0u;
+    x = (u64)(lo & kHalfMask) | ((u64)(hi & kHalfMask) << kHalfBits);
+    const u32 tag_lo = lo >> kHalfBits, tag_hi = hi >> kHalfBits;  // status : epoch
+    return (tag_lo == tag_hi && (tag_lo & kEpochMask) == epoch) ? (lo >> 30) : 0u;
 }
 __device__ __forceinline__ void store_desc(u64* p, u64 v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -273,16 +288,17 @@ __device__ __forceinline__ u64 load_desc(const u64* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ __forceinline__ void publish_aggregate(u64* desc, u32 tile, Desc agg) {
-    store_desc(desc + tile, encode_desc(kStatusAgg, (u64)agg.p | ((u64)agg.a << 1) | ((u64)agg.b << 25)));
+__device__ __forceinline__ void publish_aggregate(u64* desc, u32 tile, u32 epoch, Desc agg) {
+    store_desc(desc + tile,
+               encode_desc(kStatusAgg, epoch, (u64)agg.p | ((u64)agg.a << 1) | ((u64)agg.b << kAggShiftB)));
 }
 
 // Resolves the entering state and tape base of `tile` (whose aggregate is already published) and
 // publishes its inclusive word.  Whole wave; every poll looks at 256 predecessors (4 per lane):
 // on MI355X a cross-XCD poll costs 1-2 us while tiles complete every ~30 ns chip-wide, so the
 // nearest inclusive word is routinely > 64 tiles back.
-__device__ __forceinline__ void resolve(u64* desc, u32 tile, Desc agg, u32 in_quote_in, u32 lane, u32& pin_out,
-                                        u64& base_out, u32& err) {
+__device__ __forceinline__ void resolve(u64* desc, u32 tile, u32 epoch, Desc agg, u32 in_quote_in, u32 lane,
+                                        u32& pin_out, u64& base_out, u32& err) {
     u32 pin = in_quote_in;
     u64 base = 0;
     // acc = composition of the tiles in (hi, tile): function of the state entering tile hi+1
@@ -297,7 +313,7 @@ __device__ __forceinline__ void resolve(u64* desc, u32 tile, Desc agg, u32 in_qu
     if (tile != 0) {
         for (;;) {
             u64 x;
-            const u32 st = decode_desc(load_desc(desc + (tile - 1)), x);
+            const u32 st = decode_desc(load_desc(desc + (tile - 1)), epoch, x);
             if (__builtin_amdgcn_readfirstlane((int)st) != 0) break;
             __builtin_amdgcn_s_sleep(16);
             if (++spins > kSpinLimit) { err = 1; break; }
@@ -311,12 +327,12 @@ __device__ __forceinline__ void resolve(u64* desc, u32 tile, Desc agg, u32 in_qu
         for (int i = 3; i >= 0; --i) {
             const int64_t j = hi - (int64_t)(4 * lane + i);
             // virtual tile -1 = inclusive (in_quote_in, 0): the shard's entering state
-            d[i] = encode_desc(kStatusInc, (u64)in_quote_in);
+            d[i] = encode_desc(kStatusInc, epoch, (u64)in_quote_in);
             if (j >= 0) d[i] = load_desc(desc + j);
         }
 #pragma unroll
         for (int i = 3; i >= 0; --i) {
-            const u32 status = decode_desc(d[i], x[i]);
+            const u32 status = decode_desc(d[i], epoch, x[i]);
             if (status == 0) linv = (u32)i;
             if (status == kStatusInc) linc = (u32)i;
         }
@@ -339,8 +355,8 @@ __device__ __forceinline__ void resolve(u64* desc, u32 tile, Desc agg, u32 in_qu
         for (int i = 3; i >= 0; --i) {
             Desc g;
             g.p = (u32)x[i] & 1u;
-            g.a = (u32)(x[i] >> 1) & 0xffffffu;
-            g.b = (u32)(x[i] >> 25) & 0xffffffu;
+            g.a = (u32)(x[i] >> 1) & (kHalfMask >> 1);
+            g.b = (u32)(x[i] >> kAggShiftB) & kHalfMask;
             if (4 * lane + (u32)i >= limit) { g.p = 0; g.a = 0; g.b = 0; }
             f = compose(f, g);
         }
@@ -378,7 +394,7 @@ __device__ __forceinline__ void resolve(u64* desc, u32 tile, Desc agg, u32 in_qu
     }
     const u32 state_out = pin ^ agg.p;
     const u64 count_out = base + (pin ? agg.b : agg.a);
-    if (lane == 0) store_desc(desc + tile, encode_desc(kStatusInc, (u64)state_out | (count_out << 1)));
+    if (lane == 0) store_desc(desc + tile, encode_desc(kStatusInc, epoch, (u64)state_out | (count_out << 1)));
     pin_out = pin;
     base_out = base;
 }
@@ -503,14 +519,12 @@ __device__ __forceinline__ void count_phase(rsrc_t rsrc, u32 lane, u32 w, const 
         // opaque: the eight read addresses (4 chunks x 2 images) are cheap to rebuild (one v_xad each) but,
         // hoisted out of the tile loop, they are what hipcc spills — and a scratch reload in here
         // waits for vmcnt(0), i.e. for the LDS-DMA prefetch of the next rounds (measured: -9 %)
-        if (DIALECT == 2) {
-            // the escape variant is short of registers by its third mask: there even `rslot` gets spilled,
-            // so it is rebuilt from the lane id (always live) behind the same kind of fence
+        // (round 2: the slot index itself is rebuilt from the lane id — always live — in every variant: kept
+        // across the tile loop it was the next value to be spilled, with the reload landing right here)
+        {
             u32 l = lane;
             asm volatile("" : "+v"(l));
             rslot = l * 4u + ((l >> 2) & 3u);
-        } else {
-            asm volatile("" : "+v"(rslot));
         }
 #pragma unroll
         for (int k = 0; k < kRows; ++k) stripe[k] = stage[rslot ^ (u32)k];
@@ -577,6 +591,20 @@ __device__ __forceinline__ void count_phase(rsrc_t rsrc, u32 lane, u32 w, const 
     }
 }
 
+// Control block at the head of the context scratch (stage1_kernels.h).  Zeroed once when the scratch
+// is allocated; from then on every launch leaves it ready for the next one (the last workgroup to
+// finish resets ticket / done_tot / err and advances the epoch), so a launch is ONE kernel: no
+// memset before it, no reduction kernel after it, and a captured graph replays correctly.
+struct Control {
+    u32 ticket;    // next tile id (atomic)
+    u32 epoch;     // tag of this launch's descriptor words
+    u64 done_tot;  // (workgroups finished) << 48 | comma/CR/LF bytes they saw  (one atomic per workgroup)
+    u32 err;       // look-back spin bound hit (atomic or)
+    u32 hwm;       // descriptor words possibly dirty since the last wrap of the epoch
+    u32 probe_ticket, probe_done;  // csvsimd_hbm_probe_device's own pair
+};
+static_assert(sizeof(Control) <= CSVSIMD_SCRATCH_CTL_BYTES, "control block must fit its slot");
+
 struct KernelArgs {
     const uint8_t* abase;  // 16-byte aligned
     u64 lo, hi;            // valid bytes are abase[lo, hi)
@@ -585,13 +613,18 @@ struct KernelArgs {
     u32 num_tiles;
     u64* tape;
     u64 tape_cap;
-    u64* desc;      // num_tiles words, zeroed
-    u32* ticket;    // zeroed
-    u64* tot_struct;  // 64 sharded counters, zeroed: total comma/CR/LF bytes
+    u64* desc;      // num_tiles words of this context's scratch (epoch-tagged, never zeroed per launch)
+    Control* ctl;
     csvsimd_shard_result* result;
+    // optional (sharded re-emit): device word holding the TRUE entering state of this shard.  When
+    // set, the launch does nothing at all unless *state_ptr == 1, and then runs with in_quote_in = 1.
+    const u32* state_ptr;
     // dialect variants only (DIALECT != 0)
     u32 delim, quote, escape;  // bytes; quote / escape 0 = feature off
     u32 escape_in;             // the first byte of the shard is escaped
+#ifdef CSVSIMD_DEV_PROBES
+    u64* prof;  // timing build: per-phase stamp sums
+#endif
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -675,7 +708,10 @@ __device__ __forceinline__ void emit_span(const KernelArgs& args, const RoundMas
         const u32 incl = wave_incl_scan_add(c);
         const u32 n_r = (u32)__builtin_amdgcn_readlane((int)incl, 63);
         const u32 excl = incl - c;
-        const u32 stripe_rel = (u32)r * kRoundBytes + lane * 64u;
+        // opaque: seven hoisted copies of lane * 64 + r * 4096 would otherwise stay live across the tile loop
+        u32 l64 = lane * 64u;
+        asm volatile("" : "+v"(l64));
+        const u32 stripe_rel = (u32)r * kRoundBytes + l64;
         if (fill + n_r > (u32)kCompCap) {
             wave_lds_fence();
             flush_window<NOSTORE>(args, comp, fill, run, span_off, lane);
@@ -715,10 +751,10 @@ __device__ __forceinline__ void wg_barrier() {
     __syncthreads();
 }
 
-// DBG (development probes only, never used by the product entry points): 0 = normal,
-// bit 0 = skip classification (loads only), bit 1 = static tiles (no ticket; only without look-back),
-// bit 2 = no look-back, bit 3 = accumulate per-phase s_memrealtime stamps of waves 0 and 1 into
-// tot_struct[8..] (timing build), bit 4 = emit phase without its global stores
+// DBG (development probes: instantiated only in -DCSVSIMD_DEV_PROBES builds, which the product library is
+// not): 0 = normal, bit 0 = skip classification (loads only), bit 1 = static tiles (no ticket; only without
+// look-back), bit 2 = no look-back, bit 3 = accumulate per-phase s_memrealtime stamps of waves 0 and 1
+// into args.prof (timing build), bit 4 = emit phase without its global stores
 //
 // One iteration of the workgroup loop (three barriers):
 //   ticket -> [T] -> count phase of tile_i (masks -> registers) -> [A] -> wave 0: publish the
@@ -737,6 +773,12 @@ __device__ __forceinline__ void wg_barrier() {
 // Count phases never wait on anything but their own loads, so every aggregate is eventually
 // published by a running workgroup: the look-back always terminates, with no residency assumption
 // (tile ids come from an atomic ticket drawn when the workgroup is ready to start the tile).
+//
+// The launch is self-contained (round 2): no memset before it (epoch-tagged descriptor words), no
+// reduction kernel after it — the last workgroup to finish (one returning atomic per workgroup on
+// Control::done_tot, which also carries the workgroups' comma/CR/LF byte totals) writes the whole
+// result record from the last tile's inclusive word and leaves the control block ready for the
+// next launch.
 #if CSVSIMD_WAVES_PER_EU > 0
 #define CSVSIMD_LAUNCH_BOUNDS __launch_bounds__(kThreads, CSVSIMD_WAVES_PER_EU)
 #else
@@ -760,11 +802,25 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
     const StageAddr sa = stage_addr_of_lane(lane);
     u32 err = 0;  // wave 0 only
 
+    // sharded re-emit: the true entering state sits in device memory (written by the stitch kernel
+    // earlier on this stream); a shard that really is entered outside a string has nothing to redo
+    u32 inq_in = args.in_quote_in;
+    if (args.state_ptr) {
+        const u32 st = (u32)__builtin_amdgcn_readfirstlane(
+            (int)__hip_atomic_load(args.state_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (st == 0u) return;
+        inq_in = 1u;
+    }
+    const u32 epoch = (u32)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(
+                          &args.ctl->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & kEpochMask;
+
     RoundMasks held[kRounds];
     Desc held_agg = {0, 0, 0}, held_before = {0, 0, 0};
     u32 held_tile = 0;
     bool have_held = false;
+    u64 wg_tot = 0;  // wave 0: comma/CR/LF bytes in this workgroup's tiles
 
+#ifdef CSVSIMD_DEV_PROBES
     u64 prof[6] = {0, 0, 0, 0, 0, 0};
     u64 stamp = 0;
 #define CSVSIMD_STAMP(k)                                              \
@@ -774,9 +830,12 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
         stamp = now_;                                                 \
     }
     if (DBG & 8) stamp = __builtin_amdgcn_s_memrealtime();
+#else
+#define CSVSIMD_STAMP(k)
+#endif
 
     for (u32 iter = 0;; ++iter) {
-        if (t == 0) s_tile = (DBG & 2) ? blockIdx.x + iter * gridDim.x : atomicAdd(args.ticket, 1u);
+        if (t == 0) s_tile = (DBG & 2) ? blockIdx.x + iter * gridDim.x : atomicAdd(&args.ctl->ticket, 1u);
         wg_barrier();  // barrier T
         CSVSIMD_STAMP(0)
         const u32 tile = (u32)__builtin_amdgcn_readfirstlane((int)s_tile);
@@ -856,25 +915,17 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
         }
 
         if (w == 0) {
-            if (have_cur && lane == 0) {
-                if (!(DBG & 4)) publish_aggregate(args.desc, tile, agg);
-                atomicAdd((unsigned long long*)(args.tot_struct + (tile & 7u)),
-                          (unsigned long long)(agg.a + agg.b));
+            if (have_cur) {
+                if (!(DBG & 4) && lane == 0) publish_aggregate(args.desc, tile, epoch, agg);
+                wg_tot += (u64)(u32)__builtin_amdgcn_readfirstlane((int)(agg.a + agg.b));
             }
             if (have_held) {
                 u32 pin = 0;
                 u64 base = 0;
-                if (!(DBG & 4)) resolve(args.desc, held_tile, held_agg, args.in_quote_in, lane, pin, base, err);
+                if (!(DBG & 4)) resolve(args.desc, held_tile, epoch, held_agg, inq_in, lane, pin, base, err);
                 if (lane == 0) {
                     s_pin = pin;
                     s_base = base;
-                    if (held_tile == args.num_tiles - 1) {
-                        const u64 count = base + (pin ? held_agg.b : held_agg.a);
-                        args.result->count = count;
-                        args.result->in_quote_out = pin ^ held_agg.p;
-                        args.result->quote_parity = pin ^ held_agg.p ^ args.in_quote_in;
-                        args.result->written = count < args.tape_cap ? count : args.tape_cap;
-                    }
                 }
             }
         }
@@ -898,52 +949,76 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
         for (int r = 0; r < kRounds; ++r) held[r] = m[r];
         CSVSIMD_STAMP(5)  // emit
     }
-    if (w == 0 && lane == 0 && err) args.result->error = 1;
+#ifdef CSVSIMD_DEV_PROBES
     if ((DBG & 8) && lane == 0 && w < 2) {
 #pragma unroll
         for (int k = 0; k < 6; ++k)
-            atomicAdd((unsigned long long*)(args.tot_struct + 8 + w * 8 + k), (unsigned long long)prof[k]);
-        if (w == 0) atomicAdd((unsigned long long*)(args.tot_struct + 24), 1ull);
+            atomicAdd((unsigned long long*)(args.prof + w * 8 + k), (unsigned long long)prof[k]);
+        if (w == 0) atomicAdd((unsigned long long*)(args.prof + 16), 1ull);
     }
+#endif
 #undef CSVSIMD_STAMP
-}
 
-// Zeroes the scratch prefix (ticket, counters, look-back words) and the result record before every
-// launch.  A kernel of our own rather than hipMemsetAsync: captured into a hipGraph, ROCm 7.2's
-// memset node for these sizes replays a 16-byte pattern fill whose pattern is read from memory that
-// is gone after capture (observed: the scratch came back full of stale pointers on every replay).
-__global__ void zero_kernel(uint4* a, u32 a_vec16, uint4* b, u32 b_vec16) {
-    const uint4 z = make_uint4(0, 0, 0, 0);
-    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < a_vec16; i += gridDim.x * blockDim.x) a[i] = z;
-    if (blockIdx.x == 0 && threadIdx.x < b_vec16) b[threadIdx.x] = z;
-}
+    // ---- this workgroup is done; the last one to get here completes the launch --------------------
+    if (w != 0) return;
+    Control* const ctl = args.ctl;
+    if (err && lane == 0) atomicOr(&ctl->err, 1u);
+    // every descriptor word this workgroup published (and its error flag) must have left before it
+    // counts itself done: the workgroup that finishes last reads the last tile's inclusive word
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    u64 old = 0;
+    if (lane == 0)
+        old = atomicAdd((unsigned long long*)&ctl->done_tot, (unsigned long long)((1ull << 48) | wg_tot));
+    const u32 old_lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)old);
+    const u32 old_hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(old >> 32));
+    if ((old_hi >> 16) != gridDim.x - 1u) return;
 
-// sums the sharded structural-byte counters into the result (tiny, 1 wave)
-__global__ void finalize_kernel(const u64* tot_struct, csvsimd_shard_result* result, u32 in_quote_in,
-                                u32 num_tiles, const uint8_t* abase, u64 lo, u64 hi, u32 escape, u32 escape_in) {
-    const u32 lane = threadIdx.x;
+    const u64 total = ((((u64)old_hi << 32) | old_lo) & ((1ull << 48) - 1ull)) + wg_tot;
+    u32 state_out = inq_in, e = 0;
+    u64 count = 0;
+    if (args.num_tiles > 0 && !(DBG & 4)) {
+        // published by whichever workgroup resolved the last tile, before it counted itself done
+        u64 x = 0;
+        for (u32 spins = 0;; ++spins) {
+            if (decode_desc(load_desc(args.desc + (args.num_tiles - 1)), epoch, x) == kStatusInc) break;
+            if (spins > kSpinLimit) { e = 1; x = 0; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        state_out = (u32)x & 1u;
+        count = x >> 1;
+    }
+    e |= __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // escape dialect: is the byte after the shard escaped? (chains into the next shard's escape_in)
-    const u32 esc_out = escape ? escape_run_parity(abase, lo, hi, hi, escape, escape_in, lane) : 0u;
-    u64 v = lane < 8 ? tot_struct[lane] : 0;  // 8 sharded counters; [8..] are timing-probe slots
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const u32 lo = (u32)__shfl_xor((int)(u32)v, d);
-        const u32 hi = (u32)__shfl_xor((int)(u32)(v >> 32), d);
-        v += ((u64)hi << 32) | lo;
+    u32 esc_out = 0;
+    if (DIALECT == 2)
+        esc_out = escape_run_parity(args.abase, args.lo, args.hi, args.hi, args.escape, args.escape_in, lane);
+    const u32 next_epoch = (epoch + 1u) & kEpochMask;
+    u32 hwm = ctl->hwm > args.num_tiles ? ctl->hwm : args.num_tiles;
+    if (next_epoch == 0u) {
+        // the epoch wraps: words tagged in earlier rounds of the counter must not be mistaken for
+        // the next round's, so everything used since the last wrap is cleared (once per 1024 launches)
+        for (u32 i = lane; i < hwm; i += 64u) args.desc[i] = 0;
+        hwm = 0;
     }
     if (lane == 0) {
-        if (num_tiles == 0) {
-            result->count = 0;
-            result->in_quote_out = in_quote_in;
-            result->quote_parity = 0;
-            result->written = 0;
-        }
-        const u64 total = v;
-        const u64 count = result->count;
+        csvsimd_shard_result* const r = args.result;
+        r->count = count;
         // total = count_enter_outside + count_enter_inside, whichever hypothesis was run
-        result->count_enter_outside = in_quote_in ? total - count : count;
-        result->count_enter_inside = in_quote_in ? count : total - count;
-        result->escape_out = esc_out;
+        r->count_enter_outside = inq_in ? total - count : count;
+        r->count_enter_inside = inq_in ? count : total - count;
+        r->quote_parity = state_out ^ inq_in;
+        r->in_quote_out = state_out;
+        r->error = e;
+        r->escape_out = esc_out;
+        r->written = count < args.tape_cap ? count : args.tape_cap;
+        r->reserved1[0] = 0;
+        r->reserved1[1] = 0;
+        // ready for the next launch (made visible by the end-of-kernel release)
+        ctl->ticket = 0;
+        ctl->done_tot = 0;
+        ctl->err = 0;
+        ctl->hwm = hwm;
+        ctl->epoch = next_epoch;
     }
 }
 
@@ -1016,12 +1091,12 @@ __global__ void checksum_kernel(const u64* tape, u64 n, u64 first_index, u64* ou
 // = read only, 4 = one byte written per four read (the 64x31 corpus writes 8 B per 32 B).
 template <int WRITE_DIV>
 __global__ __launch_bounds__(256) void hbm_probe_kernel(const uint8_t* __restrict__ in, uint4* __restrict__ out,
-                                                        u32* ticket, u32 num_tiles) {
+                                                        Control* ctl, u32 num_tiles) {
     __shared__ u32 s_tile;
     const u32 t = threadIdx.x, lane = t & 63u, w = t >> 6;
     uint4 acc = make_uint4(0, 0, 0, 0);
     for (;;) {
-        if (t == 0) s_tile = atomicAdd(ticket, 1u);
+        if (t == 0) s_tile = atomicAdd(&ctl->probe_ticket, 1u);
         __syncthreads();
         const u32 tile = s_tile;
         __syncthreads();
@@ -1056,6 +1131,11 @@ __global__ __launch_bounds__(256) void hbm_probe_kernel(const uint8_t* __restric
         }
     }
     if (WRITE_DIV == 0 && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) out[0] = acc;  // keeps the loads alive
+    // the last workgroup out leaves the ticket pair ready for the next launch (as stage1_kernel does)
+    if (t == 0 && atomicAdd(&ctl->probe_done, 1u) == gridDim.x - 1u) {
+        ctl->probe_ticket = 0;
+        ctl->probe_done = 0;
+    }
 }
 
 // self-test of the wavefront primitives against plain loops (one wave); out[0] = failure bits
@@ -1116,6 +1196,35 @@ __global__ void selftest_kernel(u32* out) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// multi-GPU stitch on the device: csvsimd_stitch_shards (capi.cpp) for shard `rank`, run by one lane
+// right after the all-gather on the same stream.  The two values the reference carries between
+// 64-byte blocks (inside_str, array_idx: src/reader.rs:217-218) carried between GPUs; the re-emit
+// launch reads out->in_quote_in from device memory, so the step never visits the host.
+// ---------------------------------------------------------------------------------------------
+__global__ void stitch_kernel(const csvsimd_shard_result* __restrict__ results, u32 n_shards, u32 rank,
+                              u32 file_in_quote_in, csvsimd_stitch* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    u32 state = file_in_quote_in ? 1u : 0u, err = 0;
+    u64 idx = 1;  // the sentinel occupies global index 0
+    csvsimd_stitch o = {};
+    for (u32 i = 0; i < n_shards; ++i) {
+        const u64 cnt = state ? results[i].count_enter_inside : results[i].count_enter_outside;
+        if (i == rank) {
+            o.in_quote_in = state;
+            o.count = cnt;
+            o.tape_index_base = idx;
+        }
+        idx += cnt;
+        state ^= results[i].quote_parity & 1u;
+        err |= results[i].error;
+    }
+    o.in_quote_final = state;
+    o.total_entries = idx;
+    o.error = err ? 1u : 0u;
+    *out = o;
+}
+
+// ---------------------------------------------------------------------------------------------
 // consumers of the finished tape: RecordSource::seek_field
 // (src/record_source.rs:106-140) for a whole range of records at once, on the device
 // ---------------------------------------------------------------------------------------------
@@ -1151,6 +1260,14 @@ __global__ void gather_fields_kernel(const uint8_t* __restrict__ bytes, const u6
 // ---------------------------------------------------------------------------------------------
 // host-side launchers (no allocation, no synchronisation: graph-capturable)
 // ---------------------------------------------------------------------------------------------
+#ifdef CSVSIMD_DEV_PROBES
+#define CSVSIMD_PROBE_LAUNCH(MODE, EMITV)                                                                         \
+    if (L.debug_mode == (MODE) && (EMITV) == (a.tape != nullptr)) {                                               \
+        hipLaunchKernelGGL((stage1_kernel<EMITV, MODE>), dim3(grid), dim3(kThreads), 0, stream, a);               \
+        launched = true;                                                                                          \
+    }
+#endif
+
 hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream) {
     const uintptr_t addr = (uintptr_t)L.dbuf;
     KernelArgs a;
@@ -1164,64 +1281,63 @@ hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream) {
     a.tape = (u64*)L.dtape;
     a.tape_cap = L.dtape ? L.tape_cap : 0;
     a.desc = L.scratch_desc;
-    a.ticket = L.scratch_ticket;
-    a.tot_struct = L.scratch_tot;
+    a.ctl = reinterpret_cast<Control*>(L.scratch_base);
     a.result = L.d_result;
+    a.state_ptr = L.d_state;
     a.delim = L.delimiter;
     a.quote = L.quote;
     a.escape = L.escape;
     a.escape_in = (L.escape && L.escape_in) ? 1u : 0u;
+#ifdef CSVSIMD_DEV_PROBES
+    a.prof = L.scratch_prof;
+#endif
     // 0 = the reference dialect (the tuned LUT classification), 1 = other delimiter / quote, 2 = + escape
     const int dialect = L.escape ? 2 : (L.delimiter != ',' || L.quote != '"') ? 1 : 0;
 
+    // ONE kernel per launch: an empty shard still runs one workgroup, which writes the result record
+    const u32 want = a.num_tiles ? a.num_tiles : 1u;
+    const u32 grid = want < L.max_blocks ? want : L.max_blocks;
     hipError_t e;
-    // one launch zeroes ticket + sharded totals + descriptors (contiguous, 16-byte granular) and
-    // the result record
-    static_assert(sizeof(csvsimd_shard_result) % 16 == 0, "result record is zeroed 16 bytes at a time");
-    const u32 zvec = (u32)(L.scratch_zero_bytes(a.num_tiles) / 16);
-    const u32 zblocks = zvec > 256u * 64u ? 64u : (zvec + 255u) / 256u;
-    hipLaunchKernelGGL(zero_kernel, dim3(zblocks ? zblocks : 1), dim3(256), 0, stream, (uint4*)L.scratch_base, zvec,
-                       (uint4*)L.d_result, (u32)(sizeof(csvsimd_shard_result) / 16));
+    if (L.ev_begin && (e = hipEventRecord(L.ev_begin, stream)) != hipSuccess) return e;
+    bool launched = false;
+#ifdef CSVSIMD_DEV_PROBES
+    CSVSIMD_PROBE_LAUNCH(1, false)
+    CSVSIMD_PROBE_LAUNCH(4, false)
+    CSVSIMD_PROBE_LAUNCH(6, false)
+    CSVSIMD_PROBE_LAUNCH(7, false)
+    CSVSIMD_PROBE_LAUNCH(16, true)
+    CSVSIMD_PROBE_LAUNCH(8, true)
+    CSVSIMD_PROBE_LAUNCH(8, false)
+#endif
+    if (launched) {
+    } else if (dialect == 2 && a.tape)
+        hipLaunchKernelGGL((stage1_kernel<true, 0, 2>), dim3(grid), dim3(kThreads), 0, stream, a);
+    else if (dialect == 2)
+        hipLaunchKernelGGL((stage1_kernel<false, 0, 2>), dim3(grid), dim3(kThreads), 0, stream, a);
+    else if (dialect == 1 && a.tape)
+        hipLaunchKernelGGL((stage1_kernel<true, 0, 1>), dim3(grid), dim3(kThreads), 0, stream, a);
+    else if (dialect == 1)
+        hipLaunchKernelGGL((stage1_kernel<false, 0, 1>), dim3(grid), dim3(kThreads), 0, stream, a);
+    else if (a.tape)
+        hipLaunchKernelGGL((stage1_kernel<true, 0>), dim3(grid), dim3(kThreads), 0, stream, a);
+    else
+        hipLaunchKernelGGL((stage1_kernel<false, 0>), dim3(grid), dim3(kThreads), 0, stream, a);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (a.num_tiles > 0) {
-        const u32 grid = a.num_tiles < L.max_blocks ? a.num_tiles : L.max_blocks;
-        if (L.ev_begin && (e = hipEventRecord(L.ev_begin, stream)) != hipSuccess) return e;
-        if (L.debug_mode == 1)
-            hipLaunchKernelGGL((stage1_kernel<false, 1>), dim3(grid), dim3(kThreads), 0, stream, a);
-        else if (L.debug_mode == 2)
-            hipLaunchKernelGGL((stage1_kernel<false, 2>), dim3(grid), dim3(kThreads), 0, stream, a);
-        else if (L.debug_mode == 4)
-            hipLaunchKernelGGL((stage1_kernel<false, 4>), dim3(grid), dim3(kThreads), 0, stream, a);
-        else if (L.debug_mode == 6)
-            hipLaunchKernelGGL((stage1_kernel<false, 6>), dim3(grid), dim3(kThreads), 0, stream, a);
-        else if (L.debug_mode == 7)
-            hipLaunchKernelGGL((stage1_kernel<false, 7>), dim3(grid), dim3(kThreads), 0, stream, a);
-        else if (L.debug_mode == 16 && a.tape)
-            hipLaunchKernelGGL((stage1_kernel<true, 16>), dim3(grid), dim3(kThreads), 0, stream, a);
-        else if (L.debug_mode == 8 && a.tape)
-            hipLaunchKernelGGL((stage1_kernel<true, 8>), dim3(grid), dim3(kThreads), 0, stream, a);
-        else if (L.debug_mode == 8)
-            hipLaunchKernelGGL((stage1_kernel<false, 8>), dim3(grid), dim3(kThreads), 0, stream, a);
-        else if (dialect == 2 && a.tape)
-            hipLaunchKernelGGL((stage1_kernel<true, 0, 2>), dim3(grid), dim3(kThreads), 0, stream, a);
-        else if (dialect == 2)
-            hipLaunchKernelGGL((stage1_kernel<false, 0, 2>), dim3(grid), dim3(kThreads), 0, stream, a);
-        else if (dialect == 1 && a.tape)
-            hipLaunchKernelGGL((stage1_kernel<true, 0, 1>), dim3(grid), dim3(kThreads), 0, stream, a);
-        else if (dialect == 1)
-            hipLaunchKernelGGL((stage1_kernel<false, 0, 1>), dim3(grid), dim3(kThreads), 0, stream, a);
-        else if (a.tape)
-            hipLaunchKernelGGL((stage1_kernel<true, 0>), dim3(grid), dim3(kThreads), 0, stream, a);
-        else
-            hipLaunchKernelGGL((stage1_kernel<false, 0>), dim3(grid), dim3(kThreads), 0, stream, a);
-        e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        if (L.ev_end && (e = hipEventRecord(L.ev_end, stream)) != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, stream, a.tot_struct, a.result,
-                       a.in_quote_in, a.num_tiles, a.abase, a.lo, a.hi, a.escape, a.escape_in);
-    return hipGetLastError();
+    if (L.ev_end && (e = hipEventRecord(L.ev_end, stream)) != hipSuccess) return e;
+    return hipSuccess;
+}
+
+// name of the kernel launch_stage1 runs for this configuration (bench.py reports it next to the time)
+const char* stage1_kernel_name(bool emit, int dialect) {
+    static const char* names[2][3] = {
+        {"void csvsimd::stage1_kernel<false, 0, 0>(csvsimd::KernelArgs)",
+         "void csvsimd::stage1_kernel<false, 0, 1>(csvsimd::KernelArgs)",
+         "void csvsimd::stage1_kernel<false, 0, 2>(csvsimd::KernelArgs)"},
+        {"void csvsimd::stage1_kernel<true, 0, 0>(csvsimd::KernelArgs)",
+         "void csvsimd::stage1_kernel<true, 0, 1>(csvsimd::KernelArgs)",
+         "void csvsimd::stage1_kernel<true, 0, 2>(csvsimd::KernelArgs)"}};
+    return names[emit ? 1 : 0][dialect < 0 || dialect > 2 ? 0 : dialect];
 }
 
 hipError_t launch_synth(void* dbuf, u64 file_off, u64 len, u32 cols, u32 width, u64 seed, u32 quote_pct,
@@ -1264,17 +1380,24 @@ hipError_t launch_gather_fields(const void* dbytes, const void* d_begin, const v
     return hipGetLastError();
 }
 
-hipError_t launch_hbm_probe(const void* din, u64 len, void* dout, int write_div, u32* ticket, u32 blocks,
+hipError_t launch_hbm_probe(const void* din, u64 len, void* dout, int write_div, void* scratch_base, u32 blocks,
                             hipStream_t stream) {
     const u32 tiles = (u32)(len / 131072);
     if (tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(zero_kernel, dim3(1), dim3(64), 0, stream, (uint4*)ticket, 1u, (uint4*)ticket, 0u);
+    Control* const ctl = reinterpret_cast<Control*>(scratch_base);
     if (write_div == 4)
         hipLaunchKernelGGL(hbm_probe_kernel<4>, dim3(blocks), dim3(256), 0, stream, (const uint8_t*)din, (uint4*)dout,
-                           ticket, tiles);
+                           ctl, tiles);
     else
         hipLaunchKernelGGL(hbm_probe_kernel<0>, dim3(blocks), dim3(256), 0, stream, (const uint8_t*)din, (uint4*)dout,
-                           ticket, tiles);
+                           ctl, tiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_stitch(const void* d_results, u32 n_shards, u32 rank, u32 file_in_quote_in, void* d_stitch,
+                         hipStream_t stream) {
+    hipLaunchKernelGGL(stitch_kernel, dim3(1), dim3(64), 0, stream, (const csvsimd_shard_result*)d_results, n_shards,
+                       rank, file_in_quote_in, (csvsimd_stitch*)d_stitch);
     return hipGetLastError();
 }
 

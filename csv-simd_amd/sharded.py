@@ -55,21 +55,112 @@ def words_from_result(r: ShardResult) -> List[int]:
             r.error | (r.escape_out << 32), r.written, 0, 0]
 
 
+STITCH_WORDS = 5  # csvsimd_stitch as int64 words: in_quote_in | in_quote_final << 32, count, base, total, error
+
+
+def stitch_from_words(h) -> Stitch:
+    h = [int(x) for x in h]
+    st = Stitch()
+    st.in_quote_in = h[0] & 0xFFFFFFFF
+    st.in_quote_final = (h[0] >> 32) & 0xFFFFFFFF
+    st.count, st.tape_index_base, st.total_entries = h[1], h[2], h[3]
+    st.error = h[4] & 0xFFFFFFFF
+    return st
+
+
+class ShardedStep:
+    """Buffers of one rank's sharded step, allocated once: the step itself allocates nothing and never
+    waits for the host until its single copy-out at the end.
+
+        launch(0)                      speculative stage-1 pass, record -> d_result       (caller's C-ABI call)
+        all_gather_into_tensor         ONE collective, device to device (RCCL over xGMI)
+        stitch_shards_device_async     one-lane kernel: entering state / tape base / totals, on the device
+        reemit(d_stitch)               stage-1 launch that reads its entering state from device memory and
+                                       returns at once unless it is 1                     (caller's C-ABI call)
+        copy-out                       [final record | stitch | all records] -> pinned host, one synchronise
+    """
+
+    def __init__(self, device: torch.device, group=None):
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.device = device
+        w = self.world
+        # one device block so a single copy carries everything the host wants: [mine 8 | stitch 5 | all 8w]
+        self.d_block = torch.zeros(8 + STITCH_WORDS + 8 * w, dtype=torch.int64, device=device)
+        self.d_result = self.d_block[0:8]
+        self.d_stitch = self.d_block[8:8 + STITCH_WORDS]
+        self.d_all = self.d_block[8 + STITCH_WORDS:]
+        self.h_block = torch.zeros_like(self.d_block, device="cpu")
+        if device.type == "cuda":
+            self.h_block = self.h_block.pin_memory()
+
+    def stitch_via_host(self, file_in_quote_in: int = 0) -> None:
+        """CPU rehearsal of the stitch kernel (gloo groups, tensors in host memory): the same arithmetic
+        through csvsimd_stitch_shards, written where the kernel would write it."""
+        host = self.d_all.tolist()
+        results = [result_from_words(host[8 * i: 8 * i + 8]) for i in range(self.world)]
+        st = stitch_shards(results, self.rank, file_in_quote_in)
+        self.d_stitch.copy_(torch.tensor([st.in_quote_in | (st.in_quote_final << 32), st.count, st.tape_index_base,
+                                          st.total_entries, st.error], dtype=torch.int64))
+
+    def run(self, launch: Callable[[int], None], reemit: Callable[[int], None], file_in_quote_in: int = 0,
+            rehearsal: bool = False) -> Tuple[Stitch, ShardResult, List[ShardResult]]:
+        """launch(0) must enqueue the speculative pass with its record going to self.d_result;
+        reemit(d_stitch_ptr) must enqueue csvsimd_stage1_reemit_device_async into the same tape / record.
+        Returns (stitch, this rank's final record, every rank's speculative record)."""
+        from . import stitch_shards_device_async
+        err = None
+        try:
+            launch(0)
+        except Exception as e:  # still join the collective: the peers are about to block in it
+            err = e
+            self.d_result.zero_()
+            self.d_result[4] = 1  # error flag set: every rank will report the failure
+        dist.all_gather_into_tensor(self.d_all, self.d_result, group=self.group)
+        if rehearsal:
+            self.stitch_via_host(file_in_quote_in)
+        else:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            stitch_shards_device_async(self.d_all.data_ptr(), self.world, self.rank, file_in_quote_in,
+                                       self.d_stitch.data_ptr(), stream)
+        if err is None:
+            reemit(self.d_stitch.data_ptr())
+        self.h_block.copy_(self.d_block, non_blocking=True)
+        if self.device.type == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()   # the step's only synchronisation
+        if err is not None:
+            raise err
+        h = self.h_block.tolist()
+        st = stitch_from_words(h[8:8 + STITCH_WORDS])
+        final = result_from_words(h[0:8])
+        if st.error or final.error:
+            raise RuntimeError("stage 1 reported an internal error on some rank (no rank has a valid tape)")
+        return st, final, [result_from_words(h[8 + STITCH_WORDS + 8 * i: 16 + STITCH_WORDS + 8 * i])
+                           for i in range(self.world)]
+
+
 def index_sharded(launch: Callable[[int], None], d_result: torch.Tensor, group=None,
                   file_in_quote_in: int = 0) -> Tuple[Stitch, ShardResult, bool]:
-    """One sharded stage-1 step for this rank.
-
-    launch(in_quote_in) ENQUEUES stage 1 over this rank's byte range into its own tape shard, with
-    the 64-byte csvsimd_shard_result going to `d_result` (8 x int64, on the device the collective
-    runs on).  The step is: launch(0) -> ONE all-gather of the result records, device to device
-    (RCCL over xGMI) -> one copy to the host (the only synchronisation) -> csvsimd_stitch_shards ->
+    """One sharded stage-1 step with the stitch on the HOST (kept for callers without a device-side
+    re-emit, and as the arithmetic the gloo tests compare the device stitch with):
+    launch(0) -> ONE all-gather of the result records -> copy to the host -> csvsimd_stitch_shards ->
     launch(1) only if this rank turns out to start inside a quoted string.
-    Returns (stitch, final result of this rank, re_emitted)."""
+    Returns (stitch, final result of this rank, re_emitted).  Every rank joins the collective even if its
+    own launch raises."""
     rank = dist.get_rank(group)
     world = dist.get_world_size(group)
-    launch(0)
+    err = None
+    try:
+        launch(0)
+    except Exception as e:
+        err = e
+        d_result.zero_()
+        d_result[4] = 1
     gathered = torch.empty(8 * world, dtype=torch.int64, device=d_result.device)
     dist.all_gather_into_tensor(gathered, d_result, group=group)
+    if err is not None:
+        raise err
     host = gathered.cpu().tolist()
     results = [result_from_words(host[8 * i: 8 * i + 8]) for i in range(world)]
     for i, r in enumerate(results):

@@ -45,7 +45,7 @@ extern "C" {
 const char* csvsimd_strerror(int code);
 const char* csvsimd_last_error(void); /* thread-local text of the last HIP failure */
 int csvsimd_device_count(void);       /* number of HIP devices visible, 0 if none */
-uint32_t csvsimd_abi_version(void);
+uint32_t csvsimd_abi_version(void); /* 2: csvsimd_stitch grew an error field; device-side stitch / re-emit */
 /* bytes one workgroup indexes per look-back step (informational: tests probe sizes around it) */
 uint32_t csvsimd_tile_bytes(void);
 
@@ -145,22 +145,41 @@ int csvsimd_stage1_index_dialect(csvsimd_ctx* ctx, const csvsimd_dialect* dialec
  * `rank` its true entering state and the global tape index of its first entry (sentinel
  * included), plus the whole-file totals. */
 typedef struct csvsimd_stitch {
-    uint32_t in_quote_in;      /* entering state of this shard                          */
+    uint32_t in_quote_in;      /* entering state of this shard (first field: the re-emit launch reads it) */
     uint32_t in_quote_final;   /* state after the last shard                            */
     uint64_t count;            /* this shard's entry count under its true entering state */
     uint64_t tape_index_base;  /* global index of this shard's first entry (>= 1)       */
     uint64_t total_entries;    /* whole file, sentinel included                         */
+    uint32_t error;            /* 1 if any shard's record carried its error flag        */
+    uint32_t reserved;
 } csvsimd_stitch;
 int csvsimd_stitch_shards(const csvsimd_shard_result* results, uint32_t n_shards, uint32_t rank,
                           uint32_t file_in_quote_in, csvsimd_stitch* out);
+/* The same arithmetic as a one-lane kernel on hip_stream: d_results = n_shards records in DEVICE memory
+ * (the all-gather's receive buffer), d_stitch = DEVICE csvsimd_stitch (8-byte aligned).  With
+ * csvsimd_stage1_reemit_device_async below the sharded step never waits for the host:
+ *     speculative csvsimd_stage1_index_device_async(in_quote_in = 0)  ->  all-gather of the records
+ *     ->  csvsimd_stitch_shards_device_async  ->  csvsimd_stage1_reemit_device_async
+ * csvsimd_stage1_reemit_device_async is csvsimd_stage1_index_device_async whose in_quote_in is read on the
+ * device from d_stitch->in_quote_in when the kernel starts: if it is 0 the launch returns at once and
+ * leaves tape and d_result exactly as the speculative pass wrote them (which is then final); if it is 1
+ * the shard is indexed again, for real, as "entered inside a quoted string" (README.md:24 of the
+ * reference: "requires toggling interpretation if/when start in quoted text"). */
+int csvsimd_stitch_shards_device_async(const void* d_results, uint32_t n_shards, uint32_t rank,
+                                       uint32_t file_in_quote_in, void* d_stitch, void* hip_stream);
+int csvsimd_stage1_reemit_device_async(csvsimd_ctx* ctx, const void* dbuf, uint64_t len, uint64_t base_off,
+                                       const void* d_stitch, void* dtape, uint64_t tape_cap,
+                                       void* d_result, void* hip_stream);
 
 /* Native form of the same step for hosts without torch.distributed: one communicator per rank
  * (one process per GPU).  Rank 0 obtains an id (ncclGetUniqueId) and hands its 128 bytes to the
  * other ranks by whatever channel the application has; every rank then creates its communicator
  * (ncclCommInitRank).  csvsimd_stage1_index_sharded = speculative pass (entered outside a string)
- * -> ONE ncclAllGather of the 64-byte result records over xGMI -> one copy to the host (the only
- * synchronisation) -> csvsimd_stitch_shards -> re-emit only if this shard starts inside a quoted
- * string.  The tape stays sharded (entries of this rank's bytes, absolute offsets).  RCCL is
+ * -> ONE ncclAllGather of the 64-byte result records over xGMI -> stitch on the device -> re-emit
+ * launch that does nothing unless this shard starts inside a quoted string -> the final record and the
+ * stitch are copied to the host; one synchronisation at the very end.  The tape stays sharded (entries
+ * of this rank's bytes, absolute offsets).  Every rank reaches the collective even if its own launch
+ * fails (it contributes a record with the error flag set and all ranks return an error).  RCCL is
  * resolved with dlopen at first use: CSVSIMD_ERR_RCCL if it is absent. */
 #define CSVSIMD_COMM_ID_BYTES 128
 typedef struct csvsimd_comm csvsimd_comm;
@@ -283,6 +302,12 @@ int csvsimd_selftest_device(int device);
 int csvsimd_stage1_time_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len, void* dtape,
                                uint64_t tape_cap, void* d_result, void* hip_stream, int warmup,
                                int iters, float* avg_ms);
+/* Name of the kernel a stage-1 launch runs (emit = a tape is written; dialect NULL = the reference's),
+ * as rocprofv3 prints it: bench.py reports what it timed instead of a string of its own. */
+const char* csvsimd_stage1_kernel_name(int emit, const csvsimd_dialect* dialect);
+/* 1 if this library was built with -DCSVSIMD_DEV_PROBES (environment-driven ablation hooks in
+ * csvsimd_stage1_time_device, scripts/probe*.py): never the product library; bench.py refuses such a build. */
+uint32_t csvsimd_build_has_probes(void);
 
 /* HBM streaming probe: the stage-1 traffic shape with none of its work, so bench.py can report
  * the ceiling this GPU actually reaches next to the 8 TB/s spec peak.  Reads dbuf[0..len) (16-byte

@@ -14,7 +14,7 @@ def make_data(n, seed, p_quote):
     return random_csvish(np.random.default_rng(seed), n, p_quote)
 
 
-def worker(rank, world, port, n, seed, p_quote, skew, outdir):
+def worker(rank, world, port, n, seed, p_quote, skew, outdir, device_flow=False):
     import torch
     import torch.distributed as dist
 
@@ -46,7 +46,23 @@ def worker(rank, world, port, n, seed, p_quote, skew, outdir):
             passes.append(in_quote_in)
             run_pass.entries = entries
 
-        st, final, re_emitted = sharded.index_sharded(run_pass, d_result)
+        if device_flow:
+            # the control flow bench.py and the native C entry point drive on GPUs (stitch in "device"
+            # memory, re-emit launch that reads its entering state from there), rehearsed on host tensors
+            step = sharded.ShardedStep(torch.device("cpu"))
+            d_result = step.d_result
+
+            def reemit(d_stitch_ptr):
+                assert d_stitch_ptr == step.d_stitch.data_ptr()
+                if int(step.d_stitch[0]) & 0xFFFFFFFF:   # what the kernel reads when it starts
+                    run_pass(1)
+
+            st, final, records = step.run(run_pass, reemit, rehearsal=True)
+            re_emitted = bool(st.in_quote_in)
+            assert len(records) == world and records[rank].count_enter_outside + records[rank].count_enter_inside \
+                == int(np.isin(shard, (0x2C, 0x0A, 0x0D)).sum())
+        else:
+            st, final, re_emitted = sharded.index_sharded(run_pass, d_result)
         assert final.count == st.count
         assert re_emitted == bool(st.in_quote_in) and passes == ([0, 1] if re_emitted else [0])
         np.save(os.path.join(outdir, f"shard{rank}.npy"), run_pass.entries)

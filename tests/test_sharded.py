@@ -56,11 +56,13 @@ def test_stitch_host_arithmetic(pkg, oracle):
             state, base = q, base + e.size
 
 
-@pytest.mark.parametrize("world,p_quote,skew", [(2, 0.0, 0), (2, 0.06, 0), (2, 0.06, 777), (3, 0.1, 13)])
-def test_gloo_sharded_stitch(pkg, oracle, tmp_path, world, p_quote, skew):
+@pytest.mark.parametrize("world,p_quote,skew,device_flow",
+                         [(2, 0.0, 0, False), (2, 0.06, 0, False), (2, 0.06, 777, False), (3, 0.1, 13, False),
+                          (2, 0.06, 777, True), (4, 0.1, 13, True)])
+def test_gloo_sharded_stitch(pkg, oracle, tmp_path, world, p_quote, skew, device_flow):
     import torch.multiprocessing as mp
     n, seed = 40000, 4242
-    mp.spawn(_dist_worker.worker, args=(world, free_port(), n, seed, p_quote, skew, str(tmp_path)),
+    mp.spawn(_dist_worker.worker, args=(world, free_port(), n, seed, p_quote, skew, str(tmp_path), device_flow),
              nprocs=world, join=True)
     data = _dist_worker.make_data(n, seed, p_quote)
     want = oracle.scalar_read(data)
