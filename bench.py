@@ -1,21 +1,33 @@
 #!/usr/bin/env python3
 """bench.py — stage-1 CSV structural indexing throughput on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--gib-per-gpu G]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--gib-per-gpu G] [--skew B]
 
 A "step" is one pass of the hot path over one batch of synthetic CSV already resident in HBM:
 each rank indexes its contiguous byte shard of the file (speculative stage-1 launch through the
-C ABI), the ranks exchange their shard descriptors with ONE all-gather over RCCL (N > 1), stitch
-quote parity / tape bases, and a rank whose true entering state is "inside a string" re-emits.
-The step ends when the tape and its length are final on every rank.  Weak scaling: every rank
-always holds the same number of bytes (default 8 GiB = one GPU's shard of BASELINE config 4,
-"64 GiB synthetic CSV, 64 cols, chunk-sharded 8xMI355X").
+C ABI), the ranks exchange their shard descriptors with ONE all-gather over RCCL (N > 1), a one-lane
+kernel stitches quote parity / tape bases ON THE DEVICE, and a second launch re-emits the shard iff
+its true entering state (read from device memory) is "inside a string".  Nothing between the first
+launch and the final copy-out waits for the host; the step ends when the tape and its length are
+final on every rank.  Weak scaling: every rank always holds the same number of bytes (default 8 GiB =
+one GPU's shard of BASELINE config 4, "64 GiB synthetic CSV, 64 cols, chunk-sharded 8xMI355X").
+
+The timed path is VERIFIED at every N (the line carries "verified", the process exits non-zero on a
+mismatch): each rank compares its whole tape shard, entry for entry, with an independent restatement of
+the definition in plain torch ops on the same device bytes (and with the closed form on quote-free
+corpora), compares 1 Mi entries either side of its shard boundaries and an order-sensitive checksum
+with the CPU oracle, and rank 0 checks the stitched bases / totals / final state against the per-rank
+truths.  On the default workload a second, untimed-for-`value` leg runs the QUOTED corpus cut mid-row
+(--skew 777 semantics: shards start inside rows, some inside quoted fields) so that the re-emit path is
+exercised and verified whenever this file runs with N > 1 ("q10_skew_check").
 
 Rank 0 prints ONE JSON line.  value = whole-job GiB/s (all ranks' bytes / max-over-ranks time).
 roofline: HBM-bound, algorithmic bytes = 1 byte read per CSV byte scanned;
-duration = the stage-1 kernel's average launch time from HIP events recorded on its own stream.
-cpu_baseline: the oracle's faithful SSE restatement of the reference loop ("ref_sse_1t": 1 thread
-like the reference, growing Vec) timed on this host over a bounded sample of the same bytes.
+duration = the stage-1 kernel's average launch time from HIP events recorded on its own stream
+(a launch is exactly one kernel).  cpu_baseline: the oracle's faithful SSE restatement of the reference
+loop ("ref_sse_1t": 1 thread like the reference, growing Vec) timed on this host over a bounded sample
+of the same bytes.  ingest: the host-buffer drop-in (PCIe-inclusive) next to the probed H2D rate —
+never part of `value`.
 """
 import argparse
 import json
@@ -31,6 +43,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable (copy)
+WINDOW_ENTRIES = 1 << 20  # entries compared with the CPU oracle either side of every shard boundary
 
 
 def build_if_needed():
@@ -39,21 +52,38 @@ def build_if_needed():
         graft.build()
 
 
-class ShardBench:
-    """One rank's shard: device buffer, tape shard, context."""
+def refuse_probe_environment(pkg):
+    """The number this file prints must come from the product library and nothing else."""
+    bad = sorted(k for k in os.environ if k.startswith("CSVSIMD_PROBE"))
+    if bad:
+        sys.exit(f"bench.py refuses to run with development probe variables set: {bad}")
+    if os.environ.get("CSVSIMD_LIB"):
+        sys.exit("bench.py refuses to run with CSVSIMD_LIB set: it times csv-simd_amd/csrc/libcsvsimd_hip.so only")
+    if pkg.build_has_probes():
+        sys.exit("bench.py refuses a library built with -DCSVSIMD_DEV_PROBES")
 
-    def __init__(self, pkg, device, workload, shard_bytes, rank, world):
-        self.pkg, self.device = pkg, device
+
+class ShardBench:
+    """One rank's shard: device buffer, tape shard, context.  Shards are contiguous byte ranges of one
+    file of world * n bytes (n = whole rows); with skew every interior cut moves `skew` bytes to the right,
+    i.e. into the middle of a row ("deliberately misaligned variant")."""
+
+    def __init__(self, pkg, device, workload, shard_bytes, rank, world, skew=0):
+        self.pkg, self.device, self.workload = pkg, device, workload
         cols, width, seed, q = pkg.WORKLOADS[workload]
-        self.cols, self.width = cols, width
-        row = cols * (width + 1)
-        self.n = (shard_bytes // row) * row           # whole rows per shard (boundary = row start)
-        self.lo = rank * self.n
-        self.total = world * self.n
+        self.cols, self.width, self.seed, self.q = cols, width, seed, q
+        self.row = cols * (width + 1)
+        per = (shard_bytes // self.row) * self.row
+        self.total = world * per
+        cut = lambda i: 0 if i <= 0 else self.total if i >= world else i * per + skew  # noqa: E731
+        self.lo, self.hi = cut(rank), cut(rank + 1)
+        self.n = self.hi - self.lo
+        self.rank, self.world, self.skew = rank, world, skew
         self.dbuf = torch.empty(self.n, dtype=torch.uint8, device=device)
         pkg.synth_fill_device(self.dbuf.data_ptr(), self.lo, self.n, cols, width, seed, q)
-        # the bench sizes the tape from the known shape: no retry, no count pre-pass in a step
-        self.cap = self.n // (width + 1) + 64
+        # the bench sizes the tape from the known shape: no retry, no count pre-pass in a step (a quoted
+        # corpus holds up to three comma/LF bytes per quoted field; a wrong speculation may count them all)
+        self.cap = int(self.n // (width + 1) * (1.25 if q else 1.0)) + 1024
         self.dtape = torch.empty(self.cap, dtype=torch.int64, device=device)
         self.d_result = torch.zeros(8, dtype=torch.int64, device=device)
         self.h_result = torch.zeros(8, dtype=torch.int64).pin_memory()
@@ -62,12 +92,18 @@ class ShardBench:
         self.ctx.reserve(self.n)
         torch.cuda.synchronize(device)
 
-    def launch(self, in_quote_in):
+    def stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def launch(self, in_quote_in, d_result=None):
         """Enqueue stage 1 over this rank's shard (asynchronous; result record -> d_result)."""
-        s = torch.cuda.current_stream(self.device)
+        d_result = self.d_result if d_result is None else d_result
         self.ctx.stage1_index_device_async(self.dbuf.data_ptr(), self.n, self.lo, in_quote_in,
-                                           self.dtape.data_ptr(), self.cap, self.d_result.data_ptr(),
-                                           s.cuda_stream)
+                                           self.dtape.data_ptr(), self.cap, d_result.data_ptr(), self.stream())
+
+    def reemit(self, d_stitch_ptr, d_result):
+        self.ctx.stage1_reemit_device_async(self.dbuf.data_ptr(), self.n, self.lo, d_stitch_ptr,
+                                            self.dtape.data_ptr(), self.cap, d_result.data_ptr(), self.stream())
 
     def check(self, r):
         if r.error or r.count > self.cap:
@@ -84,6 +120,121 @@ class ShardBench:
         if (int(w[4]) & 0xFFFFFFFF) or int(w[0]) > self.cap:   # error flag / more entries than the tape holds
             return self.check(sharded.result_from_words(self.h_result.tolist()))
         return w
+
+
+# ------------------------------------------------------------------------------------------------
+# verification of the timed path (never inside the timed region)
+# ------------------------------------------------------------------------------------------------
+def torch_reference_compare(sb, in_quote_in, count):
+    """Entry-for-entry comparison of the whole tape shard with the DEFINITION restated in torch ops on the
+    same device bytes: byte i is structural iff it is ',', CR or LF and the number of '"' at positions <= i
+    (plus the entering state) is even (src/avx/stage1.rs:342-407).  Independent of the HIP
+    kernels (eq / cumsum / nonzero), chunked so that it runs at 8 GiB.  Returns (ok, entries, state_out)."""
+    chunk = 256 << 20
+    state, pos, ok = int(in_quote_in), 0, True
+    for c0 in range(0, sb.n, chunk):
+        x = sb.dbuf[c0: c0 + chunk]
+        isq = x == 0x22
+        par = torch.cumsum(isq, 0, dtype=torch.int32)
+        par &= 1
+        if state:
+            par ^= 1
+        st = ((x == 0x2C) | (x == 0x0A) | (x == 0x0D)) & (par == 0)
+        idx = torch.nonzero(st).flatten()
+        idx += sb.lo + c0
+        k = idx.numel()
+        if pos + k > count or not torch.equal(sb.dtape[pos: pos + k], idx):
+            ok = False
+        pos += k
+        state ^= int(isq.sum().item()) & 1
+        del x, isq, par, st, idx
+    return ok and pos == count, pos, state
+
+
+def closed_form_compare(sb, count):
+    """Quote-free corpora: entry k of the file is the byte k * (width + 1) + width."""
+    pitch = sb.width + 1
+    k0, k1 = sb.lo // pitch, sb.hi // pitch
+    if count != k1 - k0:
+        return False
+    ok, step = True, 64 << 20
+    for a in range(k0, k1, step):
+        b = min(k1, a + step)
+        want = torch.arange(a, b, dtype=torch.int64, device=sb.device) * pitch + sb.width
+        ok = ok and torch.equal(sb.dtape[a - k0: b - k0], want)
+    return ok
+
+
+def oracle_windows_compare(oracle, sb, in_quote_in, count):
+    """The CPU oracle on the head and the tail of the shard: WINDOW_ENTRIES entries either side of the
+    shard boundaries, entry for entry, plus the order-sensitive checksum of the head window computed by
+    the device checksum kernel and by the oracle.  The entering state of the tail window is derived on
+    the CPU from the synthetic corpus itself (a row start is never inside a quoted field)."""
+    pkg = sb.pkg
+    per_entry = sb.width + 1
+    wbytes = min(sb.n, (WINDOW_ENTRIES + 4096) * per_entry)
+    head = sb.dbuf[:wbytes].cpu().numpy()
+    want, _ = oracle.scalar_index(head, base_off=sb.lo, in_quote_in=in_quote_in)
+    k = min(want.size, WINDOW_ENTRIES, count)
+    got = sb.dtape[:k].cpu().numpy().view(np.uint64)
+    ok = bool(np.array_equal(got, want[:k]))
+    # the same bytes regenerated by the CPU generator: the device corpus is the file both sides mean
+    small = min(wbytes, 1 << 20)
+    ok = ok and bool(np.array_equal(head[:small], oracle.synth(sb.lo, small, sb.cols, sb.width, sb.seed, sb.q)))
+    out = torch.zeros(2, dtype=torch.int64, device=sb.device)
+    pkg.tape_checksum_device(sb.dtape.data_ptr(), k, 1, out.data_ptr(), sb.stream())
+    ok = ok and tuple(int(v) & (2**64 - 1) for v in out.cpu().tolist()) == oracle.tape_checksum(want[:k], 1)
+    # tail: start at the last row boundary that leaves >= wbytes before the end of the shard
+    t0 = ((sb.hi - wbytes) // sb.row) * sb.row
+    if t0 <= sb.lo:
+        return ok
+    tail = sb.dbuf[t0 - sb.lo:].cpu().numpy()
+    want_t, _ = oracle.scalar_index(tail, base_off=t0, in_quote_in=0)
+    kt = min(want_t.size, WINDOW_ENTRIES, count)
+    got_t = sb.dtape[count - kt: count].cpu().numpy().view(np.uint64)
+    return ok and bool(np.array_equal(got_t, want_t[want_t.size - kt:]))
+
+
+def true_entering_state(oracle, sb):
+    """In-quote state at byte `lo` of the synthetic file, from the CPU generator alone."""
+    r0 = (sb.lo // sb.row) * sb.row
+    if r0 == sb.lo or not sb.q:
+        return 0
+    part = oracle.synth(r0, sb.lo - r0, sb.cols, sb.width, sb.seed, sb.q)
+    return int(np.count_nonzero(part == 0x22)) & 1
+
+
+def verify_rank(oracle, sb, st_in_quote_in, count, tape_index_base, total_entries, in_quote_final):
+    """Everything one rank can check about its own shard.  Returns a dict of booleans + facts."""
+    t = sb.dtape[:count]
+    truth_in = true_entering_state(oracle, sb)
+    ok_ref, ref_count, state_out = torch_reference_compare(sb, truth_in, count)
+    res = {
+        "entering_state_matches_generator": truth_in == int(st_in_quote_in),
+        "tape_equals_torch_reference": bool(ok_ref),
+        "ascending_in_range": bool(count == 0 or ((t[1:] > t[:-1]).all() and int(t[0]) >= sb.lo and int(t[-1]) < sb.hi)),
+        "oracle_windows": bool(oracle_windows_compare(oracle, sb, truth_in, count)),
+    }
+    if not sb.q:
+        res["closed_form"] = bool(closed_form_compare(sb, count))
+    facts = {"rank": sb.rank, "lo": sb.lo, "hi": sb.hi, "count": int(count), "ref_count": int(ref_count),
+             "state_in": truth_in, "state_out": int(state_out), "base": int(tape_index_base),
+             "total": int(total_entries), "final": int(in_quote_final), "reemit": int(st_in_quote_in)}
+    return res, facts
+
+
+def verify_job(all_facts):
+    """Rank 0: the stitched bases, totals and states against the per-rank truths."""
+    all_facts = sorted(all_facts, key=lambda f: f["rank"])
+    base, state, ok = 1, 0, True
+    for f in all_facts:
+        ok = ok and f["base"] == base and f["state_in"] == state and f["count"] == f["ref_count"]
+        base += f["ref_count"]
+        state = f["state_out"]
+    ok = ok and all(f["total"] == base and f["final"] == state for f in all_facts)
+    for a, b in zip(all_facts, all_facts[1:]):
+        ok = ok and a["hi"] == b["lo"]
+    return ok, sum(f["reemit"] for f in all_facts), base
 
 
 def time_steps(step, steps, warmup, device, dist_on):
@@ -141,15 +292,112 @@ def cpu_baseline(oracle, sb, sample_bytes):
             "entries": entries, "host_cpus": os.cpu_count()}
 
 
+def ingest_leg(pkg, sb, sample_bytes):
+    """The host-buffer drop-in for reader::read (csvsimd_stage1_index: pageable host bytes in, host tape
+    out) on a bounded sample of the same corpus, next to what this box's PCIe link moves host -> device
+    (one pinned hipMemcpy).  PCIe-inclusive by construction; reported beside `value`, never in it."""
+    n = min(sb.n, sample_bytes)
+    host = sb.dbuf[:n].cpu().numpy()
+    tape = np.empty(n // (sb.width + 1) + 64, dtype=np.uint64)
+    ctx = pkg.Context(sb.device.index)
+    rc, tl, _ = ctx.read_into(host[: 64 << 20], tape)      # allocates the pipeline, pages everything in
+    best, ok = None, rc == 0
+    for _ in range(3):
+        t0 = time.perf_counter()
+        rc, tl, _ = ctx.read_into(host, tape)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+        ok = ok and rc == 0
+    pitch = sb.width + 1
+    if not sb.q and sb.lo == 0:
+        want = np.arange(n // pitch, dtype=np.uint64) * pitch + sb.width
+        ok = ok and tl == want.size + 1 and tape[0] == 0 and bool(np.array_equal(tape[1:tl], want))
+    ctx.close()
+    # probed link rate: pinned host -> device, the same number of bytes, best of 3
+    pin = torch.empty(min(n, 1 << 30), dtype=torch.uint8).pin_memory()
+    dst = torch.empty_like(pin, device=sb.device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    h2d = None
+    for _ in range(4):
+        e0.record()
+        dst.copy_(pin, non_blocking=True)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1)
+        h2d = ms if h2d is None else min(h2d, ms)
+    h2d_gib = pin.numel() / (h2d * 1e-3) / 2**30
+    gib = n / best / 2**30
+    return {"value": round(gib, 2), "unit": "GiB/s", "bytes": n, "tape_entries": int(tl), "verified": bool(ok),
+            "h2d_probe_GiB_s": round(h2d_gib, 2), "frac_of_h2d_probe": round(gib / h2d_gib, 3),
+            "note": "csvsimd_stage1_index: pageable host buffer -> pinned staging -> H2D -> kernel -> D2H of the "
+                    "tape -> caller's tape (chunks pipelined over three streams); PCIe-inclusive, never part of `value`"}
+
+
+def run_sharded(pkg, sb, device, dist_on, rehearsal, comm, steps, warmup):
+    """Times `steps` steps of the workload in `sb`; returns (dt, state of the last step)."""
+    from csv_simd_amd import sharded
+    state = {}
+    stepper = sharded.ShardedStep(device, gather_via_host=rehearsal) if (dist_on and comm is None) else None
+
+    def step():
+        if comm is not None:
+            r, st = comm.index_sharded(sb.ctx, sb.dbuf.data_ptr(), sb.n, sb.lo, sb.dtape.data_ptr(), sb.cap, 0,
+                                       sb.stream())
+            sb.check(r)
+            state.update(count=st.count, inq=st.in_quote_in, base=st.tape_index_base, total=st.total_entries,
+                         final=st.in_quote_final)
+        elif dist_on:
+            st, final, _ = stepper.run(lambda inq: sb.launch(inq, stepper.d_result),
+                                       lambda p: sb.reemit(p, stepper.d_result))
+            sb.check(final)
+            assert final.count == st.count
+            state.update(count=st.count, inq=st.in_quote_in, base=st.tape_index_base, total=st.total_entries,
+                         final=st.in_quote_final)
+        else:
+            w = sb.run_pass(0)
+            state.update(count=int(w[0]), inq=0, base=1, total=int(w[0]) + 1, final=(int(w[3]) >> 32) & 1)
+
+    dt = time_steps(step, steps, warmup, device, dist_on)
+    return dt, state
+
+
+def verify_everything(oracle, sb, state, dist_on, rank, world):
+    """Per-rank checks, then the job-level stitch check on rank 0; raises SystemExit on any mismatch."""
+    import torch.distributed as dist
+    res, facts = verify_rank(oracle, sb, state["inq"], state["count"], state["base"], state["total"], state["final"])
+    gathered = [None] * world
+    if dist_on:
+        dist.all_gather_object(gathered, (res, facts))
+    else:
+        gathered = [(res, facts)]
+    job_ok, reemits, total = verify_job([g[1] for g in gathered])
+    tape_ok = all(all(g[0].values()) for g in gathered)
+    out = {"tape": bool(tape_ok), "stitch": bool(job_ok), "reemits": int(reemits), "total_entries": int(total),
+           "how": "every rank: whole tape shard == torch restatement of the definition on the same bytes"
+                  + ("" if sb.q else " == closed form")
+                  + f"; {WINDOW_ENTRIES} entries either side of each shard boundary + checksum == CPU oracle; "
+                    "entering state == CPU generator; rank 0: bases / totals / final state chain"}
+    if not (tape_ok and job_ok):
+        out["failed"] = [{"rank": g[1]["rank"], **{k: v for k, v in g[0].items() if not v}} for g in gathered
+                         if not all(g[0].values())]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="64x31_noquote")
+    ap.add_argument("--workload", default="64x31_noquote",
+                    choices=["64x31_noquote", "64x31_q10", "16x32_noquote", "16x32_q10", "1024x4_dense"])
     ap.add_argument("--gib-per-gpu", type=float, default=8.0)
+    ap.add_argument("--skew", type=int, default=0,
+                    help="move every interior shard cut this many bytes to the right (SURVEY §8d: 777)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the other BASELINE shapes at N=1")
+    ap.add_argument("--no-verify", action="store_true", help="development only: the line then says verified: null")
+    ap.add_argument("--no-q10-check", action="store_true", help="skip the quoted, mid-row-cut verification leg")
+    ap.add_argument("--no-ingest", action="store_true")
     ap.add_argument("--native-rccl", action="store_true",
                     help="do the sharded step inside the C ABI (csvsimd_stage1_index_sharded: ncclAllGather "
                          "from C++) instead of torch.distributed.all_gather_into_tensor")
@@ -169,63 +417,44 @@ def main():
     # under torch.distributed.run the collective path is exercised even with a single rank
     dist_on = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("CSVSIMD_BENCH_FORCE_DIST") == "1"
     # rehearsal of the N > 1 control flow on a ONE-GPU box (dev only, never used by the driver): all
-    # ranks share cuda:0 and the records travel over gloo through the host instead of RCCL
+    # ranks share cuda:0 and the records travel over gloo through the host instead of RCCL; the stitch
+    # kernel and the re-emit launch are the real ones
     rehearsal = os.environ.get("CSVSIMD_BENCH_REHEARSAL") == "1"
     device = torch.device("cuda", 0 if rehearsal else local_rank)
     torch.cuda.set_device(device)
+    import torch.distributed as dist
     if dist_on:
-        import torch.distributed as dist
         if rehearsal:
             dist.init_process_group("gloo")
         else:
+            if "MASTER_ADDR" not in os.environ:   # CSVSIMD_BENCH_FORCE_DIST=1 without a launcher
+                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
             dist.init_process_group("nccl", device_id=device)
         dist.barrier()
     pkg = graft.load_package()
+    refuse_probe_environment(pkg)
     from csv_simd_amd import sharded
+    oracle = graft.load_oracle() if not (args.no_verify and args.no_cpu_baseline) else None
 
     shard_bytes = int(args.gib_per_gpu * 2**30)
-    sb = ShardBench(pkg, device, args.workload, shard_bytes, rank, world)
-    state = {}
+    sb = ShardBench(pkg, device, args.workload, shard_bytes, rank, world, args.skew)
 
     comm = None
     if dist_on and args.native_rccl:
-        import torch.distributed as dist
         uid = [pkg.Comm.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)   # the 128-byte RCCL id travels over the existing group
         comm = pkg.Comm(uid[0], rank, world, device.index)
 
-    def step():
-        if comm is not None:
-            r, st = comm.index_sharded(sb.ctx, sb.dbuf.data_ptr(), sb.n, sb.lo, sb.dtape.data_ptr(), sb.cap, 0,
-                                       torch.cuda.current_stream(device).cuda_stream)
-            sb.check(r)
-            state["count"], state["re"], state["total_entries"] = st.count, bool(st.in_quote_in), st.total_entries
-        elif dist_on and rehearsal:
-            def launch_via_host(inq):
-                sb.launch(inq)
-                sb.h_result.copy_(sb.d_result, non_blocking=True)
-                torch.cuda.current_stream(device).synchronize()
-            st, final, re = sharded.index_sharded(launch_via_host, sb.h_result)
-            sb.check(final)
-            state["count"], state["re"] = st.count, re
-            state["total_entries"] = st.total_entries
-        elif dist_on:
-            st, final, re = sharded.index_sharded(sb.launch, sb.d_result)
-            sb.check(final)
-            state["count"], state["re"] = st.count, re
-            state["total_entries"] = st.total_entries
-        else:
-            w = sb.run_pass(0)
-            state["count"], state["re"], state["total_entries"] = int(w[0]), False, int(w[0]) + 1
-
-    dt = time_steps(step, args.steps, args.warmup, device, dist_on)
+    dt, state = run_sharded(pkg, sb, device, dist_on, rehearsal, comm, args.steps, args.warmup)
     total_bytes = sb.total
     gib_s = total_bytes * args.steps / dt / 2**30
-    rows = total_bytes // (sb.cols * (sb.width + 1))
+    rows = total_bytes // sb.row
+
+    verified = None if args.no_verify else verify_everything(oracle, sb, state, dist_on, rank, world)
 
     # ---- roofline leg: the stage-1 kernel alone, HIP events on its own stream -------------------
     kern_ms = sb.ctx.stage1_time_device(sb.dbuf.data_ptr(), sb.n, sb.dtape.data_ptr(), sb.cap,
-                                        sb.d_result.data_ptr(), torch.cuda.current_stream(device).cuda_stream,
+                                        sb.d_result.data_ptr(), sb.stream(),
                                         warmup=2, iters=max(5, min(args.steps, 50)))
     achieved = sb.n / (kern_ms * 1e-3) / 1e9
     entries = state["count"]
@@ -233,7 +462,7 @@ def main():
     # shard doubles as the probe's output buffer: it is rewritten by the next launch anyway)
     probed = None
     if rank == 0 and sb.cap * 8 >= sb.n // 4:
-        s_ = torch.cuda.current_stream(device).cuda_stream
+        s_ = sb.stream()
         ms_r = sb.ctx.hbm_probe_device(sb.dbuf.data_ptr(), sb.n, sb.dtape.data_ptr(), 0, s_, 1, 5)
         ms_rw = sb.ctx.hbm_probe_device(sb.dbuf.data_ptr(), sb.n, sb.dtape.data_ptr(), 4, s_, 1, 5)
         probed = {"read_only_GBps": round(sb.n / (ms_r * 1e-3) / 1e9, 1),
@@ -243,7 +472,9 @@ def main():
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": load_traffic(args.workload, sb.n),
-        "kernel": "void csvsimd::stage1_kernel<true, 0, 0>(csvsimd::KernelArgs)", "kernel_ms": round(kern_ms, 4),
+        "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
+        "kernel": pkg.stage1_kernel_name(True), "kernels_per_launch": 1, "kernel_ms": round(kern_ms, 4),
+        "entry_point": "csvsimd_stage1_time_device -> launch_stage1 (the product library; probe builds refused)",
         "algorithmic_bytes_per_launch": sb.n,
         "read_plus_tape_write_GBps": round((sb.n + 8 * entries) / (kern_ms * 1e-3) / 1e9, 1),
         "probed_stream": probed,
@@ -256,14 +487,38 @@ def main():
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {sb.cols} cols x {sb.width}-byte fields, LF rows, "
                                f"{sb.n / 2**30:.3f} GiB per GPU (BASELINE config 4's per-GPU shard shape)",
-                   "bytes_per_gpu": sb.n, "total_bytes": total_bytes, "tape_entries": int(state["total_entries"]),
-                   "parallelism": f"chunk-sharded x{world}, one all-gather of shard descriptors"
+                   "bytes_per_gpu": sb.n, "total_bytes": total_bytes, "tape_entries": int(state["total"]),
+                   "skew": args.skew,
+                   "parallelism": f"chunk-sharded x{world}, one all-gather of shard descriptors, stitch + "
+                                  "conditional re-emit on the device"
                                   + (" (native RCCL from the C ABI)" if comm is not None else "")
                                   + (" [REHEARSAL: all ranks on one GPU, gloo]" if rehearsal else "")},
         "rows_indexed_per_s": round(rows * args.steps / dt, 1),
         "gib_per_s_per_gpu": round(gib_s / world, 3),
+        "verified": verified,
         "roofline": roofline,
     }
+
+    # ---- the quoted corpus, cut mid-row: the stitch is non-trivial and ranks re-emit -------------
+    failed = verified is not None and not (verified["tape"] and verified["stitch"])
+    if not args.no_q10_check and args.workload == "64x31_noquote" and not args.no_verify:
+        del sb.dtape, sb.dbuf
+        sbq = ShardBench(pkg, device, "64x31_q10", shard_bytes, rank, world, 777)
+        k = max(3, min(args.steps, 5))
+        dtq, stq = run_sharded(pkg, sbq, device, dist_on, rehearsal, comm, k, 1)
+        vq = verify_everything(oracle, sbq, stq, dist_on, rank, world)
+        failed = failed or not (vq["tape"] and vq["stitch"])
+        out["q10_skew_check"] = {"workload": "64x31_q10, interior cuts at i*N/world + 777 (mid-row)",
+                                 "ms_per_step": round(dtq / k * 1e3, 4), "steps": k,
+                                 "GiB/s": round(sbq.total * k / dtq / 2**30, 2), "verified": vq}
+        if rank == 0 and world == 1:
+            ms = sbq.ctx.stage1_time_device(sbq.dbuf.data_ptr(), sbq.n, sbq.dtape.data_ptr(), sbq.cap,
+                                            sbq.d_result.data_ptr(), sbq.stream(), 2, 5)
+            out["q10_skew_check"]["kernel_ms"] = round(ms, 4)
+            out["q10_skew_check"]["hbm_read_frac"] = round(sbq.n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+        del sbq
+        # the default corpus again, for the legs below (cpu baseline, ingest)
+        sb = ShardBench(pkg, device, args.workload, shard_bytes, rank, world, args.skew)
 
     if rank == 0 and world == 1:
         if not args.no_extra:
@@ -272,22 +527,30 @@ def main():
                 del_sb = ShardBench(pkg, device, name, 1 << 30, 0, 1)
                 r = sharded.result_from_words(del_sb.run_pass(0).tolist())
                 ms = del_sb.ctx.stage1_time_device(del_sb.dbuf.data_ptr(), del_sb.n, del_sb.dtape.data_ptr(),
-                                                   del_sb.cap, del_sb.d_result.data_ptr(),
-                                                   torch.cuda.current_stream(device).cuda_stream, 2, 10)
+                                                   del_sb.cap, del_sb.d_result.data_ptr(), del_sb.stream(), 2, 10)
                 extra[name] = {"bytes": del_sb.n, "entries": r.count, "kernel_ms": round(ms, 4),
                                "GiB/s": round(del_sb.n / (ms * 1e-3) / 2**30, 2),
-                               "hbm_read_frac": round(del_sb.n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+                               "hbm_read_frac": round(del_sb.n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                               "read_plus_tape_write_GBps": round((del_sb.n + 8 * r.count) / (ms * 1e-3) / 1e9, 1)}
+                if not args.no_verify:
+                    del_sb.run_pass(0)
+                    ok, _, _ = torch_reference_compare(del_sb, 0, r.count)
+                    extra[name]["verified"] = bool(ok and oracle_windows_compare(oracle, del_sb, 0, r.count))
+                    failed = failed or not extra[name]["verified"]
                 del del_sb
             out["other_workloads"] = extra
+        if not args.no_ingest:
+            out["ingest"] = ingest_leg(pkg, sb, 2 << 30)
+            failed = failed or not out["ingest"]["verified"]
         if not args.no_cpu_baseline:
-            oracle = graft.load_oracle()
             out["cpu_baseline"] = cpu_baseline(oracle, sb, 2 << 30)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist_on:
-        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+    if failed:
+        sys.exit("bench.py: VERIFICATION FAILED (see `verified` in the JSON line)")
 
 
 if __name__ == "__main__":

@@ -879,7 +879,16 @@ int csvsimd_stage1_time_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len,
             L.escape = (uint8_t)e;
         }
     }
+    if (const char* e = getenv("CSVSIMD_PROBE_EMIT_DELAY")) L.pace_emit_delay = atoi(e);
+    if (const char* e = getenv("CSVSIMD_PROBE_COUNT_PRIO")) L.pace_count_prio = atoi(e);
     if (L.debug_mode == 8) HIP_TRY(hipMemsetAsync(L.scratch_prof, 0, 17 * 8, s));
+    uint64_t* d_trace = nullptr;
+    const uint64_t trace_tiles = (len + 127 + CSVSIMD_TILE_BYTES - 1) / CSVSIMD_TILE_BYTES + 1;
+    if (L.debug_mode == 40) {  // per-tile timeline (scripts/trace_tiles.py): its own buffer, slots as in CSVSIMD_TRACE
+        HIP_TRY(hipMalloc((void**)&d_trace, (32 + trace_tiles * 8) * 8));
+        HIP_TRY(hipMemset(d_trace, 0, (32 + trace_tiles * 8) * 8));
+        L.scratch_prof = d_trace;
+    }
 #endif
     ctx->last_stream = s;
     ctx->launched = true;
@@ -902,6 +911,16 @@ int csvsimd_stage1_time_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len,
     }
     *avg_ms = (float)(total / iters);
 #ifdef CSVSIMD_DEV_PROBES
+    if (d_trace) {
+        std::vector<uint64_t> h(32 + trace_tiles * 8);
+        HIP_TRY(hipMemcpy(h.data(), d_trace, h.size() * 8, hipMemcpyDeviceToHost));
+        (void)hipFree(d_trace);
+        const char* path = getenv("CSVSIMD_PROBE_TRACE");
+        if (FILE* f = fopen(path ? path : "/tmp/csvsimd_trace.bin", "wb")) {
+            fwrite(h.data() + 32, 8, trace_tiles * 8, f);
+            fclose(f);
+        }
+    }
     if (L.debug_mode == 8) {  // print the per-phase stamps (summed over warm-up + timed launches)
         uint64_t h[17];
         HIP_TRY(hipMemcpy(h, L.scratch_prof, sizeof h, hipMemcpyDeviceToHost));

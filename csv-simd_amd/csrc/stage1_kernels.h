@@ -45,6 +45,7 @@ struct Stage1Launch {
     // optional: recorded immediately around the stage-1 kernel itself (bench roofline leg)
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     int debug_mode = 0;  // development probes (-DCSVSIMD_DEV_PROBES builds only; see stage1_kernel's DBG)
+    int pace_emit_delay = -1, pace_count_prio = -1;  // -1 = chosen from the launch size (launch_stage1)
     // dialect extension (csvsimd_dialect): the defaults are the reference's hard-wired dialect
     uint8_t delimiter = ',', quote = '"', escape = 0;
     uint32_t escape_in = 0;

@@ -493,9 +493,14 @@ __device__ __forceinline__ void dma_round(rsrc_t rsrc, u32 voff, uint4* stage) {
 // keep the machine scheduler from doing the same and the opaque asm anchors each round's results.
 template <int DIALECT>
 __device__ __forceinline__ void count_phase(rsrc_t rsrc, u32 lane, u32 w, const EdgeKeep& ek, uint4* stage0,
-                                            uint4* stage1, const StageAddr sa, RoundMasks (&m)[kRounds],
+                                            uint4* stage1, RoundMasks (&m)[kRounds],
                                             u32& carry, u32& cnt_a, u32& cnt_t, const DialectRegs& dr,
                                             u32 esc_carry) {
+    // derived from the lane id once per tile, behind a fence: computed once per kernel these two addresses stay
+    // live across the emit phase, where the register peak is (two tiles' masks: 64 VGPRs)
+    u32 l_ = lane;
+    asm volatile("" : "+v"(l_));
+    const StageAddr sa = stage_addr_of_lane(l_);
     // two images per wave: rounds r+1 and r+2 stream in (8 KiB per wave in flight, no VGPRs) while
     // round r is classified
     u32 voff = w * (u32)kSpanBytes + sa.src;  // one running VGPR, advanced per round
@@ -519,12 +524,14 @@ __device__ __forceinline__ void count_phase(rsrc_t rsrc, u32 lane, u32 w, const 
         // opaque: the eight read addresses (4 chunks x 2 images) are cheap to rebuild (one v_xad each) but,
         // hoisted out of the tile loop, they are what hipcc spills — and a scratch reload in here
         // waits for vmcnt(0), i.e. for the LDS-DMA prefetch of the next rounds (measured: -9 %)
-        // (round 2: the slot index itself is rebuilt from the lane id — always live — in every variant: kept
-        // across the tile loop it was the next value to be spilled, with the reload landing right here)
-        {
+        if (DIALECT == 2) {
+            // the escape variant is short of registers by its third mask: there even `rslot` gets spilled,
+            // so it is rebuilt from the lane id (always live) behind the same kind of fence
             u32 l = lane;
             asm volatile("" : "+v"(l));
             rslot = l * 4u + ((l >> 2) & 3u);
+        } else {
+            asm volatile("" : "+v"(rslot));
         }
 #pragma unroll
         for (int k = 0; k < kRows; ++k) stripe[k] = stage[rslot ^ (u32)k];
@@ -622,6 +629,9 @@ struct KernelArgs {
     // dialect variants only (DIALECT != 0)
     u32 delim, quote, escape;  // bytes; quote / escape 0 = feature off
     u32 escape_in;             // the first byte of the shard is escaped
+    // pacing knobs, chosen by the host from the launch size
+    u32 emit_delay;  // x 640 cycles of s_sleep between barrier B and the emit phase
+    u32 count_prio;  // 1: count phases run at s_setprio 3
 #ifdef CSVSIMD_DEV_PROBES
     u64* prof;  // timing build: per-phase stamp sums
 #endif
@@ -698,6 +708,7 @@ __device__ __forceinline__ void emit_span(const KernelArgs& args, const RoundMas
     const u64 flipall = wstate ? ~0ull : 0ull;
     const u64 span_off = args.base_off + span0 - args.lo;  // tape value of the span's byte 0
     u32 fill = 0;                                           // entries waiting in the window
+
     // wave-uniform by construction; tell the compiler (it arrives through LDS, i.e. in a VGPR)
     run = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(run >> 32)) << 32) |
           (u32)__builtin_amdgcn_readfirstlane((int)(u32)run);
@@ -708,10 +719,12 @@ __device__ __forceinline__ void emit_span(const KernelArgs& args, const RoundMas
         const u32 incl = wave_incl_scan_add(c);
         const u32 n_r = (u32)__builtin_amdgcn_readlane((int)incl, 63);
         const u32 excl = incl - c;
-        // opaque: seven hoisted copies of lane * 64 + r * 4096 would otherwise stay live across the tile loop
-        u32 l64 = lane * 64u;
-        asm volatile("" : "+v"(l64));
-        const u32 stripe_rel = (u32)r * kRoundBytes + l64;
+        // the round offset goes through an opaque SGPR: folded, hipcc keeps seven hoisted copies of
+        // lane * 64 + r * 4096 alive across the whole tile loop — exactly the registers whose absence makes
+        // it spill (round 1: 11 VGPRs to scratch; now none)
+        u32 roff = (u32)r * kRoundBytes;
+        asm volatile("" : "+s"(roff));
+        const u32 stripe_rel = roff + lane * 64u;
         if (fill + n_r > (u32)kCompCap) {
             wave_lds_fence();
             flush_window<NOSTORE>(args, comp, fill, run, span_off, lane);
@@ -799,7 +812,6 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
     const u32 t = threadIdx.x;
     const u32 lane = t & 63u;
     const u32 w = (u32)__builtin_amdgcn_readfirstlane((int)(t >> 6));
-    const StageAddr sa = stage_addr_of_lane(lane);
     u32 err = 0;  // wave 0 only
 
     // sharded re-emit: the true entering state sits in device memory (written by the stitch kernel
@@ -811,8 +823,8 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
         if (st == 0u) return;
         inq_in = 1u;
     }
-    const u32 epoch = (u32)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(
-                          &args.ctl->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & kEpochMask;
+    // requested now, consumed after the first count phase (the load's latency hides behind it)
+    const u32 epoch_v = __hip_atomic_load(&args.ctl->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     RoundMasks held[kRounds];
     Desc held_agg = {0, 0, 0}, held_before = {0, 0, 0};
@@ -829,9 +841,16 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
         prof[k] += now_ - stamp;                                      \
         stamp = now_;                                                 \
     }
+    // DBG bit 5 (with bit 3): wave 0 also leaves absolute stamps per tile in args.prof + 32:
+    // [tile * 8 + k], k = 0 ticket drawn, 1 counted, 2 past barrier A, 3 resolved, 4 past barrier B, 5 emitted,
+    // 6 = blockIdx | XCC id << 32
+#define CSVSIMD_TRACE(k, tid)                                                                          \
+    if ((DBG & 32) && w == 0 && lane == 0 && (tid) < args.num_tiles)                                   \
+        args.prof[32 + (u64)(tid) * 8 + (k)] = __builtin_amdgcn_s_memrealtime();
     if (DBG & 8) stamp = __builtin_amdgcn_s_memrealtime();
 #else
 #define CSVSIMD_STAMP(k)
+#define CSVSIMD_TRACE(k, tid)
 #endif
 
     for (u32 iter = 0;; ++iter) {
@@ -839,6 +858,7 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
         wg_barrier();  // barrier T
         CSVSIMD_STAMP(0)
         const u32 tile = (u32)__builtin_amdgcn_readfirstlane((int)s_tile);
+        CSVSIMD_TRACE(0, tile)
         const bool have_cur = tile < args.num_tiles;
         if (!have_cur && !have_held) break;
 
@@ -889,8 +909,13 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
                 }
                 cnt_a = acc & 1u;
             } else {
-                count_phase<DIALECT>(rsrc, lane, w, ek, s_stage[w], s_stage_b[w], sa, m, carry, cnt_a, cnt_t, dr,
+                // pacing (host-chosen per launch size, measured: DESIGN.md §4 "Pacing"): short launches give
+                // the phase that keeps HBM loads in flight the SIMD's issue priority over the partner
+                // workgroup's emit phase
+                if (args.count_prio) __builtin_amdgcn_s_setprio(3);
+                count_phase<DIALECT>(rsrc, lane, w, ek, s_stage[w], s_stage_b[w], m, carry, cnt_a, cnt_t, dr,
                                      esc_carry);
+                if (args.count_prio) __builtin_amdgcn_s_setprio(0);
             }
             const u32 wave_a = wave_sum(cnt_a);
             const u32 wave_t = wave_sum(cnt_t);
@@ -901,9 +926,12 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
             }
         }
         CSVSIMD_STAMP(1)  // count phase
+        CSVSIMD_TRACE(1, tile)
         wg_barrier();     // barrier A
         CSVSIMD_STAMP(2)
+        CSVSIMD_TRACE(2, tile)
 
+        const u32 epoch = (u32)__builtin_amdgcn_readfirstlane((int)epoch_v) & kEpochMask;
         if (have_cur) {
             // ---- tile aggregate; this wave's entering state/offset relative to the tile ------
 #pragma unroll
@@ -930,9 +958,13 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
             }
         }
         CSVSIMD_STAMP(3)  // publish + resolve (wave 0)
+        if (have_held) { CSVSIMD_TRACE(3, held_tile) }
         wg_barrier();     // barrier B
         CSVSIMD_STAMP(4)
+        if (have_held) { CSVSIMD_TRACE(4, held_tile) }
         if (EMIT && have_held) {
+            // pacing, long launches: ~2 us between barrier B and the emit phase (see DESIGN.md §4 "Pacing")
+            for (u32 z = 0; z < args.emit_delay; ++z) __builtin_amdgcn_s_sleep(10);
             const u32 pin = s_pin;
             // state entering this wave's span and tape index of its first entry
             const u32 wstate = pin ^ held_before.p;
@@ -940,6 +972,13 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
             const u64 span0 = (u64)held_tile * kTileBytes + (u64)w * kSpanBytes;
             emit_span<(DBG & 16) != 0>(args, held, lane, span0, wstate, run, reinterpret_cast<unsigned short*>(s_stage[w]));
         }
+        if (have_held) { CSVSIMD_TRACE(5, held_tile) }
+#ifdef CSVSIMD_DEV_PROBES
+        if ((DBG & 32) && w == 0 && lane == 0 && have_cur) {
+            args.prof[32 + (u64)tile * 8 + 6] = (u64)blockIdx.x | ((u64)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xf) << 32);
+            args.prof[32 + (u64)tile * 8 + 7] = (u64)(u32)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));  // HW_ID
+        }
+#endif
         // the tile counted in this iteration becomes the held one
         have_held = have_cur;
         held_tile = tile;
@@ -958,9 +997,11 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
     }
 #endif
 #undef CSVSIMD_STAMP
+#undef CSVSIMD_TRACE
 
     // ---- this workgroup is done; the last one to get here completes the launch --------------------
     if (w != 0) return;
+    const u32 epoch = (u32)__builtin_amdgcn_readfirstlane((int)epoch_v) & kEpochMask;
     Control* const ctl = args.ctl;
     if (err && lane == 0) atomicOr(&ctl->err, 1u);
     // every descriptor word this workgroup published (and its error flag) must have left before it
@@ -1288,6 +1329,13 @@ hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream) {
     a.quote = L.quote;
     a.escape = L.escape;
     a.escape_in = (L.escape && L.escape_in) ? 1u : 0u;
+    // Pacing.  Measured on MI355X (scripts/ab_variants.py, gpurun_out/r2b): on launches long enough to reach a
+    // steady state (64 tiles per workgroup at 8 GiB) a ~2 us pause before each emit phase is worth +3..5 %
+    // (1.80 -> 1.72-1.73 ms at 8 GiB) and count-phase priority costs 2 %; on short launches (8 tiles per
+    // workgroup at 1 GiB) the pause does nothing and the priority is worth +2 % (0.249 -> 0.243 ms).
+    const bool long_launch = L.len >= (2ull << 30);
+    a.emit_delay = L.pace_emit_delay >= 0 ? (u32)L.pace_emit_delay : (long_launch ? 8u : 0u);
+    a.count_prio = L.pace_count_prio >= 0 ? (u32)L.pace_count_prio : (long_launch ? 0u : 1u);
 #ifdef CSVSIMD_DEV_PROBES
     a.prof = L.scratch_prof;
 #endif
@@ -1307,6 +1355,7 @@ hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream) {
     CSVSIMD_PROBE_LAUNCH(7, false)
     CSVSIMD_PROBE_LAUNCH(16, true)
     CSVSIMD_PROBE_LAUNCH(8, true)
+    CSVSIMD_PROBE_LAUNCH(40, true)
     CSVSIMD_PROBE_LAUNCH(8, false)
 #endif
     if (launched) {

@@ -80,7 +80,10 @@ class ShardedStep:
         copy-out                       [final record | stitch | all records] -> pinned host, one synchronise
     """
 
-    def __init__(self, device: torch.device, group=None):
+    def __init__(self, device: torch.device, group=None, gather_via_host: bool = False):
+        # gather_via_host: development rehearsal on a one-GPU box (several ranks share the card, the group is
+        # gloo): the records make the trip through host memory; stitch kernel and re-emit launch are the real ones
+        self.gather_via_host = gather_via_host
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
@@ -117,7 +120,12 @@ class ShardedStep:
             err = e
             self.d_result.zero_()
             self.d_result[4] = 1  # error flag set: every rank will report the failure
-        dist.all_gather_into_tensor(self.d_all, self.d_result, group=self.group)
+        if self.gather_via_host:
+            h_all = torch.empty(8 * self.world, dtype=torch.int64)
+            dist.all_gather_into_tensor(h_all, self.d_result.cpu(), group=self.group)
+            self.d_all.copy_(h_all)
+        else:
+            dist.all_gather_into_tensor(self.d_all, self.d_result, group=self.group)
         if rehearsal:
             self.stitch_via_host(file_in_quote_in)
         else:

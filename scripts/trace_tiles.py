@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""dev tool (needs a -DCSVSIMD_DEV_PROBES library: CSVSIMD_LIB=.../libcsvsimd_probes.so): per-tile timeline of one
+stage-1 launch.  Prints when tiles start / finish, the phase durations by position in a workgroup's sequence of
+tiles, the start-up and the tail of the launch."""
+import os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft
+pkg = graft.load_package()
+name = sys.argv[1] if len(sys.argv) > 1 else "16x32_noquote"
+gib = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+cols, width, seed, q = pkg.WORKLOADS[name]
+n = pkg.workload_len(name, int(gib * 2**30))
+ctx = pkg.Context(0)
+dbuf = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+pkg.synth_fill_device(dbuf.data_ptr(), 0, n, cols, width, seed, q)
+cap = int(n // (width + 1) * 1.25) + 1024
+dtape = torch.empty(cap, dtype=torch.int64, device="cuda:0")
+dres = torch.zeros(8, dtype=torch.int64, device="cuda:0")
+ctx.reserve(n)
+s = torch.cuda.current_stream().cuda_stream
+path = os.environ.setdefault("CSVSIMD_PROBE_TRACE", "/tmp/csvsimd_trace.bin")
+os.environ["CSVSIMD_PROBE_MODE"] = "40"
+ms = ctx.stage1_time_device(dbuf.data_ptr(), n, dtape.data_ptr(), cap, dres.data_ptr(), s, 2, 3)
+tr = np.fromfile(path, dtype=np.uint64).reshape(-1, 8)
+T = pkg.tile_bytes()
+nt = (n + T - 1) // T
+tr = tr[:nt].astype(np.float64)
+t0 = tr[:, 0].min()
+us = (tr[:, :6] - t0) / 100.0          # s_memrealtime ticks at 100 MHz
+blk = (tr[:, 6].astype(np.uint64) & np.uint64(0xffffffff)).astype(np.int64)
+xcc = (tr[:, 6].astype(np.uint64) >> np.uint64(32)).astype(np.int64) & 0xf
+hwid = tr[:, 7].astype(np.uint64).astype(np.int64)
+print(f"== {name} {gib} GiB: {ms:.4f} ms (timing build), {nt} tiles, {len(set(blk))} workgroups drew tiles")
+end = us[:, 5].max()
+print(f"launch span by stamps: first ticket 0.0 .. last emit end {end:.1f} us")
+order = np.argsort(us[:, 0])
+# position of each tile within its workgroup's sequence
+pos = np.zeros(nt, dtype=np.int64)
+seen = {}
+for i in order:
+    pos[i] = seen.get(blk[i], 0)
+    seen[blk[i]] = pos[i] + 1
+names = ["count (ticket->counted)", "wait barrier A", "publish+resolve (lagged: next iteration)", "barrier B", "emit"]
+print("per-position medians (us):  pos  tiles  t_start  count  waitA  [A->resolved of THIS tile]  emit_dur  t_end")
+for p_ in range(int(pos.max()) + 1):
+    m = pos == p_
+    if m.sum() == 0:
+        continue
+    c = np.median(us[m, 1] - us[m, 0]); a = np.median(us[m, 2] - us[m, 1])
+    lag = np.median(us[m, 3] - us[m, 2]); em = np.median(us[m, 5] - us[m, 4])
+    print(f"   {p_:3d} {int(m.sum()):6d} {np.median(us[m, 0]):8.1f} {c:7.2f} {a:6.2f} {lag:8.2f} {em:8.2f} {np.median(us[m, 5]):8.1f}")
+fin = np.sort(us[:, 5])
+print("tape completion times (us): 1%% %.1f  50%% %.1f  90%% %.1f  99%% %.1f  max %.1f" % tuple(np.percentile(fin, [1, 50, 90, 99, 100])))
+cnt_end = np.sort(us[:, 1])
+print("count completion times (us): 1%% %.1f  50%% %.1f  90%% %.1f  99%% %.1f  max %.1f" % tuple(np.percentile(cnt_end, [1, 50, 90, 99, 100])))
+# bytes counted per 10-us bucket -> read rate over time
+b = np.histogram(us[:, 1], bins=np.arange(0, end + 10, 10))[0] * T / 10e-6 / 1e12
+print("read rate by 10-us bucket of count completion (TB/s):", " ".join(f"{x:.1f}" for x in b))
+b = np.histogram(us[:, 5], bins=np.arange(0, end + 10, 10))[0] * T / 10e-6 / 1e12
+print("emit rate by 10-us bucket of emit completion (input TB/s):", " ".join(f"{x:.1f}" for x in b))
+# which workgroups share a CU: HW_ID bits (gfx9 layout: cu_id [11:8], sh_id [12], se_id [15:13]) + xcc
+cu = (xcc << 8) | ((hwid >> 8) & 0xff)
+per_cu = {}
+for i in range(nt):
+    per_cu.setdefault(int(cu[i]), set()).add(int(blk[i]))
+sizes = np.bincount([len(v) for v in per_cu.values()])
+print("distinct (xcc, se/sh/cu) ids:", len(per_cu), " workgroups per id histogram:", sizes.tolist())
+pairs = [sorted(v) for v in per_cu.values() if len(v) == 2][:6]
+print("example co-resident workgroup pairs (blockIdx):", pairs)

@@ -622,3 +622,114 @@ def test_distinct_contexts_on_concurrent_host_threads(pkg, torch_cuda, oracle):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_launch_epochs_wrap_and_shard_sizes_change(pkg, torch_cuda, oracle):
+    # round 2: a launch is ONE kernel — the look-back words are tagged with a launch epoch instead of
+    # being zeroed, and the last workgroup leaves the control block ready for the next launch.  Drive one
+    # context through more than two wraps of the 10-bit epoch while the shard size keeps changing, so that
+    # words left behind by larger earlier launches (same epoch value, one wrap earlier) would be picked up
+    # if the wrap did not clear them.  Every launch: count, state and order-sensitive checksum vs the oracle.
+    torch = torch_cuda
+    c = pkg.Context(0)
+    try:
+        T = pkg.tile_bytes()
+        rng = np.random.default_rng(77)
+        big = random_csvish(rng, 9 * T + 4321, 0.03)
+        sizes = [big.size, 3 * T + 17, T // 2 + 5, 5 * T, 64, 0, 7 * T + 1]
+        dbuf = torch.from_numpy(big).cuda()
+        dtape = torch.empty(big.size + 8, dtype=torch.int64, device="cuda:0")
+        dres = torch.zeros(8, dtype=torch.int64, device="cuda:0")
+        want = {}
+        for n in sizes:
+            for inq in (0, 1):
+                e, q = oracle.scalar_index(big[:n], base_off=5, in_quote_in=inq)
+                want[(n, inq)] = (e.size, q, oracle.tape_checksum(e, 1))
+        from csv_simd_amd import sharded
+        launches = 2300
+        sums = torch.zeros((launches, 2), dtype=torch.int64, device="cuda:0")
+        recs = torch.zeros((launches, 8), dtype=torch.int64, device="cuda:0")
+        s = torch.cuda.current_stream().cuda_stream
+        plan = []
+        for i in range(launches):
+            n = sizes[(i * 5 + i // 7) % len(sizes)]
+            inq = (i // 3) & 1
+            plan.append((n, inq))
+            c.stage1_index_device_async(dbuf.data_ptr(), n, 5, inq, dtape.data_ptr(), dtape.numel(),
+                                        recs[i].data_ptr(), s)
+            if i % 23 == 0 or i > launches - 40:   # the checksum reads the record, so it synchronises: sampled
+                torch.cuda.synchronize()
+                cnt = int(recs[i, 0])
+                pkg.tape_checksum_device(dtape.data_ptr(), cnt, 1, sums[i].data_ptr(), s)
+        torch.cuda.synchronize()
+        recs_h, sums_h = recs.cpu().tolist(), sums.cpu().tolist()
+        for i, (n, inq) in enumerate(plan):
+            r = sharded.result_from_words(recs_h[i])
+            cnt, q, chk = want[(n, inq)]
+            assert (r.count, r.in_quote_out, r.error, r.written) == (cnt, q, 0, cnt), (i, n, inq)
+            if i % 23 == 0 or i > launches - 40:
+                assert tuple(int(x) & (2**64 - 1) for x in sums_h[i]) == chk, (i, n, inq)
+    finally:
+        c.close()
+
+
+def test_device_stitch_and_reemit_three_shards_one_gpu(pkg, torch_cuda, oracle):
+    # the N > 1 step as bench.py / csvsimd_stage1_index_sharded drive it, with three shards on ONE GPU and
+    # a device-to-device copy standing in for the all-gather: speculative pass -> records side by side in
+    # device memory -> stitch kernel -> re-emit launch that reads its entering state from device memory.
+    # No host value is used between the first launch and the final copy-out.
+    torch = torch_cuda
+    from csv_simd_amd import sharded
+    rng = np.random.default_rng(5150)
+    T = pkg.tile_bytes()
+    for trial, p_quote in enumerate((0.0, 0.02, 0.11, 0.5)):
+        n = 3 * T + 1000 * trial + 99
+        d = random_csvish(rng, n, p_quote)
+        cuts = [0, T + 777, 2 * T + 13, n]
+        dbuf = torch.from_numpy(d).cuda()
+        world = 3
+        ctxs = [pkg.Context(0) for _ in range(world)]
+        try:
+            tapes = [torch.full((n + 8,), -1, dtype=torch.int64, device="cuda:0") for _ in range(world)]
+            d_all = torch.zeros(8 * world, dtype=torch.int64, device="cuda:0")
+            d_st = torch.zeros((world, sharded.STITCH_WORDS), dtype=torch.int64, device="cuda:0")
+            d_fin = torch.zeros((world, 8), dtype=torch.int64, device="cuda:0")
+            s = torch.cuda.current_stream().cuda_stream
+            for file_inq in (0, 1):
+                for r in range(world):
+                    lo, hi = cuts[r], cuts[r + 1]
+                    tapes[r].fill_(-1)
+                    ctxs[r].stage1_index_device_async(dbuf.data_ptr() + lo, hi - lo, lo, 0, tapes[r].data_ptr(),
+                                                      tapes[r].numel(), d_fin[r].data_ptr(), s)
+                    d_all[8 * r: 8 * r + 8].copy_(d_fin[r])          # "all-gather"
+                spec = [t.clone() for t in tapes]
+                for r in range(world):
+                    lo, hi = cuts[r], cuts[r + 1]
+                    pkg.stitch_shards_device_async(d_all.data_ptr(), world, r, file_inq, d_st[r].data_ptr(), s)
+                    ctxs[r].stage1_reemit_device_async(dbuf.data_ptr() + lo, hi - lo, lo, d_st[r].data_ptr(),
+                                                       tapes[r].data_ptr(), tapes[r].numel(), d_fin[r].data_ptr(), s)
+                torch.cuda.synchronize()
+                want, q_final = oracle.scalar_index(d, in_quote_in=file_inq)
+                got, state, base = [], file_inq, 1
+                recs = [sharded.result_from_words(d_all[8 * r: 8 * r + 8].cpu().tolist()) for r in range(world)]
+                for r in range(world):
+                    lo, hi = cuts[r], cuts[r + 1]
+                    st = sharded.stitch_from_words(d_st[r].cpu().tolist())
+                    host_st = pkg.stitch_shards(recs, r, file_inq)     # device stitch == host stitch
+                    for f in ("in_quote_in", "in_quote_final", "count", "tape_index_base", "total_entries", "error"):
+                        assert getattr(st, f) == getattr(host_st, f), (f, r)
+                    e, q = oracle.scalar_index(d[lo:hi], base_off=lo, in_quote_in=state)
+                    fin = sharded.result_from_words(d_fin[r].cpu().tolist())
+                    assert (st.in_quote_in, st.count, st.tape_index_base) == (state, e.size, base)
+                    assert (fin.count, fin.in_quote_out, fin.error) == (e.size, q, 0)
+                    if state == 0:   # the re-emit launch must have been a no-op: tape untouched, bit for bit
+                        assert torch.equal(tapes[r], spec[r])
+                    # (entries of the speculative pass beyond a shorter re-emitted tape stay where they were)
+                    assert bool((tapes[r][max(fin.count, recs[r].count):] == -1).all())
+                    got.append(tapes[r][: fin.count].cpu().numpy().view(np.uint64))
+                    state, base = q, base + e.size
+                assert np.array_equal(np.concatenate(got), want)
+                assert st.total_entries == want.size + 1 and st.in_quote_final == q_final
+        finally:
+            for c in ctxs:
+                c.close()
