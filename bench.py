@@ -68,15 +68,17 @@ class ShardBench:
     file of world * n bytes (n = whole rows); with skew every interior cut moves `skew` bytes to the right,
     i.e. into the middle of a row ("deliberately misaligned variant")."""
 
-    def __init__(self, pkg, device, workload, shard_bytes, rank, world, skew=0):
+    def __init__(self, pkg, device, workload, shard_bytes, rank, world, skew=0, cuts=None):
         self.pkg, self.device, self.workload = pkg, device, workload
         cols, width, seed, q = pkg.WORKLOADS[workload]
         self.cols, self.width, self.seed, self.q = cols, width, seed, q
         self.row = cols * (width + 1)
         per = (shard_bytes // self.row) * self.row
         self.total = world * per
-        cut = lambda i: 0 if i <= 0 else self.total if i >= world else i * per + skew  # noqa: E731
-        self.lo, self.hi = cut(rank), cut(rank + 1)
+        if cuts is None:
+            cuts = [0] + [i * per + skew for i in range(1, world)] + [self.total]
+        assert len(cuts) == world + 1 and cuts[0] == 0 and cuts[-1] == self.total
+        self.lo, self.hi = cuts[rank], cuts[rank + 1]
         self.n = self.hi - self.lo
         self.rank, self.world, self.skew = rank, world, skew
         self.dbuf = torch.empty(self.n, dtype=torch.uint8, device=device)
@@ -237,6 +239,34 @@ def verify_job(all_facts):
     return ok, sum(f["reemit"] for f in all_facts), base
 
 
+def mid_row_cuts(oracle, pkg, workload, shard_bytes, world):
+    """Shard cuts for the quoted corpus that are GUARANTEED to exercise both outcomes of the stitch: every
+    interior cut lies in the middle of a row; odd cuts lie inside a quoted field (that rank's speculation is
+    wrong and it re-emits), even cuts 777 bytes into the row or the next byte outside a quoted field (SURVEY
+    §8d's "+777").  Computed from the CPU generator, identically on every rank."""
+    cols, width, seed, q = pkg.WORKLOADS[workload]
+    row = cols * (width + 1)
+    per = (shard_bytes // row) * row
+    cuts = [0]
+    for i in range(1, world):
+        r0 = i * per
+        inside = np.zeros(row, dtype=bool)
+        k = 0
+        while not inside.any():                      # a row without a quoted field: take the next one
+            line = oracle.synth(r0 + k * row, row, cols, width, seed, q)
+            inside = (np.cumsum(line == 0x22) & 1).astype(bool)   # inclusive prefix parity: in-string bytes
+            k += 1
+        r0 += (k - 1) * row
+        if i % 2 == 1:
+            off = int(np.flatnonzero(inside)[min(5, int(inside.sum()) - 1)])
+        else:
+            off = 777
+            while inside[off - 1]:                   # the state entering byte `off` is that of byte off - 1
+                off += 1
+        cuts.append(r0 + off)
+    return cuts + [world * per]
+
+
 def time_steps(step, steps, warmup, device, dist_on):
     import torch.distributed as dist
     for _ in range(warmup):
@@ -364,7 +394,17 @@ def run_sharded(pkg, sb, device, dist_on, rehearsal, comm, steps, warmup):
 def verify_everything(oracle, sb, state, dist_on, rank, world):
     """Per-rank checks, then the job-level stitch check on rank 0; raises SystemExit on any mismatch."""
     import torch.distributed as dist
-    res, facts = verify_rank(oracle, sb, state["inq"], state["count"], state["base"], state["total"], state["final"])
+    if os.environ.get("CSVSIMD_BENCH_REHEARSAL") == "1" and dist_on:
+        # development rehearsal only (all ranks share ONE GPU): the ranks verify one after the other — three or
+        # more processes running torch's synchronising ops (nonzero, equal) on one card at once were seen to stall
+        for r in range(world):
+            if r == rank:
+                res, facts = verify_rank(oracle, sb, state["inq"], state["count"], state["base"], state["total"],
+                                         state["final"])
+                torch.cuda.synchronize()
+            dist.barrier()
+    else:
+        res, facts = verify_rank(oracle, sb, state["inq"], state["count"], state["base"], state["total"], state["final"])
     gathered = [None] * world
     if dist_on:
         dist.all_gather_object(gathered, (res, facts))
@@ -402,6 +442,9 @@ def main():
                     help="do the sharded step inside the C ABI (csvsimd_stage1_index_sharded: ncclAllGather "
                          "from C++) instead of torch.distributed.all_gather_into_tensor")
     args = ap.parse_args()
+    if os.environ.get("CSVSIMD_BENCH_WATCHDOG"):   # development: where is a stuck run stuck?
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["CSVSIMD_BENCH_WATCHDOG"]), exit=True)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -503,12 +546,15 @@ def main():
     failed = verified is not None and not (verified["tape"] and verified["stitch"])
     if not args.no_q10_check and args.workload == "64x31_noquote" and not args.no_verify:
         del sb.dtape, sb.dbuf
-        sbq = ShardBench(pkg, device, "64x31_q10", shard_bytes, rank, world, 777)
+        cuts = mid_row_cuts(oracle, pkg, "64x31_q10", shard_bytes, world)
+        sbq = ShardBench(pkg, device, "64x31_q10", shard_bytes, rank, world, cuts=cuts)
         k = max(3, min(args.steps, 5))
         dtq, stq = run_sharded(pkg, sbq, device, dist_on, rehearsal, comm, k, 1)
         vq = verify_everything(oracle, sbq, stq, dist_on, rank, world)
         failed = failed or not (vq["tape"] and vq["stitch"])
-        out["q10_skew_check"] = {"workload": "64x31_q10, interior cuts at i*N/world + 777 (mid-row)",
+        out["q10_skew_check"] = {"workload": "64x31_q10, interior cuts mid-row: odd ones inside a quoted field (that rank "
+                                             "must re-emit), even ones at +777 outside a string",
+                                 "cuts": cuts,
                                  "ms_per_step": round(dtq / k * 1e3, 4), "steps": k,
                                  "GiB/s": round(sbq.total * k / dtq / 2**30, 2), "verified": vq}
         if rank == 0 and world == 1:

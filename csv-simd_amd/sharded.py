@@ -55,7 +55,8 @@ def words_from_result(r: ShardResult) -> List[int]:
             r.error | (r.escape_out << 32), r.written, 0, 0]
 
 
-STITCH_WORDS = 5  # csvsimd_stitch as int64 words: in_quote_in | in_quote_final << 32, count, base, total, error
+STITCH_WORDS = 8  # csvsimd_stitch as int64 words (5 used: in_quote_in | in_quote_final << 32, count, base, total,
+                  # error), padded so that every part of a step's device block starts on a 64-byte boundary
 
 
 def stitch_from_words(h) -> Stitch:
@@ -89,7 +90,7 @@ class ShardedStep:
         self.world = dist.get_world_size(group)
         self.device = device
         w = self.world
-        # one device block so a single copy carries everything the host wants: [mine 8 | stitch 5 | all 8w]
+        # one device block so a single copy carries everything the host wants: [mine 8 | stitch 8 | all 8w]
         self.d_block = torch.zeros(8 + STITCH_WORDS + 8 * w, dtype=torch.int64, device=device)
         self.d_result = self.d_block[0:8]
         self.d_stitch = self.d_block[8:8 + STITCH_WORDS]
@@ -105,7 +106,7 @@ class ShardedStep:
         results = [result_from_words(host[8 * i: 8 * i + 8]) for i in range(self.world)]
         st = stitch_shards(results, self.rank, file_in_quote_in)
         self.d_stitch.copy_(torch.tensor([st.in_quote_in | (st.in_quote_final << 32), st.count, st.tape_index_base,
-                                          st.total_entries, st.error], dtype=torch.int64))
+                                          st.total_entries, st.error, 0, 0, 0], dtype=torch.int64))
 
     def run(self, launch: Callable[[int], None], reemit: Callable[[int], None], file_in_quote_in: int = 0,
             rehearsal: bool = False) -> Tuple[Stitch, ShardResult, List[ShardResult]]:
