@@ -94,6 +94,13 @@ class _Chunk(C.Structure):
     _fields_ = [("id", C.c_uint8), ("start", C.c_uint64), ("end", C.c_uint64), ("record_cnt", C.c_uint32)]
 
 
+class FreqStatus(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("n_distinct", C.c_uint64), ("collisions", C.c_uint64),
+                ("overflow", C.c_uint64)]
+
+
+SEARCH_EQUALS, SEARCH_STARTS_WITH, SEARCH_CONTAINS = 0, 1, 2
+
 # every symbol include/csvsimd.h declares: (restype, argtypes)
 _u64p = C.POINTER(C.c_uint64)
 _PROTOTYPES = {
@@ -158,8 +165,20 @@ _PROTOTYPES = {
     "csvsimd_tape_bytes": (C.POINTER(C.c_uint8), [C.c_void_p, _u64p]),
     "csvsimd_tape_field_spans_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32, C.c_uint64,
                                                   C.c_uint64, C.c_void_p, C.c_void_p, _u64p, C.c_void_p]),
-    "csvsimd_gather_fields_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
+    "csvsimd_gather_fields_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
                                                C.c_uint32, C.c_void_p, C.c_void_p]),
+    "csvsimd_chunk_field_spans_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(_Chunk),
+                                                   C.c_uint32, C.c_void_p, C.c_void_p, _u64p, C.c_void_p]),
+    "csvsimd_column_frequency_scratch_bytes": (C.c_uint64, [C.c_uint64]),
+    "csvsimd_column_frequency_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int,
+                                                  C.POINTER(_Chunk), C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64,
+                                                  C.c_void_p, C.c_uint64, C.POINTER(FreqStatus), C.c_void_p]),
+    "csvsimd_column_search_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int,
+                                               C.POINTER(_Chunk), C.c_uint32, C.c_char_p, C.c_uint32, C.c_int,
+                                               C.c_void_p, _u64p, C.c_void_p]),
+    "csvsimd_bitmap_select_scratch_bytes": (C.c_uint64, [C.c_uint64]),
+    "csvsimd_bitmap_select_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
+                                               _u64p, C.c_void_p]),
     "csvsimd_synth_fill_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
                                             C.c_uint64, C.c_uint32, C.c_void_p]),
     "csvsimd_tape_checksum_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
@@ -507,10 +526,69 @@ def tape_record_spans_device(dindex: int, index_len: int, field_cnt: int, new_li
     return n.value
 
 
-def gather_fields_device(dbytes: int, d_begin: int, d_end: int, n_records: int, d_dst: int, stride: int,
-                         d_len: int = 0, stream: int = 0) -> None:
-    _check(lib().csvsimd_gather_fields_device(dbytes, d_begin, d_end, n_records, d_dst, stride, d_len or None,
+def gather_fields_device(dbytes: int, bytes_len: int, d_begin: int, d_end: int, n_records: int, d_dst: int,
+                         stride: int, d_len: int = 0, stream: int = 0) -> None:
+    _check(lib().csvsimd_gather_fields_device(dbytes, bytes_len, d_begin, d_end, n_records, d_dst, stride,
+                                              d_len or None, stream or None))
+
+
+def _chunk(c) -> _Chunk:
+    """(id, start, end, record_cnt) as Tape.chunks returns it -> csvsimd_chunk"""
+    return c if isinstance(c, _Chunk) else _Chunk(*c)
+
+
+def chunk_field_spans_device(dindex: int, index_len: int, field_cnt: int, new_line: str, chunk, field_idx: int,
+                             d_begin: int, d_end: int, stream: int = 0) -> int:
+    """Bulk seek_field over one csvsimd_chunk (Tape::chunks' unit of parallel work); returns its record count."""
+    n = C.c_uint64()
+    ch = _chunk(chunk)
+    _check(lib().csvsimd_chunk_field_spans_device(dindex, index_len, field_cnt,
+                                                  NEWLINE_CRLF if new_line == "CRLF" else NEWLINE_LF, C.byref(ch),
+                                                  field_idx, d_begin or None, d_end or None, C.byref(n),
+                                                  stream or None))
+    return n.value
+
+
+def column_frequency_scratch_bytes(table_slots: int) -> int:
+    return lib().csvsimd_column_frequency_scratch_bytes(table_slots)
+
+
+def column_frequency_device(ctx: "Context", dbytes: int, dindex: int, index_len: int, field_cnt: int, new_line: str,
+                            chunks, field_idx: int, d_scratch: int, table_slots: int, d_entries: int,
+                            entries_cap: int, stream: int = 0) -> FreqStatus:
+    """Exact frequency count of a column over the given chunks; entries (first_record, begin, end, count as
+    4 x uint64) land in d_entries, status.n_distinct of them."""
+    arr = (_Chunk * len(chunks))(*[_chunk(c) for c in chunks])
+    st = FreqStatus()
+    _check(lib().csvsimd_column_frequency_device(ctx._h, dbytes, dindex, index_len, field_cnt,
+                                                 NEWLINE_CRLF if new_line == "CRLF" else NEWLINE_LF, arr, len(chunks),
+                                                 field_idx, d_scratch, table_slots, d_entries or None, entries_cap,
+                                                 C.byref(st), stream or None))
+    return st
+
+
+def column_search_device(ctx: "Context", dbytes: int, dindex: int, index_len: int, field_cnt: int, new_line: str,
+                         chunk, field_idx: int, needle: bytes, mode: int, d_bitmap: int, stream: int = 0) -> int:
+    """Bitmap of the chunk's records whose field equals / starts with / contains `needle`; returns the match count."""
+    n = C.c_uint64()
+    ch = _chunk(chunk)
+    _check(lib().csvsimd_column_search_device(ctx._h, dbytes, dindex, index_len, field_cnt,
+                                              NEWLINE_CRLF if new_line == "CRLF" else NEWLINE_LF, C.byref(ch),
+                                              field_idx, needle, len(needle), mode, d_bitmap or None, C.byref(n),
                                               stream or None))
+    return n.value
+
+
+def bitmap_select_scratch_bytes(n_rows: int) -> int:
+    return lib().csvsimd_bitmap_select_scratch_bytes(n_rows)
+
+
+def bitmap_select_device(d_bitmap: int, n_rows: int, first_record: int, d_scratch: int, d_out: int, out_cap: int,
+                         stream: int = 0) -> int:
+    n = C.c_uint64()
+    _check(lib().csvsimd_bitmap_select_device(d_bitmap or None, n_rows, first_record, d_scratch or None, d_out or None,
+                                              out_cap, C.byref(n), stream or None))
+    return n.value
 
 
 # ---- device utilities (raw device addresses; torch tensors' .data_ptr() fit) --------------------

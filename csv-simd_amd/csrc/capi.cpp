@@ -127,6 +127,7 @@ struct csvsimd_ctx {
     uint32_t max_blocks = 0;
     int n_cus = 0;
     csvsimd_shard_result* d_result = nullptr;  // for the synchronous entry points
+    void* d_small = nullptr;                   // 1 KiB: search needle + match counter (consumer entry points)
     // host-buffer path (csvsimd_stage1_index): two-slot pipeline, allocated on first use
     static constexpr uint64_t kChunk = 32ull << 20;  // bytes per slot
     bool pipe_ready = false;                   // every resource below exists
@@ -195,6 +196,7 @@ int csvsimd_ctx_create(int device, csvsimd_ctx** out) {
     const int per_cu = csvsimd::stage1_max_blocks_per_cu();
     ctx->max_blocks = (uint32_t)(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256) * (uint32_t)per_cu;
     HIP_TRY(hipMalloc((void**)&ctx->d_result, sizeof(csvsimd_shard_result)));
+    HIP_TRY(hipMalloc(&ctx->d_small, 1024));
     *out = ctx.release();
     const int rc = csvsimd_ctx_reserve(*out, 1ull << 30);
     if (rc != CSVSIMD_OK) {
@@ -210,6 +212,7 @@ void csvsimd_ctx_destroy(csvsimd_ctx* ctx) {
     (void)hipDeviceSynchronize();  // nothing of this context may still be in flight
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->d_result) (void)hipFree(ctx->d_result);
+    if (ctx->d_small) (void)hipFree(ctx->d_small);
     for (int k = 0; k < 2; ++k) {
         if (ctx->pin_in[k]) (void)hipHostFree(ctx->pin_in[k]);
         if (ctx->pin_out[k]) (void)hipHostFree(ctx->pin_out[k]);
@@ -730,21 +733,37 @@ int csvsimd_tape_checksum_device(const void* dtape, uint64_t n, uint64_t first_i
     return CSVSIMD_OK;
 }
 
+// row_size / record count of a tape (TapeCore::init, src/tape.rs:315-347); CSVSIMD_OK or the reference's error
+static int tape_shape(uint64_t index_len, uint32_t field_cnt, int new_line, uint64_t* row_size, uint64_t* record_cnt) {
+    if (field_cnt == 0) return CSVSIMD_ERR_INVALID_ARG;
+    *row_size = (uint64_t)field_cnt + (new_line == CSVSIMD_NEWLINE_CRLF ? 1 : 0);  // = record jump size
+    if (index_len == 0) return CSVSIMD_ERR_INVALID_STATE;
+    if ((index_len - 1) % *row_size != 0) return CSVSIMD_ERR_INVALID_CSV_FORMAT;
+    *record_cnt = (index_len - 1) / *row_size;  // includes the header row
+    return CSVSIMD_OK;
+}
+
+// a chunk must consist of whole rows of this tape (Tape::chunks, src/tape.rs:95-140, produces nothing else)
+static int chunk_rows(const csvsimd_chunk* c, uint64_t index_len, uint64_t row_size, uint64_t* n_rows) {
+    if (!c || c->end < c->start || c->start % row_size || c->end % row_size || c->end > index_len - 1 || c->start == 0)
+        return CSVSIMD_ERR_INVALID_ARG;  // start == 0 would be the header row, whose first field the tape cannot address
+    *n_rows = (c->end - c->start) / row_size;
+    return CSVSIMD_OK;
+}
+
 int csvsimd_tape_field_spans_device(const void* dindex, uint64_t index_len, uint32_t field_cnt, int new_line,
                                     uint32_t field_idx, uint64_t first_record, uint64_t n_records, void* d_begin,
                                     void* d_end, uint64_t* n_valid, void* hip_stream) {
-    if (!dindex || !n_valid || field_cnt == 0 || (n_records && (!d_begin || !d_end))) return CSVSIMD_ERR_INVALID_ARG;
+    if (!dindex || !n_valid || (n_records && (!d_begin || !d_end))) return CSVSIMD_ERR_INVALID_ARG;
     if (csvsimd_device_count() <= 0) return CSVSIMD_ERR_NO_DEVICE;
-    // TapeCore::init (src/tape.rs:315-347)
-    const uint64_t row_size = (uint64_t)field_cnt + (new_line == CSVSIMD_NEWLINE_CRLF ? 1 : 0);
-    if (index_len == 0) return CSVSIMD_ERR_INVALID_STATE;
-    if ((index_len - 1) % row_size != 0) return CSVSIMD_ERR_INVALID_CSV_FORMAT;
-    const uint64_t record_cnt = (index_len - 1) / row_size;  // includes the header row
+    uint64_t row_size = 0, record_cnt = 0;
+    const int rc = tape_shape(index_len, field_cnt, new_line, &row_size, &record_cnt);
+    if (rc != CSVSIMD_OK) return rc;
     *n_valid = 0;
     // seek_field: Ok(None) when record_idx + 1 >= record_cnt or field_idx >= field_cnt
     if (field_idx >= field_cnt || first_record + 1 >= record_cnt) return CSVSIMD_OK;
     const uint64_t n = std::min<uint64_t>(n_records, record_cnt - 1 - first_record);
-    HIP_TRY(csvsimd::launch_field_spans(dindex, row_size, field_idx, 1, first_record, n, d_begin, d_end,
+    HIP_TRY(csvsimd::launch_chunk_spans(dindex, (first_record + 1) * row_size, row_size, field_idx, 1, n, d_begin, d_end,
                                         (hipStream_t)hip_stream));
     *n_valid = n;
     return CSVSIMD_OK;
@@ -753,28 +772,132 @@ int csvsimd_tape_field_spans_device(const void* dindex, uint64_t index_len, uint
 int csvsimd_tape_record_spans_device(const void* dindex, uint64_t index_len, uint32_t field_cnt, int new_line,
                                      uint64_t first_record, uint64_t n_records, void* d_begin, void* d_end,
                                      uint64_t* n_valid, void* hip_stream) {
-    if (!dindex || !n_valid || field_cnt == 0 || (n_records && (!d_begin || !d_end))) return CSVSIMD_ERR_INVALID_ARG;
+    if (!dindex || !n_valid || (n_records && (!d_begin || !d_end))) return CSVSIMD_ERR_INVALID_ARG;
     if (csvsimd_device_count() <= 0) return CSVSIMD_ERR_NO_DEVICE;
-    const uint64_t row_size = (uint64_t)field_cnt + (new_line == CSVSIMD_NEWLINE_CRLF ? 1 : 0);  // = record jump size
-    if (index_len == 0) return CSVSIMD_ERR_INVALID_STATE;
-    if ((index_len - 1) % row_size != 0) return CSVSIMD_ERR_INVALID_CSV_FORMAT;
-    const uint64_t record_cnt = (index_len - 1) / row_size;
+    uint64_t row_size = 0, record_cnt = 0;
+    const int rc = tape_shape(index_len, field_cnt, new_line, &row_size, &record_cnt);
+    if (rc != CSVSIMD_OK) return rc;
     *n_valid = 0;
     if (first_record + 1 >= record_cnt) return CSVSIMD_OK;  // seek_record: Ok(None)
     const uint64_t n = std::min<uint64_t>(n_records, record_cnt - 1 - first_record);
-    HIP_TRY(csvsimd::launch_field_spans(dindex, row_size, 0, field_cnt, first_record, n, d_begin, d_end,
+    HIP_TRY(csvsimd::launch_chunk_spans(dindex, (first_record + 1) * row_size, row_size, 0, field_cnt, n, d_begin, d_end,
                                         (hipStream_t)hip_stream));
     *n_valid = n;
     return CSVSIMD_OK;
 }
 
-int csvsimd_gather_fields_device(const void* dbytes, const void* d_begin, const void* d_end, uint64_t n_records,
-                                 void* d_dst, uint32_t stride, void* d_len, void* hip_stream) {
+int csvsimd_chunk_field_spans_device(const void* dindex, uint64_t index_len, uint32_t field_cnt, int new_line,
+                                     const csvsimd_chunk* chunk, uint32_t field_idx, void* d_begin, void* d_end,
+                                     uint64_t* n_records, void* hip_stream) {
+    if (!dindex || !n_records) return CSVSIMD_ERR_INVALID_ARG;
+    if (csvsimd_device_count() <= 0) return CSVSIMD_ERR_NO_DEVICE;
+    uint64_t row_size = 0, record_cnt = 0, n = 0;
+    int rc = tape_shape(index_len, field_cnt, new_line, &row_size, &record_cnt);
+    if (rc == CSVSIMD_OK) rc = chunk_rows(chunk, index_len, row_size, &n);
+    if (rc != CSVSIMD_OK) return rc;
+    if (field_idx >= field_cnt || (n && (!d_begin || !d_end))) return CSVSIMD_ERR_INVALID_ARG;
+    HIP_TRY(csvsimd::launch_chunk_spans(dindex, chunk->start, row_size, field_idx, 1, n, d_begin, d_end,
+                                        (hipStream_t)hip_stream));
+    *n_records = n;
+    return CSVSIMD_OK;
+}
+
+int csvsimd_gather_fields_device(const void* dbytes, uint64_t bytes_len, const void* d_begin, const void* d_end,
+                                 uint64_t n_records, void* d_dst, uint32_t stride, void* d_len, void* hip_stream) {
     if ((n_records && (!dbytes || !d_begin || !d_end || !d_dst)) || stride == 0) return CSVSIMD_ERR_INVALID_ARG;
     if (csvsimd_device_count() <= 0) return CSVSIMD_ERR_NO_DEVICE;
-    HIP_TRY(csvsimd::launch_gather_fields(dbytes, d_begin, d_end, n_records, d_dst, stride, d_len,
+    HIP_TRY(csvsimd::launch_gather_fields(dbytes, bytes_len, d_begin, d_end, n_records, d_dst, stride, d_len,
                                           (hipStream_t)hip_stream));
     return CSVSIMD_OK;
+}
+
+uint64_t csvsimd_column_frequency_scratch_bytes(uint64_t table_slots) { return table_slots * 32 + 64; }
+
+int csvsimd_column_frequency_device(csvsimd_ctx* ctx, const void* dbytes, const void* dindex, uint64_t index_len,
+                                    uint32_t field_cnt, int new_line, const csvsimd_chunk* chunks, uint32_t n_chunks,
+                                    uint32_t field_idx, void* d_scratch, uint64_t table_slots, void* d_entries,
+                                    uint64_t entries_cap, csvsimd_freq_status* status, void* hip_stream) {
+    if (!ctx || !dbytes || !dindex || !chunks || !n_chunks || !d_scratch || !status || (entries_cap && !d_entries))
+        return CSVSIMD_ERR_INVALID_ARG;
+    if (table_slots < 64 || (table_slots & (table_slots - 1)) || ((uintptr_t)d_scratch & 15) || ((uintptr_t)d_entries & 7))
+        return CSVSIMD_ERR_INVALID_ARG;
+    uint64_t row_size = 0, record_cnt = 0;
+    int rc = tape_shape(index_len, field_cnt, new_line, &row_size, &record_cnt);
+    if (rc != CSVSIMD_OK) return rc;
+    if (field_idx >= field_cnt) return CSVSIMD_ERR_INVALID_ARG;
+    std::vector<uint64_t> rows(n_chunks);
+    for (uint32_t i = 0; i < n_chunks; ++i)
+        if ((rc = chunk_rows(&chunks[i], index_len, row_size, &rows[i])) != CSVSIMD_OK) return rc;
+    hipStream_t s = (hipStream_t)hip_stream;
+    void* d_status = (char*)d_scratch + table_slots * 32;
+    static_assert(sizeof(csvsimd_freq_status) == 32 && sizeof(csvsimd_freq_entry) == 32, "layouts shared with the kernels");
+    // a 64-bit hash collision between two different values is detected by the verification pass, never merged:
+    // the count is then repeated with another seed (three tries; 2^-64-ish per pair of distinct values each)
+    for (uint64_t attempt = 0; attempt < 3; ++attempt) {
+        const uint64_t seed = 0x243F6A8885A308D3ull + attempt * 0x9E3779B97F4A7C15ull;
+        HIP_TRY(hipMemsetAsync(d_scratch, 0, table_slots * 32 + 64, s));
+        for (uint32_t i = 0; i < n_chunks; ++i)
+            HIP_TRY(csvsimd::launch_freq_insert(dbytes, dindex, chunks[i].start, row_size, rows[i], field_idx, d_scratch,
+                                                table_slots, d_status, seed, ctx->n_cus, s));
+        for (uint32_t i = 0; i < n_chunks; ++i)
+            HIP_TRY(csvsimd::launch_freq_verify(dbytes, dindex, chunks[i].start, row_size, rows[i], field_idx, d_scratch,
+                                                table_slots, d_status, seed, s));
+        HIP_TRY(csvsimd::launch_freq_compact(d_scratch, table_slots, dindex, row_size, field_idx, d_entries, entries_cap,
+                                             d_status, s));
+        HIP_TRY(hipMemcpyAsync(status, d_status, sizeof(*status), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (status->overflow) return CSVSIMD_ERR_TAPE_CAPACITY;  // the table is full: call again with more slots
+        if (status->collisions == 0) break;
+    }
+    if (status->collisions) {
+        g_last_error = "column frequency: hash collisions persisted over three seeds";
+        return CSVSIMD_ERR_INTERNAL;
+    }
+    if (status->n_distinct > entries_cap) return CSVSIMD_ERR_TAPE_CAPACITY;  // status->n_distinct = the size needed
+    return CSVSIMD_OK;
+}
+
+int csvsimd_column_search_device(csvsimd_ctx* ctx, const void* dbytes, const void* dindex, uint64_t index_len,
+                                 uint32_t field_cnt, int new_line, const csvsimd_chunk* chunk, uint32_t field_idx,
+                                 const void* needle, uint32_t needle_len, int mode, void* d_bitmap, uint64_t* n_matches,
+                                 void* hip_stream) {
+    if (!ctx || !dbytes || !dindex || !n_matches || (needle_len && !needle) || needle_len > 256) return CSVSIMD_ERR_INVALID_ARG;
+    if (mode != CSVSIMD_SEARCH_EQUALS && mode != CSVSIMD_SEARCH_STARTS_WITH && mode != CSVSIMD_SEARCH_CONTAINS)
+        return CSVSIMD_ERR_INVALID_ARG;
+    uint64_t row_size = 0, record_cnt = 0, n = 0;
+    int rc = tape_shape(index_len, field_cnt, new_line, &row_size, &record_cnt);
+    if (rc == CSVSIMD_OK) rc = chunk_rows(chunk, index_len, row_size, &n);
+    if (rc != CSVSIMD_OK) return rc;
+    if (field_idx >= field_cnt || (n && (!d_bitmap || ((uintptr_t)d_bitmap & 7)))) return CSVSIMD_ERR_INVALID_ARG;
+    *n_matches = 0;
+    if (n == 0) return CSVSIMD_OK;
+    hipStream_t s = (hipStream_t)hip_stream;
+    // the needle and the match counter live in the context's small device block: [0, 8) counter, [64, 64 + 264) needle
+    HIP_TRY(hipMemsetAsync(ctx->d_small, 0, 8, s));
+    if (needle_len) HIP_TRY(hipMemcpyAsync((char*)ctx->d_small + 64, needle, needle_len, hipMemcpyHostToDevice, s));
+    HIP_TRY(csvsimd::launch_search(dbytes, dindex, chunk->start, row_size, n, field_idx, (char*)ctx->d_small + 64, needle_len,
+                                   mode, d_bitmap, ctx->d_small, s));
+    HIP_TRY(hipMemcpyAsync(n_matches, ctx->d_small, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return CSVSIMD_OK;
+}
+
+uint64_t csvsimd_bitmap_select_scratch_bytes(uint64_t n_rows) { return ((n_rows + 4095) / 4096 + 2) * 8; }
+
+int csvsimd_bitmap_select_device(const void* d_bitmap, uint64_t n_rows, uint64_t first_record, void* d_scratch, void* d_out,
+                                 uint64_t out_cap, uint64_t* n_out, void* hip_stream) {
+    if (!n_out || (n_rows && (!d_bitmap || !d_scratch)) || (out_cap && !d_out) || ((uintptr_t)d_scratch & 7))
+        return CSVSIMD_ERR_INVALID_ARG;
+    if (csvsimd_device_count() <= 0) return CSVSIMD_ERR_NO_DEVICE;
+    *n_out = 0;
+    if (n_rows == 0) return CSVSIMD_OK;
+    hipStream_t s = (hipStream_t)hip_stream;
+    const uint64_t n_blocks = (n_rows + 4095) / 4096;
+    uint64_t* const d_total = (uint64_t*)d_scratch + n_blocks;  // behind the per-block counts
+    HIP_TRY(csvsimd::launch_bitmap_select(d_bitmap, n_rows, first_record, d_scratch, d_out, out_cap, d_total, s));
+    HIP_TRY(hipMemcpyAsync(n_out, d_total, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return *n_out > out_cap ? CSVSIMD_ERR_TAPE_CAPACITY : CSVSIMD_OK;
 }
 
 int csvsimd_trim_spans_device(const void* dbytes, void* d_begin, void* d_end, uint64_t n_records, uint32_t flags,

@@ -1,0 +1,444 @@
+// consumer_kernels.hip — gfx950 kernels that CONSUME a finished, device-resident tape.
+//
+// The reference's stated goal for the tape is "use the result to run frequency counts, and function search"
+// (design_notes_1.md:1-4), with `Chunk {start, end, record_cnt}` as "atomic representation of how to utilize the
+// tape in a parallel-processing context" (src/tape.rs:12-19; produced by Tape::chunks, src/tape.rs:95-140).  The
+// reference itself stops at the chunk list (single-threaded seek_field, src/record_source.rs:106-140); what is
+// here is the device side of that plan, driven by the same chunk records:
+//
+//   * field spans of a column of a chunk           (bulk seek_field)
+//   * gather of a column into fixed-stride rows    (16-byte loads at any alignment)
+//   * frequency count of a column                  (exact: hash table + byte-for-byte verification pass)
+//   * search in a column: equals / starts-with / contains  -> bitmap of records + count, bitmap -> record ids
+//
+// Index arithmetic is seek_field's: row r of the file (0 = header) owns index keys [r * jump, (r + 1) * jump),
+// field f of it is bytes[index[r * jump + f] + 1 .. index[r * jump + f + 1]).  A chunk covers keys
+// [chunk.start, chunk.end), i.e. chunk.record_cnt rows from row chunk.start / jump (chunk 0 starts after the
+// header: src/tape.rs:116-122).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "stage1_kernels.h"
+
+namespace csvsimd {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(1)));  // 16 bytes at any address: ONE global_load_dwordx4
+typedef uint64_t u64u __attribute__((aligned(1)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// One column of one chunk (or of any run of whole rows): everything a consumer kernel needs to find its fields.
+struct Column {
+    const uint8_t* bytes;
+    const u64* index;  // the tape WITH its sentinel
+    u64 first_key;     // index key of the first row's field 0 (= chunk.start)
+    u64 jump;          // record_jump_size
+    u64 n_rows;
+    u64 first_row;     // row number of the first row in the file (for record ids): first_key / jump
+    u32 field;
+};
+
+__device__ __forceinline__ void field_span(const Column& c, u64 i, u64& b, u64& e) {
+    const u64 k = c.first_key + i * c.jump + c.field;
+    b = c.index[k] + 1;
+    e = c.index[k + 1];
+    if (e < b) e = b;  // cannot happen on a well-formed tape; keeps a corrupt one from running backwards
+}
+
+// ---------------------------------------------------------------------------------------------
+// bulk seek_field / seek_record over a run of rows
+// ---------------------------------------------------------------------------------------------
+__global__ void chunk_spans_kernel(const u64* __restrict__ index, u64 first_key, u64 jump, u32 field, u32 fields, u64 n_rows,
+                                   u64* __restrict__ begin, u64* __restrict__ end) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += (u64)gridDim.x * blockDim.x) {
+        const u64 k = first_key + i * jump + field;
+        begin[i] = index[k] + 1;
+        end[i] = index[k + fields];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// gather: text of each span -> row i of dst (stride bytes, truncated, zero padded); len[i] = untruncated length.
+// A 16-lane group per record, each lane moves 16 bytes per step with one unaligned 16-byte load and one 16-byte
+// store (stride % 16 == 0 and an aligned dst) — round 1 moved single bytes.
+// ---------------------------------------------------------------------------------------------
+__global__ void gather_fields_kernel(const uint8_t* __restrict__ bytes, u64 bytes_len, const u64* __restrict__ begin,
+                                     const u64* __restrict__ end, u64 n_records, uint8_t* __restrict__ dst, u32 stride,
+                                     u32* __restrict__ len, int wide) {
+    const u32 sub = threadIdx.x & 15u;
+    for (u64 i = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 4; i < n_records;
+         i += ((u64)gridDim.x * blockDim.x) >> 4) {
+        const u64 b = begin[i], e = end[i];
+        const u64 n = e > b ? e - b : 0;
+        if (sub == 0 && len) len[i] = (u32)(n > 0xffffffffull ? 0xffffffffull : n);
+        uint8_t* const row = dst + i * stride;
+        if (wide) {
+            for (u32 k = sub * 16u; k < stride; k += 256u) {
+                u32x4 v = {0, 0, 0, 0};
+                if (k < n) {
+                    if (b + k + 16 <= bytes_len) {
+                        v = *reinterpret_cast<const u32x4u*>(bytes + b + k);
+                    } else {  // the last 15 bytes of the buffer: never read past it
+                        uint8_t t[16];
+                        for (u32 j = 0; j < 16; ++j) t[j] = b + k + j < bytes_len ? bytes[b + k + j] : (uint8_t)0;
+                        v = *reinterpret_cast<const u32x4*>(t);
+                    }
+                    if (n - k < 16) {  // zero the bytes past the field's end
+                        const u32 keep = (u32)(n - k);
+                        const u32 full = keep >> 2, part = keep & 3u;
+                        const u32 m = part ? (0xffffffffu >> (32u - 8u * part)) : 0u;
+                        v.x = full > 0 ? v.x : (full == 0 ? v.x & m : 0u);
+                        v.y = full > 1 ? v.y : (full == 1 ? v.y & m : 0u);
+                        v.z = full > 2 ? v.z : (full == 2 ? v.z & m : 0u);
+                        v.w = full > 3 ? v.w : (full == 3 ? v.w & m : 0u);
+                    }
+                }
+                *reinterpret_cast<u32x4*>(row + k) = v;
+            }
+        } else {
+            for (u32 k = sub; k < stride; k += 16) row[k] = k < n ? bytes[b + k] : (uint8_t)0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// hashing of a field's bytes: 8 bytes per step (unaligned loads), splitmix-style finish; never 0 (0 = empty slot)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 mix64(u64 z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ u64 hash_bytes(const uint8_t* p, u64 n, u64 seed) {
+    u64 h = seed ^ (n * 0x9E3779B97F4A7C15ull);
+    u64 k = 0;
+    for (; k + 8 <= n; k += 8) h = mix64(h ^ *reinterpret_cast<const u64u*>(p + k)) + 0x9E3779B97F4A7C15ull;
+    u64 tail = 0;
+    for (u32 j = 0; k + j < n; ++j) tail |= (u64)p[k + j] << (8 * j);
+    h = mix64(h ^ tail ^ 0xA5A5A5A5A5A5A5A5ull);
+    return h ? h : 1ull;
+}
+__device__ __forceinline__ bool bytes_equal(const uint8_t* a, const uint8_t* b, u64 n) {
+    u64 k = 0;
+    for (; k + 8 <= n; k += 8)
+        if (*reinterpret_cast<const u64u*>(a + k) != *reinterpret_cast<const u64u*>(b + k)) return false;
+    for (; k < n; ++k)
+        if (a[k] != b[k]) return false;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// frequency count of a column.  Global open-addressing table of csvsimd_freq_slot {hash, first_row, count}:
+//   insert  : every record hashes its field; a workgroup first aggregates in an LDS table (a column of few
+//             distinct values would otherwise hammer a handful of global counters), then merges its LDS slots
+//             into the global table (CAS on the hash word, atomicAdd count, atomicMin first row);
+//   verify  : every record compares its bytes with the bytes of its slot's first row — two different values
+//             with the same 64-bit hash are DETECTED (counted in `collisions`; the host then repeats with another
+//             seed), never silently merged: the counts are exact, not probabilistic;
+//   compact : occupied slots -> dense csvsimd_freq_entry array (first row, span of its text, count).
+// ---------------------------------------------------------------------------------------------
+static constexpr u32 kLdsSlots = 1024;  // per workgroup (power of two)
+
+struct FreqSlot {  // 32 bytes; the table is cleared with one memset, so the "first row" is kept as the MAXIMUM of
+    u64 hash, first_inv, count, pad;  // ~row (0 = none yet): first row = ~first_inv
+};
+struct FreqStatus {  // == csvsimd_freq_status
+    u64 n_records, n_distinct, collisions, overflow;
+};
+
+__device__ __forceinline__ bool global_insert(FreqSlot* table, u64 mask, u64 h, u64 first_row, u64 count) {
+    u64 s = h & mask;
+    for (u64 probes = 0; probes <= mask; ++probes, s = (s + 1) & mask) {
+        const u64 old = atomicCAS((unsigned long long*)&table[s].hash, 0ull, (unsigned long long)h);
+        if (old == 0 || old == h) {
+            atomicAdd((unsigned long long*)&table[s].count, (unsigned long long)count);
+            atomicMax((unsigned long long*)&table[s].first_inv, (unsigned long long)~first_row);
+            return true;
+        }
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(256) void freq_insert_kernel(const Column c, FreqSlot* __restrict__ table, u64 mask,
+                                                          FreqStatus* __restrict__ status, u64 seed) {
+    __shared__ u64 s_hash[kLdsSlots];
+    __shared__ u64 s_first[kLdsSlots];
+    __shared__ u32 s_count[kLdsSlots];
+    for (u32 k = threadIdx.x; k < kLdsSlots; k += blockDim.x) {
+        s_hash[k] = 0;
+        s_first[k] = ~0ull;
+        s_count[k] = 0;
+    }
+    __syncthreads();
+    bool overflow = false;
+    // contiguous slab of rows per workgroup: neighbouring lanes read neighbouring rows
+    const u64 per = (c.n_rows + gridDim.x - 1) / gridDim.x;
+    const u64 r0 = (u64)blockIdx.x * per, r1 = r0 + per < c.n_rows ? r0 + per : c.n_rows;
+    for (u64 i = r0 + threadIdx.x; i < r1; i += blockDim.x) {
+        u64 b, e;
+        field_span(c, i, b, e);
+        const u64 h = hash_bytes(c.bytes + b, e - b, seed);
+        const u64 row = c.first_row + i;
+        // LDS first: at most 8 probes, then straight to the global table (a column of many distinct values)
+        u32 s = (u32)(h >> 32) & (kLdsSlots - 1);
+        bool done = false;
+        for (int p = 0; p < 8 && !done; ++p, s = (s + 1) & (kLdsSlots - 1)) {
+            const u64 old = atomicCAS((unsigned long long*)&s_hash[s], 0ull, (unsigned long long)h);
+            if (old == 0 || old == h) {
+                atomicAdd(&s_count[s], 1u);
+                atomicMin((unsigned long long*)&s_first[s], (unsigned long long)row);
+                done = true;
+            }
+        }
+        if (!done && !global_insert(table, mask, h, row, 1)) overflow = true;
+    }
+    __syncthreads();
+    for (u32 k = threadIdx.x; k < kLdsSlots; k += blockDim.x)
+        if (s_hash[k] && !global_insert(table, mask, s_hash[k], s_first[k], s_count[k])) overflow = true;
+    if (overflow) atomicAdd((unsigned long long*)&status->overflow, 1ull);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd((unsigned long long*)&status->n_records, (unsigned long long)c.n_rows);
+}
+
+__global__ __launch_bounds__(256) void freq_verify_kernel(const Column c, const FreqSlot* __restrict__ table, u64 mask,
+                                                          FreqStatus* __restrict__ status, u64 seed, u64 table_jump,
+                                                          u32 table_field) {
+    u32 bad = 0;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < c.n_rows; i += (u64)gridDim.x * blockDim.x) {
+        u64 b, e;
+        field_span(c, i, b, e);
+        const u64 h = hash_bytes(c.bytes + b, e - b, seed);
+        u64 s = h & mask;
+        bool found = false;
+        for (u64 probes = 0; probes <= mask; ++probes, s = (s + 1) & mask) {
+            const u64 th = table[s].hash;
+            if (th == h) { found = true; break; }
+            if (th == 0) break;
+        }
+        if (!found) { ++bad; continue; }
+        // the representative: field `table_field` of row first_row (any chunk of the same tape)
+        const u64 k = ~table[s].first_inv * table_jump + table_field;
+        const u64 rb = c.index[k] + 1, re = c.index[k + 1];
+        if (re - rb != e - b || !bytes_equal(c.bytes + rb, c.bytes + b, e - b)) ++bad;
+    }
+    if (bad) atomicAdd((unsigned long long*)&status->collisions, (unsigned long long)bad);
+}
+
+struct FreqEntry {  // == csvsimd_freq_entry: 32 bytes
+    u64 first_record, begin, end, count;
+};
+__global__ void freq_compact_kernel(const FreqSlot* __restrict__ table, u64 slots, const u64* __restrict__ index, u64 jump,
+                                    u32 field, FreqEntry* __restrict__ out, u64 out_cap, FreqStatus* __restrict__ status) {
+    for (u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x; s < slots; s += (u64)gridDim.x * blockDim.x) {
+        if (table[s].hash == 0) continue;
+        const u64 at = atomicAdd((unsigned long long*)&status->n_distinct, 1ull);
+        if (at >= out_cap) continue;
+        const u64 row = ~table[s].first_inv;
+        const u64 k = row * jump + field;
+        out[at] = FreqEntry{row - 1, index[k] + 1, index[k + 1], table[s].count};  // record id as seek_field counts
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// search: one bit per row of the chunk (bit i of word i / 64 = row i matches) + the number of matches.
+//   mode 0 = field == needle, 1 = field starts with needle, 2 = field contains needle
+// One lane per row; the needle sits in LDS.  "contains" is the plain quadratic scan with a first-byte filter
+// (fields are tens of bytes): bytes.find's definition, not its algorithm.
+// ---------------------------------------------------------------------------------------------
+static constexpr u32 kMaxNeedle = 256;
+
+__global__ __launch_bounds__(256) void search_kernel(const Column c, const uint8_t* __restrict__ needle, u32 m, int mode,
+                                                     u64* __restrict__ bitmap, u64* __restrict__ count) {
+    __shared__ uint8_t s_needle[kMaxNeedle + 8];
+    for (u32 k = threadIdx.x; k < kMaxNeedle + 8; k += blockDim.x) s_needle[k] = k < m ? needle[k] : (uint8_t)0;
+    __syncthreads();
+    const u64 n_words = (c.n_rows + 63) / 64;
+    const u32 lane = threadIdx.x & 63u;
+    u32 hits = 0;
+    for (u64 word = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; word < n_words;
+         word += ((u64)gridDim.x * blockDim.x) >> 6) {
+        const u64 i = word * 64 + lane;
+        bool match = false;
+        if (i < c.n_rows) {
+            u64 b, e;
+            field_span(c, i, b, e);
+            const u64 n = e - b;
+            const uint8_t* p = c.bytes + b;
+            if (mode == 0) {
+                match = n == m;
+            } else {
+                match = n >= m;
+            }
+            if (match && mode != 2) {
+                for (u32 k = 0; k < m && match; ++k) match = p[k] == s_needle[k];
+            } else if (match) {  // contains
+                match = m == 0;
+                const uint8_t first = s_needle[0];
+                for (u64 at = 0; at + m <= n && !match; ++at) {
+                    if (p[at] != first) continue;
+                    u32 k = 1;
+                    while (k < m && p[at + k] == s_needle[k]) ++k;
+                    match = k == m;
+                }
+            }
+        }
+        const u64 bits = __ballot(match);
+        if (lane == 0) {
+            bitmap[word] = bits;
+            hits += (u32)__builtin_popcountll(bits);
+        }
+    }
+    if (lane == 0 && hits) atomicAdd((unsigned long long*)count, (unsigned long long)hits);
+}
+
+// bitmap -> ascending record ids.  Two small passes keep the order without any global atomics on the output:
+//   pass 1: popcount per 4096-bit block -> block_counts;  (host-free) pass 2: one workgroup scans the block
+//   counts;  pass 3: every block writes its ids from its base.
+__global__ void bitmap_block_count_kernel(const u64* __restrict__ bitmap, u64 n_words, u64* __restrict__ block_counts) {
+    const u64 blk = blockIdx.x;
+    u32 c = 0;
+    for (u32 k = threadIdx.x; k < 64; k += blockDim.x) {
+        const u64 w = blk * 64 + k;
+        c += w < n_words ? (u32)__builtin_popcountll(bitmap[w]) : 0u;
+    }
+    for (int d = 32; d >= 1; d >>= 1) c += (u32)__shfl_xor((int)c, d);
+    if (threadIdx.x == 0) block_counts[blk] = c;
+}
+__global__ __launch_bounds__(1024) void bitmap_scan_kernel(u64* __restrict__ block_counts, u64 n_blocks, u64* __restrict__ total) {
+    __shared__ u64 s_part[1024];
+    // each thread owns a contiguous run of blocks
+    const u64 per = (n_blocks + blockDim.x - 1) / blockDim.x;
+    const u64 a = (u64)threadIdx.x * per, b = a + per < n_blocks ? a + per : n_blocks;
+    u64 sum = 0;
+    for (u64 k = a; k < b; ++k) sum += block_counts[k];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 run = 0;
+        for (u32 k = 0; k < blockDim.x; ++k) {
+            const u64 v = s_part[k];
+            s_part[k] = run;
+            run += v;
+        }
+        *total = run;
+    }
+    __syncthreads();
+    u64 run = s_part[threadIdx.x];
+    for (u64 k = a; k < b; ++k) {
+        const u64 v = block_counts[k];
+        block_counts[k] = run;  // exclusive prefix
+        run += v;
+    }
+}
+__global__ void bitmap_select_kernel(const u64* __restrict__ bitmap, u64 n_words, const u64* __restrict__ block_base,
+                                     u64 first_row, u64* __restrict__ out, u64 out_cap) {
+    // one wave per 4096-bit block: lane l owns word l of the block
+    const u64 blk = blockIdx.x;
+    const u32 lane = threadIdx.x;
+    const u64 w = blk * 64 + lane;
+    u64 bits = w < n_words ? bitmap[w] : 0;
+    u32 c = (u32)__builtin_popcountll(bits);
+    u32 incl = c;
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 v = (u32)__shfl_up((int)incl, d);
+        if (lane >= (u32)d) incl += v;
+    }
+    u64 at = block_base[blk] + (incl - c);
+    while (bits) {
+        const u32 b = (u32)__builtin_ctzll(bits);
+        bits &= bits - 1;
+        if (at < out_cap) out[at] = first_row + w * 64 + b;
+        ++at;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+static u32 grid_for(u64 items, u32 per_block, u32 cap) {
+    u64 blocks = (items + per_block - 1) / per_block;
+    if (blocks < 1) blocks = 1;
+    return (u32)(blocks > cap ? cap : blocks);
+}
+
+hipError_t launch_chunk_spans(const void* dindex, u64 first_key, u64 jump, u32 field, u32 fields, u64 n_rows, void* d_begin,
+                              void* d_end, hipStream_t stream) {
+    if (n_rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(chunk_spans_kernel, dim3(grid_for(n_rows, 256, 4096)), dim3(256), 0, stream, (const u64*)dindex,
+                       first_key, jump, field, fields, n_rows, (u64*)d_begin, (u64*)d_end);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_fields(const void* dbytes, u64 bytes_len, const void* d_begin, const void* d_end, u64 n_records,
+                                void* d_dst, u32 stride, void* d_len, hipStream_t stream) {
+    if (n_records == 0 || stride == 0) return hipSuccess;
+    const int wide = (stride % 16 == 0) && (((uintptr_t)d_dst & 15) == 0);
+    hipLaunchKernelGGL(gather_fields_kernel, dim3(grid_for(n_records * 16, 256, 8192)), dim3(256), 0, stream,
+                       (const uint8_t*)dbytes, bytes_len, (const u64*)d_begin, (const u64*)d_end, n_records, (uint8_t*)d_dst,
+                       stride, (u32*)d_len, wide);
+    return hipGetLastError();
+}
+
+static Column make_column(const void* dbytes, const void* dindex, u64 first_key, u64 jump, u64 n_rows, u32 field) {
+    Column c;
+    c.bytes = (const uint8_t*)dbytes;
+    c.index = (const u64*)dindex;
+    c.first_key = first_key;
+    c.jump = jump;
+    c.n_rows = n_rows;
+    c.first_row = first_key / jump;
+    c.field = field;
+    return c;
+}
+
+hipError_t launch_freq_insert(const void* dbytes, const void* dindex, u64 first_key, u64 jump, u64 n_rows, u32 field,
+                              void* d_table, u64 slots, void* d_status, u64 seed, int n_cus, hipStream_t stream) {
+    if (n_rows == 0) return hipSuccess;
+    const Column c = make_column(dbytes, dindex, first_key, jump, n_rows, field);
+    // >= 2048 rows per workgroup so that the LDS pre-aggregation has something to aggregate
+    const u32 grid = grid_for(n_rows, 2048, (u32)(n_cus > 0 ? n_cus : 256) * 8);
+    hipLaunchKernelGGL(freq_insert_kernel, dim3(grid), dim3(256), 0, stream, c, (FreqSlot*)d_table, slots - 1,
+                       (FreqStatus*)d_status, seed);
+    return hipGetLastError();
+}
+
+hipError_t launch_freq_verify(const void* dbytes, const void* dindex, u64 first_key, u64 jump, u64 n_rows, u32 field,
+                              const void* d_table, u64 slots, void* d_status, u64 seed, hipStream_t stream) {
+    if (n_rows == 0) return hipSuccess;
+    const Column c = make_column(dbytes, dindex, first_key, jump, n_rows, field);
+    hipLaunchKernelGGL(freq_verify_kernel, dim3(grid_for(n_rows, 256, 8192)), dim3(256), 0, stream, c,
+                       (const FreqSlot*)d_table, slots - 1, (FreqStatus*)d_status, seed, jump, field);
+    return hipGetLastError();
+}
+
+hipError_t launch_freq_compact(const void* d_table, u64 slots, const void* dindex, u64 jump, u32 field, void* d_out,
+                               u64 out_cap, void* d_status, hipStream_t stream) {
+    hipLaunchKernelGGL(freq_compact_kernel, dim3(grid_for(slots, 256, 4096)), dim3(256), 0, stream, (const FreqSlot*)d_table,
+                       slots, (const u64*)dindex, jump, field, (FreqEntry*)d_out, out_cap, (FreqStatus*)d_status);
+    return hipGetLastError();
+}
+
+hipError_t launch_search(const void* dbytes, const void* dindex, u64 first_key, u64 jump, u64 n_rows, u32 field,
+                         const void* d_needle, u32 needle_len, int mode, void* d_bitmap, void* d_count, hipStream_t stream) {
+    if (n_rows == 0) return hipSuccess;
+    const Column c = make_column(dbytes, dindex, first_key, jump, n_rows, field);
+    hipLaunchKernelGGL(search_kernel, dim3(grid_for(n_rows, 256, 8192)), dim3(256), 0, stream, c, (const uint8_t*)d_needle,
+                       needle_len, mode, (u64*)d_bitmap, (u64*)d_count);
+    return hipGetLastError();
+}
+
+hipError_t launch_bitmap_select(const void* d_bitmap, u64 n_rows, u64 first_row, void* d_block_scratch, void* d_out,
+                                u64 out_cap, void* d_total, hipStream_t stream) {
+    if (n_rows == 0) return hipSuccess;
+    const u64 n_words = (n_rows + 63) / 64;
+    const u64 n_blocks = (n_words + 63) / 64;
+    if (n_blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(bitmap_block_count_kernel, dim3((u32)n_blocks), dim3(64), 0, stream, (const u64*)d_bitmap, n_words,
+                       (u64*)d_block_scratch);
+    hipLaunchKernelGGL(bitmap_scan_kernel, dim3(1), dim3(1024), 0, stream, (u64*)d_block_scratch, n_blocks, (u64*)d_total);
+    hipLaunchKernelGGL(bitmap_select_kernel, dim3((u32)n_blocks), dim3(64), 0, stream, (const u64*)d_bitmap, n_words,
+                       (const u64*)d_block_scratch, first_row, (u64*)d_out, out_cap);
+    return hipGetLastError();
+}
+
+}  // namespace csvsimd

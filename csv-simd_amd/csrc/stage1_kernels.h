@@ -74,11 +74,24 @@ hipError_t launch_hbm_probe(const void* din, uint64_t len, void* dout, int write
 hipError_t launch_stitch(const void* d_results, uint32_t n_shards, uint32_t rank, uint32_t file_in_quote_in,
                          void* d_stitch, hipStream_t stream);
 const char* stage1_kernel_name(bool emit, int dialect);
-hipError_t launch_field_spans(const void* dindex, uint64_t row_size, uint32_t field_idx, uint32_t fields,
-                              uint64_t first_record, uint64_t n_records, void* d_begin, void* d_end,
+// consumer_kernels.hip: consumers of a finished, device-resident tape
+hipError_t launch_chunk_spans(const void* dindex, uint64_t first_key, uint64_t jump, uint32_t field, uint32_t fields,
+                              uint64_t n_rows, void* d_begin, void* d_end, hipStream_t stream);
+hipError_t launch_gather_fields(const void* dbytes, uint64_t bytes_len, const void* d_begin, const void* d_end,
+                                uint64_t n_records, void* d_dst, uint32_t stride, void* d_len, hipStream_t stream);
+hipError_t launch_freq_insert(const void* dbytes, const void* dindex, uint64_t first_key, uint64_t jump, uint64_t n_rows,
+                              uint32_t field, void* d_table, uint64_t slots, void* d_status, uint64_t seed, int n_cus,
                               hipStream_t stream);
-hipError_t launch_gather_fields(const void* dbytes, const void* d_begin, const void* d_end, uint64_t n_records,
-                                void* d_dst, uint32_t stride, void* d_len, hipStream_t stream);
+hipError_t launch_freq_verify(const void* dbytes, const void* dindex, uint64_t first_key, uint64_t jump, uint64_t n_rows,
+                              uint32_t field, const void* d_table, uint64_t slots, void* d_status, uint64_t seed,
+                              hipStream_t stream);
+hipError_t launch_freq_compact(const void* d_table, uint64_t slots, const void* dindex, uint64_t jump, uint32_t field,
+                               void* d_out, uint64_t out_cap, void* d_status, hipStream_t stream);
+hipError_t launch_search(const void* dbytes, const void* dindex, uint64_t first_key, uint64_t jump, uint64_t n_rows,
+                         uint32_t field, const void* d_needle, uint32_t needle_len, int mode, void* d_bitmap, void* d_count,
+                         hipStream_t stream);
+hipError_t launch_bitmap_select(const void* d_bitmap, uint64_t n_rows, uint64_t first_row, void* d_block_scratch,
+                                void* d_out, uint64_t out_cap, void* d_total, hipStream_t stream);
 // text_kernels.hip
 hipError_t launch_utf8_validate(const void* dbuf, uint64_t len, void* d_result, int n_cus, hipStream_t stream);
 hipError_t launch_trim_spans(const void* dbytes, void* d_begin, void* d_end, uint64_t n, uint32_t flags,

@@ -1266,39 +1266,6 @@ __global__ void stitch_kernel(const csvsimd_shard_result* __restrict__ results, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// consumers of the finished tape: RecordSource::seek_field
-// (src/record_source.rs:106-140) for a whole range of records at once, on the device
-// ---------------------------------------------------------------------------------------------
-// index = the tape WITH its sentinel (index[0] == 0); row_size = field_cnt (+1 for CRLF files,
-// src/record_source.rs:124-127); record r (0 = first data row) field f:
-//   idx = (r + 1) * row_size + f;  text = bytes[index[idx] + 1 .. index[idx + 1])
-// seek_record (src/record_source.rs:70-104) is the same walk over `fields` = field_cnt entries from
-// field 0: text = bytes[index[(r + 1) * row_size] + 1 .. index[(r + 1) * row_size + field_cnt])
-__global__ void field_spans_kernel(const u64* __restrict__ index, u64 row_size, u32 field_idx, u32 fields,
-                                   u64 first_record, u64 n_records, u64* __restrict__ begin, u64* __restrict__ end) {
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_records; i += (u64)gridDim.x * blockDim.x) {
-        const u64 idx = (first_record + i + 1) * row_size + field_idx;
-        begin[i] = index[idx] + 1;
-        end[i] = index[idx + fields];
-    }
-}
-
-// copies each field's text into a fixed-stride row (truncated to `stride`, zero padded), one
-// 16-lane group per record; len[i] = the untruncated length
-__global__ void gather_fields_kernel(const uint8_t* __restrict__ bytes, const u64* __restrict__ begin,
-                                     const u64* __restrict__ end, u64 n_records, uint8_t* __restrict__ dst,
-                                     u32 stride, u32* __restrict__ len) {
-    const u32 sub = threadIdx.x & 15u;
-    for (u64 i = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 4; i < n_records;
-         i += ((u64)gridDim.x * blockDim.x) >> 4) {
-        const u64 b = begin[i], e = end[i];
-        const u64 n = e > b ? e - b : 0;  // an empty last field of a CRLF row has end == begin - 1 + 1
-        if (sub == 0 && len) len[i] = (u32)(n > 0xffffffffull ? 0xffffffffull : n);
-        for (u32 k = sub; k < stride; k += 16) dst[i * stride + k] = k < n ? bytes[b + k] : (uint8_t)0;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // host-side launchers (no allocation, no synchronisation: graph-capturable)
 // ---------------------------------------------------------------------------------------------
 #ifdef CSVSIMD_DEV_PROBES
@@ -1406,26 +1373,6 @@ hipError_t launch_checksum(const void* dtape, u64 n, u64 first_index, void* d_ou
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(checksum_kernel, dim3((u32)blocks), dim3(256), 0, stream, (const u64*)dtape, n,
                        first_index, (u64*)d_out);
-    return hipGetLastError();
-}
-
-hipError_t launch_field_spans(const void* dindex, u64 row_size, u32 field_idx, u32 fields, u64 first_record,
-                              u64 n_records, void* d_begin, void* d_end, hipStream_t stream) {
-    if (n_records == 0) return hipSuccess;
-    u64 blocks = (n_records + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(field_spans_kernel, dim3((u32)blocks), dim3(256), 0, stream, (const u64*)dindex, row_size,
-                       field_idx, fields, first_record, n_records, (u64*)d_begin, (u64*)d_end);
-    return hipGetLastError();
-}
-
-hipError_t launch_gather_fields(const void* dbytes, const void* d_begin, const void* d_end, u64 n_records, void* d_dst,
-                                u32 stride, void* d_len, hipStream_t stream) {
-    if (n_records == 0 || stride == 0) return hipSuccess;
-    u64 blocks = (n_records * 16 + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(gather_fields_kernel, dim3((u32)blocks), dim3(256), 0, stream, (const uint8_t*)dbytes,
-                       (const u64*)d_begin, (const u64*)d_end, n_records, (uint8_t*)d_dst, stride, (u32*)d_len);
     return hipGetLastError();
 }
 

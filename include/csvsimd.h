@@ -239,13 +239,20 @@ const uint64_t* csvsimd_tape_index(const csvsimd_tape* t, uint64_t* index_len);
 const uint8_t* csvsimd_tape_bytes(const csvsimd_tape* t, uint64_t* len);
 
 /* ---- device-side consumers of a finished, device-resident tape ---------
- * RecordSource::seek_field (src/record_source.rs:106-140) for a whole range of records at once.
- * dindex = the tape WITH its leading sentinel (dindex[0] == 0), index_len entries.  For records
- * [first_record, first_record + n_records) (0 = first data row, as in seek_field) and field
- * field_idx writes d_begin[i], d_end[i] such that bytes[begin..end) is the field text — the same
- * pair csvsimd_tape_seek_field returns.  *n_valid = how many of the requested records exist
- * (seek_field's Ok(None) cases are simply not written).  Ragged index -> CSVSIMD_ERR_INVALID_CSV_FORMAT
- * (TapeCore::init, src/tape.rs:327,342-344). */
+ * The reference's plan for the tape: "use the result to run frequency counts, and function search"
+ * (design_notes_1.md:1-4), in parallel over the `Chunk {start, end, record_cnt}` records of Tape::chunks
+ * ("Atomic representation of how to utilize the tape in a parallel-processing context", src/tape.rs:12-19,
+ * 95-140).  The reference stops at the chunk list; these entry points are the consumers, driven by the very
+ * csvsimd_chunk records csvsimd_tape_chunks returns.  Everywhere: dindex = the tape WITH its leading sentinel
+ * (dindex[0] == 0), index_len entries, in device memory; field / record arithmetic is
+ * RecordSource::seek_field's (src/record_source.rs:106-140); records are numbered as seek_field numbers them
+ * (0 = first data row).  A ragged index -> CSVSIMD_ERR_INVALID_CSV_FORMAT (TapeCore::init,
+ * src/tape.rs:327,342-344); a chunk that is not whole rows of this tape -> CSVSIMD_ERR_INVALID_ARG.
+ *
+ * Bulk seek_field: for records [first_record, first_record + n_records) and field field_idx writes
+ * d_begin[i], d_end[i] such that bytes[begin..end) is the field text — the same pair
+ * csvsimd_tape_seek_field returns.  *n_valid = how many of the requested records exist (seek_field's
+ * Ok(None) cases are simply not written). */
 int csvsimd_tape_field_spans_device(const void* dindex, uint64_t index_len, uint32_t field_cnt, int new_line,
                                     uint32_t field_idx, uint64_t first_record, uint64_t n_records,
                                     void* d_begin, void* d_end, uint64_t* n_valid, void* hip_stream);
@@ -254,12 +261,58 @@ int csvsimd_tape_field_spans_device(const void* dindex, uint64_t index_len, uint
 int csvsimd_tape_record_spans_device(const void* dindex, uint64_t index_len, uint32_t field_cnt, int new_line,
                                      uint64_t first_record, uint64_t n_records, void* d_begin, void* d_end,
                                      uint64_t* n_valid, void* hip_stream);
+/* The same for one column of one chunk: *n_records = chunk->record_cnt spans, for the chunk's rows in order. */
+int csvsimd_chunk_field_spans_device(const void* dindex, uint64_t index_len, uint32_t field_cnt, int new_line,
+                                     const csvsimd_chunk* chunk, uint32_t field_idx, void* d_begin, void* d_end,
+                                     uint64_t* n_records, void* hip_stream);
 /* Copies the text of each span into row i of d_dst (n_records x stride bytes, truncated to stride,
- * zero padded); d_len[i] (uint32, may be NULL) = untruncated length.  The column-gather step of
- * the reference's stated goal "frequency counts, and function search" (design_notes_1.md:1-4). */
-int csvsimd_gather_fields_device(const void* dbytes, const void* d_begin, const void* d_end,
+ * zero padded); d_len[i] (uint32, may be NULL) = untruncated length.  dbytes[0..bytes_len) is the file.
+ * 16 bytes per lane per step when stride % 16 == 0 and d_dst is 16-byte aligned (any field alignment). */
+int csvsimd_gather_fields_device(const void* dbytes, uint64_t bytes_len, const void* d_begin, const void* d_end,
                                  uint64_t n_records, void* d_dst, uint32_t stride, void* d_len,
                                  void* hip_stream);
+
+/* Frequency count of column field_idx over the given chunks (all of csvsimd_tape_chunks' output = the whole
+ * file): one entry per DISTINCT field text with the number of records that hold it.  EXACT: values are
+ * grouped by a 64-bit hash in a device hash table, then a verification pass compares every record's bytes with
+ * its group's first record — a hash collision between two different values is detected (and the count repeated
+ * with another seed), never merged.  Definition checked against: collections.Counter over seek_field.
+ *   d_scratch   : csvsimd_column_frequency_scratch_bytes(table_slots) bytes, 16-byte aligned; table_slots a power
+ *                 of two >= 64, at least ~2x the number of distinct values (CSVSIMD_ERR_TAPE_CAPACITY if it fills)
+ *   d_entries   : entries_cap csvsimd_freq_entry, unordered (sort by first_record for a deterministic order);
+ *                 status->n_distinct of them are valid (CSVSIMD_ERR_TAPE_CAPACITY if more exist than fit)
+ * Synchronous on hip_stream. */
+typedef struct csvsimd_freq_entry {
+    uint64_t first_record; /* first record (seek_field numbering) that holds this value */
+    uint64_t begin, end;   /* bytes[begin..end) = the value's text (of that record)      */
+    uint64_t count;        /* records holding it                                         */
+} csvsimd_freq_entry;
+typedef struct csvsimd_freq_status {
+    uint64_t n_records, n_distinct, collisions /* of the last attempt: 0 on success */, overflow;
+} csvsimd_freq_status;
+uint64_t csvsimd_column_frequency_scratch_bytes(uint64_t table_slots);
+int csvsimd_column_frequency_device(csvsimd_ctx* ctx, const void* dbytes, const void* dindex, uint64_t index_len,
+                                    uint32_t field_cnt, int new_line, const csvsimd_chunk* chunks,
+                                    uint32_t n_chunks, uint32_t field_idx, void* d_scratch, uint64_t table_slots,
+                                    void* d_entries, uint64_t entries_cap, csvsimd_freq_status* status,
+                                    void* hip_stream);
+
+/* Search in column field_idx of one chunk: bit i of d_bitmap (uint64 words, (record_cnt + 63) / 64 of them,
+ * bit i of word i / 64) is set iff the chunk's i-th record matches; *n_matches = how many do.  needle is HOST
+ * memory, at most 256 bytes.  Definitions checked against Python's ==, bytes.startswith, `needle in field`. */
+#define CSVSIMD_SEARCH_EQUALS 0
+#define CSVSIMD_SEARCH_STARTS_WITH 1
+#define CSVSIMD_SEARCH_CONTAINS 2
+int csvsimd_column_search_device(csvsimd_ctx* ctx, const void* dbytes, const void* dindex, uint64_t index_len,
+                                 uint32_t field_cnt, int new_line, const csvsimd_chunk* chunk, uint32_t field_idx,
+                                 const void* needle, uint32_t needle_len, int mode, void* d_bitmap,
+                                 uint64_t* n_matches, void* hip_stream);
+/* Bitmap -> ascending record ids: d_out[k] = first_record + (position of the k-th set bit); *n_out = number of
+ * set bits among the first n_rows (CSVSIMD_ERR_TAPE_CAPACITY if > out_cap; the first out_cap are written).
+ * d_scratch: csvsimd_bitmap_select_scratch_bytes(n_rows) bytes, 8-byte aligned. */
+uint64_t csvsimd_bitmap_select_scratch_bytes(uint64_t n_rows);
+int csvsimd_bitmap_select_device(const void* d_bitmap, uint64_t n_rows, uint64_t first_record, void* d_scratch,
+                                 void* d_out, uint64_t out_cap, uint64_t* n_out, void* hip_stream);
 
 /* Trims every span [d_begin[i], d_end[i]) in place: CSVSIMD_TRIM_SPACE drops leading / trailing
  * 0x20 bytes — the reference's class 4, whose legend says `todo: trim " xx "`

@@ -39,6 +39,23 @@ static const uint8_t HI_TABLE[16] = {1, 0, 22, 0, 0, 8, 0, 0, 0, 0, 0, 0, 0, 0, 
 
 uint8_t oracle_byte_class(uint8_t b) { return LO_TABLE[b & 15] & HI_TABLE[b >> 4]; }
 
+/* The reference's string_mask_go closure on its own (src/avx/stage1.rs:342-361): carry-less multiply of the
+ * quote bits by all ones = inclusive prefix-xor.  Its own worked example ("0b100010000 quotes ->
+ * 0b011110000 string mask", same file :350-352 and design_notes_1.md:90-91) is a known answer
+ * (tests/test_oracle.py).  The second function is the recipe as design_notes_1.md:92-93 words it. */
+uint64_t oracle_string_mask_clmul(uint64_t quote_bits) {
+    const __m128i ones = _mm_set1_epi8((char)0xff);
+    return (uint64_t)_mm_cvtsi128_si64(_mm_clmulepi64_si128(_mm_set_epi64x(0, (int64_t)quote_bits), ones, 0));
+}
+uint64_t oracle_string_mask_loop(uint64_t quote_bits) {
+    uint64_t m = 0, acc = 0;
+    for (int i = 0; i < 64; ++i) {
+        acc ^= (quote_bits >> i) & 1u; /* bit-value i = cumulative XOR bit-value including i */
+        m |= acc << i;
+    }
+    return m;
+}
+
 int oracle_scalar_index(const uint8_t* buf, uint64_t len, uint64_t base_off, uint32_t in_quote_in,
                         uint64_t* tape, uint64_t cap, uint64_t* n_out, uint32_t* in_quote_out) {
     uint64_t n = 0;

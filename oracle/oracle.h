@@ -13,6 +13,10 @@ extern "C" {
 
 /* class byte of the reference's nibble tables (src/stage1.rs:23-48) */
 uint8_t oracle_byte_class(uint8_t b);
+/* in-string mask of one 64-byte block entered outside a string (src/avx/stage1.rs:342-361): the clmul form
+ * the reference executes and the bit loop design_notes_1.md:92-93 describes */
+uint64_t oracle_string_mask_clmul(uint64_t quote_bits);
+uint64_t oracle_string_mask_loop(uint64_t quote_bits);
 
 /* scalar definition; offsets = base_off + i; no sentinel */
 int oracle_scalar_index(const uint8_t* buf, uint64_t len, uint64_t base_off, uint32_t in_quote_in,

@@ -26,6 +26,8 @@ def lib() -> C.CDLL:
             build()
         h = C.CDLL(LIB_PATH)
         h.oracle_byte_class.restype, h.oracle_byte_class.argtypes = C.c_uint8, [C.c_uint8]
+        for f in (h.oracle_string_mask_clmul, h.oracle_string_mask_loop):
+            f.restype, f.argtypes = C.c_uint64, [C.c_uint64]
         h.oracle_scalar_index.restype = C.c_int
         h.oracle_scalar_index.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64,
                                           _u64p, C.POINTER(C.c_uint32)]
@@ -168,3 +170,38 @@ def synth(file_off: int, length: int, cols: int, width: int, seed: int, quote_pc
     out = aligned_copy(np.zeros(length, dtype=np.uint8))
     lib().oracle_synth_fill(out.ctypes.data, file_off, length, cols, width, seed, quote_pct)
     return out
+
+
+# ---- consumers of the tape: scalar definitions (test infrastructure; pinned on Python's own string semantics) ----
+def seek_field(data: bytes, index, field_cnt: int, crlf: bool, record_idx: int, field_idx: int):
+    """RecordSource::seek_field (src/record_source.rs:106-140), line by line."""
+    row_size = field_cnt + 1 if crlf else field_cnt
+    record_cnt = (len(index) - 1) // row_size
+    if record_idx + 1 >= record_cnt or field_idx >= field_cnt:
+        return None
+    idx_start = (record_idx + 1) * row_size + field_idx
+    return bytes(data[int(index[idx_start]) + 1: int(index[idx_start + 1])])
+
+
+def chunk_record_ids(chunk, field_cnt: int, crlf: bool):
+    """Records (seek_field numbering) of a Chunk {id, start, end, record_cnt} of Tape::chunks (src/tape.rs:95-140)."""
+    row_size = field_cnt + 1 if crlf else field_cnt
+    _, start, end, _ = chunk
+    return range(start // row_size - 1, end // row_size - 1)
+
+
+def column_frequency(data: bytes, index, field_cnt: int, crlf: bool, chunks, field_idx: int):
+    """design_notes_1.md:1-4 "frequency counts": collections.Counter over the column's field texts."""
+    from collections import Counter
+    c = Counter()
+    for ch in chunks:
+        for r in chunk_record_ids(ch, field_cnt, crlf):
+            c[seek_field(data, index, field_cnt, crlf, r, field_idx)] += 1
+    return c
+
+
+def column_search(data: bytes, index, field_cnt: int, crlf: bool, chunk, field_idx: int, needle: bytes, mode: int):
+    """design_notes_1.md:1-4 "function search": record ids whose field == / startswith / contains the needle."""
+    test = (lambda v: v == needle, lambda v: v.startswith(needle), lambda v: needle in v)[mode]
+    return [r for r in chunk_record_ids(chunk, field_cnt, crlf)
+            if test(seek_field(data, index, field_cnt, crlf, r, field_idx))]

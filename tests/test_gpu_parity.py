@@ -55,6 +55,20 @@ def test_golden_fixtures_via_read(ctx, golden, oracle, name):
         assert got[1] == 4 and got[-1] == 95
 
 
+def test_reference_worked_example_string_mask_on_gpu(ctx, pkg, torch_cuda, oracle):
+    # "0b100010000 quotes -> 0b011110000 string mask" (src/avx/stage1.rs:350-352, design_notes_1.md:90-91),
+    # at every position of a stripe / round / span the kernel treats differently, and through read()
+    from test_oracle import known_answer_block
+    block, want = known_answer_block()
+    assert np.array_equal(ctx.read(block)[1:], want)
+    T = pkg.tile_bytes()
+    for pad in (0, 64, 4032, 4096, 32704, 32768, T - 64, T):
+        buf = np.full(pad + 64 + 70, 0x61, dtype=np.uint8)
+        buf[pad: pad + 64] = block
+        got, r = gpu_index(ctx, torch_cuda, buf)
+        assert np.array_equal(got, want + np.uint64(pad)) and r.in_quote_out == 0, pad
+
+
 def test_config1_sample_csv_to_tape(ctx, pkg, golden, tmp_path):
     # BASELINE config 1: res/sample.csv -> stage 1 -> tape, end to end through csv_simd::create
     data, exp = golden["sample.csv"]
@@ -408,11 +422,15 @@ def test_device_field_spans_and_gather(ctx, torch_cuda, pkg, golden, oracle):
             stride = 48
             dst = torch.zeros(nrec * stride, dtype=torch.uint8, device="cuda:0")
             ln = torch.zeros(nrec, dtype=torch.int32, device="cuda:0")
-            pkg.gather_fields_device(dbytes.data_ptr(), b.data_ptr(), e.data_ptr(), nrec, dst.data_ptr(), stride, ln.data_ptr())
+            pkg.gather_fields_device(dbytes.data_ptr(), len(data), b.data_ptr(), e.data_ptr(), nrec, dst.data_ptr(), stride,
+                                     ln.data_ptr())
             bh, eh, dh, lh = b.cpu().tolist(), e.cpu().tolist(), dst.cpu().numpy().reshape(nrec, stride), ln.cpu().tolist()
             step = max(1, nrec // 500)
             for rec in list(range(0, nrec, step)) + [nrec - 1]:
-                want = t.seek_field(rec, f)
+                # the definition: seek_field restated line by line in the oracle (src/record_source.rs:106-140);
+                # the product's own host mirror must say the same
+                want = oracle.seek_field(data, host_index, t.field_cnt, t.new_line == "CRLF", rec, f)
+                assert want == t.seek_field(rec, f)
                 assert data[bh[rec]: eh[rec]] == want, (rec, f)
                 assert lh[rec] == len(want)
                 row = bytes(dh[rec][: min(len(want), stride)])

@@ -32,6 +32,40 @@ def test_class_table_all_bytes(oracle):
         assert oracle.lib().oracle_byte_class(b) == want.get(b, 0), hex(b)
 
 
+# The reference holds exactly two more known answers for this path besides src/reader.rs:325-326 — both in
+# prose, not in a test: the worked string-mask example and the two rows of the class table.
+REF_QUOTES, REF_STRING_MASK = 0b100010000, 0b011110000   # src/avx/stage1.rs:350-352, design_notes_1.md:90-91
+REF_LO_ROW = [4, 0, 16, 0, 0, 0, 0, 0, 0, 0, 1, 0, 10, 1, 0, 0]   # design_notes_1.md:130-132 "low nibble ... encode"
+REF_HI_ROW = [1, 0, 22, 0, 0, 8, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]    # design_notes_1.md:136-138 "high nibble ... encode"
+
+
+def known_answer_block():
+    """64 bytes whose quote bits are REF_QUOTES (quotes at bytes 4 and 8) and whose every other byte is a
+    comma: the tape shows the string mask directly — bytes 5, 6, 7 are inside the string, byte 9 is not."""
+    b = np.full(64, 0x2C, dtype=np.uint8)
+    b[4] = b[8] = 0x22
+    want = np.array([i for i in range(64) if not (REF_STRING_MASK >> i) & 1 and i != 8], dtype=np.uint64)
+    return b, want
+
+
+def test_reference_worked_example_string_mask(oracle):
+    L = oracle.lib()
+    assert L.oracle_string_mask_clmul(REF_QUOTES) == REF_STRING_MASK      # what the reference executes
+    assert L.oracle_string_mask_loop(REF_QUOTES) == REF_STRING_MASK       # the recipe in the notes
+    rng = np.random.default_rng(3)
+    for q in [0, 1, 1 << 63, (1 << 64) - 1] + [int(x) for x in rng.integers(0, 2**63, size=200, dtype=np.uint64)]:
+        assert L.oracle_string_mask_clmul(q) == L.oracle_string_mask_loop(q)
+    # ... and through both restatements of the whole path
+    block, want = known_answer_block()
+    assert np.array_equal(oracle.scalar_index(block)[0], want)
+    assert np.array_equal(oracle.sse_read(block)[1:], want)
+
+
+def test_reference_class_table_rows(oracle):
+    for b in range(256):
+        assert oracle.lib().oracle_byte_class(b) == (REF_LO_ROW[b & 15] & REF_HI_ROW[b >> 4]), hex(b)
+
+
 def test_scalar_equals_sse_random(oracle):
     rng = np.random.default_rng(1234)
     lengths = list(range(64, 64 + 130)) + [255, 256, 257, 1000, 4095, 4096, 4097, 10000]
