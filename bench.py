@@ -363,6 +363,84 @@ def ingest_leg(pkg, sb, sample_bytes):
                     "tape -> caller's tape (chunks pipelined over three streams); PCIe-inclusive, never part of `value`"}
 
 
+def consumers_leg(pkg, oracle, device):
+    """§8f rank 3 — the reference's stated use of the tape ("frequency counts, and function search",
+    design_notes_1.md:1-4) on a device-resident tape of the 16x32 corpus (1 GiB, 2.03 M records, one column):
+    wall time of the synchronous entry points, best of 3.  Algorithmic bytes per record = its two tape entries
+    (16 B) + its field text; HBM moves whole 64/128-byte sectors of a row-major file, so a single column of a
+    528-byte row cannot come near the streaming roofline — reported, not hidden."""
+    name = "16x32_noquote"
+    cols, width, seed, q = pkg.WORKLOADS[name]
+    n = pkg.workload_len(name, 1 << 30)
+    dbytes = torch.empty(n, dtype=torch.uint8, device=device)
+    pkg.synth_fill_device(dbytes.data_ptr(), 0, n, cols, width, seed, q)
+    entries = n // (width + 1)
+    dindex = torch.zeros(entries + 2, dtype=torch.int64, device=device)
+    ctx = pkg.Context(device.index)
+    r = ctx.stage1_index_device(dbytes.data_ptr(), n, 0, 0, dindex.data_ptr() + 8, entries + 1)
+    index_len, rows = r.count + 1, r.count // cols
+    nrec, field = rows - 1, 5
+    whole = (0, cols, rows * cols, nrec)
+    args = (dbytes.data_ptr(), dindex.data_ptr(), index_len, cols, "LF")
+
+    def best(fn, reps=3):
+        t = None
+        for _ in range(reps):
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            out = fn()
+            torch.cuda.synchronize(device)
+            dt = time.perf_counter() - t0
+            t = dt if t is None else min(t, dt)
+        return t, out
+
+    alg = nrec * (16 + width)
+    res = {"workload": f"{name} 1 GiB: {nrec} records, column {field} ({width}-byte fields)",
+           "algorithmic_bytes": alg, "note": "bytes per record = 2 tape entries + field text; sector-granular HBM traffic "
+                                             "of one column of a row-major file is several times that"}
+    # spans + gather of the column
+    b = torch.empty(nrec, dtype=torch.int64, device=device)
+    e = torch.empty(nrec, dtype=torch.int64, device=device)
+    dst = torch.empty(nrec * 32, dtype=torch.uint8, device=device)
+
+    def spans_gather():
+        pkg.chunk_field_spans_device(args[1], index_len, cols, "LF", whole, field, b.data_ptr(), e.data_ptr())
+        pkg.gather_fields_device(args[0], n, b.data_ptr(), e.data_ptr(), nrec, dst.data_ptr(), 32)
+    t, _ = best(spans_gather)
+    ok = bool((e - b == width).all()) and bytes(dst[:32].cpu().numpy()) == bytes(dbytes[int(b[0]): int(e[0])].cpu().numpy())
+    res["spans_plus_gather"] = {"ms": round(t * 1e3, 3), "GBps_algorithmic": round((alg + nrec * 48) / t / 1e9, 1)}
+    # frequency count (all values distinct: the table's worst case)
+    slots = 1 << 22
+    scratch = torch.empty(pkg.column_frequency_scratch_bytes(slots), dtype=torch.uint8, device=device)
+    ent = torch.empty((nrec + 8, 4), dtype=torch.int64, device=device)
+    t, st = best(lambda: pkg.column_frequency_device(ctx, *args, [whole], field, scratch.data_ptr(), slots, ent.data_ptr(),
+                                                     ent.shape[0]))
+    ok = ok and st.n_records == nrec and st.collisions == 0 and int(ent[: st.n_distinct, 3].sum()) == nrec
+    # the CPU definition on a bounded sample: first 50 k records
+    host = dbytes[: 50001 * cols * (width + 1)].cpu().numpy().tobytes()
+    hidx = dindex[: 50001 * cols + 1].cpu().numpy().view(np.uint64)
+    sample = (0, cols, 50001 * cols, 50000)
+    want = oracle.column_frequency(host, hidx, cols, False, [sample], field)
+    st_s = pkg.column_frequency_device(ctx, args[0], args[1], 50001 * cols + 1, cols, "LF", [sample], field,
+                                       scratch.data_ptr(), slots, ent.data_ptr(), ent.shape[0])
+    got = {host[b_: e_]: c for _, b_, e_, c in ent[: st_s.n_distinct].cpu().tolist()}
+    ok = ok and got == dict(want)
+    res["frequency_count"] = {"ms": round(t * 1e3, 3), "distinct": int(st.n_distinct),
+                              "GBps_algorithmic": round(2 * alg / t / 1e9, 1),
+                              "note": "insert pass + byte-for-byte verification pass (exact counts)"}
+    # search
+    needle = host[int(hidx[1000 * cols + field]) + 4: int(hidx[1000 * cols + field]) + 10]
+    bm = torch.zeros((nrec + 63) // 64 + 1, dtype=torch.int64, device=device)
+    t, hits = best(lambda: pkg.column_search_device(ctx, args[0], n, *args[1:], whole, field, needle, pkg.SEARCH_CONTAINS, bm.data_ptr()))
+    hits_s = pkg.column_search_device(ctx, args[0], n, args[1], 50001 * cols + 1, cols, "LF", sample, field, needle,
+                                      pkg.SEARCH_CONTAINS, bm.data_ptr())
+    ok = ok and hits >= 1 and hits_s == len(oracle.column_search(host, hidx, cols, False, sample, field, needle, 2))
+    res["search_contains"] = {"ms": round(t * 1e3, 3), "matches": int(hits), "GBps_algorithmic": round(alg / t / 1e9, 1)}
+    res["verified"] = bool(ok)
+    ctx.close()
+    return res
+
+
 def run_sharded(pkg, sb, device, dist_on, rehearsal, comm, steps, warmup):
     """Times `steps` steps of the workload in `sb`; returns (dt, state of the last step)."""
     from csv_simd_amd import sharded
@@ -585,6 +663,8 @@ def main():
                     failed = failed or not extra[name]["verified"]
                 del del_sb
             out["other_workloads"] = extra
+            out["consumers"] = consumers_leg(pkg, oracle, device)
+            failed = failed or not out["consumers"]["verified"]
         if not args.no_ingest:
             out["ingest"] = ingest_leg(pkg, sb, 2 << 30)
             failed = failed or not out["ingest"]["verified"]

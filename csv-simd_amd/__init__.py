@@ -173,7 +173,7 @@ _PROTOTYPES = {
     "csvsimd_column_frequency_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int,
                                                   C.POINTER(_Chunk), C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64,
                                                   C.c_void_p, C.c_uint64, C.POINTER(FreqStatus), C.c_void_p]),
-    "csvsimd_column_search_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int,
+    "csvsimd_column_search_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int,
                                                C.POINTER(_Chunk), C.c_uint32, C.c_char_p, C.c_uint32, C.c_int,
                                                C.c_void_p, _u64p, C.c_void_p]),
     "csvsimd_bitmap_select_scratch_bytes": (C.c_uint64, [C.c_uint64]),
@@ -567,12 +567,13 @@ def column_frequency_device(ctx: "Context", dbytes: int, dindex: int, index_len:
     return st
 
 
-def column_search_device(ctx: "Context", dbytes: int, dindex: int, index_len: int, field_cnt: int, new_line: str,
-                         chunk, field_idx: int, needle: bytes, mode: int, d_bitmap: int, stream: int = 0) -> int:
+def column_search_device(ctx: "Context", dbytes: int, bytes_len: int, dindex: int, index_len: int, field_cnt: int,
+                         new_line: str, chunk, field_idx: int, needle: bytes, mode: int, d_bitmap: int,
+                         stream: int = 0) -> int:
     """Bitmap of the chunk's records whose field equals / starts with / contains `needle`; returns the match count."""
     n = C.c_uint64()
     ch = _chunk(chunk)
-    _check(lib().csvsimd_column_search_device(ctx._h, dbytes, dindex, index_len, field_cnt,
+    _check(lib().csvsimd_column_search_device(ctx._h, dbytes, bytes_len, dindex, index_len, field_cnt,
                                               NEWLINE_CRLF if new_line == "CRLF" else NEWLINE_LF, C.byref(ch),
                                               field_idx, needle, len(needle), mode, d_bitmap or None, C.byref(n),
                                               stream or None))

@@ -857,7 +857,7 @@ int csvsimd_column_frequency_device(csvsimd_ctx* ctx, const void* dbytes, const 
     return CSVSIMD_OK;
 }
 
-int csvsimd_column_search_device(csvsimd_ctx* ctx, const void* dbytes, const void* dindex, uint64_t index_len,
+int csvsimd_column_search_device(csvsimd_ctx* ctx, const void* dbytes, uint64_t bytes_len, const void* dindex, uint64_t index_len,
                                  uint32_t field_cnt, int new_line, const csvsimd_chunk* chunk, uint32_t field_idx,
                                  const void* needle, uint32_t needle_len, int mode, void* d_bitmap, uint64_t* n_matches,
                                  void* hip_stream) {
@@ -875,7 +875,7 @@ int csvsimd_column_search_device(csvsimd_ctx* ctx, const void* dbytes, const voi
     // the needle and the match counter live in the context's small device block: [0, 8) counter, [64, 64 + 264) needle
     HIP_TRY(hipMemsetAsync(ctx->d_small, 0, 8, s));
     if (needle_len) HIP_TRY(hipMemcpyAsync((char*)ctx->d_small + 64, needle, needle_len, hipMemcpyHostToDevice, s));
-    HIP_TRY(csvsimd::launch_search(dbytes, dindex, chunk->start, row_size, n, field_idx, (char*)ctx->d_small + 64, needle_len,
+    HIP_TRY(csvsimd::launch_search(dbytes, bytes_len, dindex, chunk->start, row_size, n, field_idx, (char*)ctx->d_small + 64, needle_len,
                                    mode, d_bitmap, ctx->d_small, s));
     HIP_TRY(hipMemcpyAsync(n_matches, ctx->d_small, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));

@@ -229,10 +229,19 @@ struct FreqEntry {  // == csvsimd_freq_entry: 32 bytes
 };
 __global__ void freq_compact_kernel(const FreqSlot* __restrict__ table, u64 slots, const u64* __restrict__ index, u64 jump,
                                     u32 field, FreqEntry* __restrict__ out, u64 out_cap, FreqStatus* __restrict__ status) {
-    for (u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x; s < slots; s += (u64)gridDim.x * blockDim.x) {
-        if (table[s].hash == 0) continue;
-        const u64 at = atomicAdd((unsigned long long*)&status->n_distinct, 1ull);
-        if (at >= out_cap) continue;
+    const u32 lane = threadIdx.x & 63u;
+    // whole waves walk the table so that one atomic per wave (not per entry) reserves the output slots
+    const u64 n_iter = (slots + (u64)gridDim.x * blockDim.x - 1) / ((u64)gridDim.x * blockDim.x);
+    for (u64 it = 0; it < n_iter; ++it) {
+        const u64 s = it * gridDim.x * blockDim.x + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+        const bool used = s < slots && table[s].hash != 0;
+        const u64 mask = __ballot(used);
+        if (mask == 0) continue;
+        u64 base = 0;
+        if (lane == 0) base = atomicAdd((unsigned long long*)&status->n_distinct, (unsigned long long)__builtin_popcountll(mask));
+        base = ((u64)(u32)__shfl((int)(u32)(base >> 32), 0) << 32) | (u32)__shfl((int)(u32)base, 0);
+        const u64 at = base + (u64)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+        if (!used || at >= out_cap) continue;
         const u64 row = ~table[s].first_inv;
         const u64 k = row * jump + field;
         out[at] = FreqEntry{row - 1, index[k] + 1, index[k + 1], table[s].count};  // record id as seek_field counts
@@ -247,13 +256,30 @@ __global__ void freq_compact_kernel(const FreqSlot* __restrict__ table, u64 slot
 // ---------------------------------------------------------------------------------------------
 static constexpr u32 kMaxNeedle = 256;
 
-__global__ __launch_bounds__(256) void search_kernel(const Column c, const uint8_t* __restrict__ needle, u32 m, int mode,
+// 8 bytes at p, never touching a byte at or past `limit` (the end of the file buffer): bytes past it read as 0
+__device__ __forceinline__ u64 load8_guarded(const uint8_t* p, const uint8_t* limit) {
+    if (p + 8 <= limit) return *reinterpret_cast<const u64u*>(p);
+    u64 v = 0;
+    for (u32 j = 0; j < 8 && p + j < limit; ++j) v |= (u64)p[j] << (8 * j);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void search_kernel(const Column c, const uint8_t* __restrict__ bytes_end,
+                                                     const uint8_t* __restrict__ needle, u32 m, int mode,
                                                      u64* __restrict__ bitmap, u64* __restrict__ count) {
-    __shared__ uint8_t s_needle[kMaxNeedle + 8];
-    for (u32 k = threadIdx.x; k < kMaxNeedle + 8; k += blockDim.x) s_needle[k] = k < m ? needle[k] : (uint8_t)0;
+    __shared__ u64 s_needle[kMaxNeedle / 8 + 1];  // the needle as little-endian words, zero padded
+    for (u32 k = threadIdx.x; k < kMaxNeedle / 8 + 1; k += blockDim.x) {
+        u64 w = 0;
+        for (u32 j = 0; j < 8; ++j)
+            if (8 * k + j < m) w |= (u64)needle[8 * k + j] << (8 * j);
+        s_needle[k] = w;
+    }
     __syncthreads();
     const u64 n_words = (c.n_rows + 63) / 64;
     const u32 lane = threadIdx.x & 63u;
+    const u32 head = m < 8 ? m : 8;                                   // bytes of the needle in its first word
+    const u64 head_mask = head == 8 ? ~0ull : ((1ull << (8 * head)) - 1ull);
+    const u64 needle0 = s_needle[0];
     u32 hits = 0;
     for (u64 word = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; word < n_words;
          word += ((u64)gridDim.x * blockDim.x) >> 6) {
@@ -264,21 +290,37 @@ __global__ __launch_bounds__(256) void search_kernel(const Column c, const uint8
             field_span(c, i, b, e);
             const u64 n = e - b;
             const uint8_t* p = c.bytes + b;
-            if (mode == 0) {
-                match = n == m;
-            } else {
-                match = n >= m;
-            }
-            if (match && mode != 2) {
-                for (u32 k = 0; k < m && match; ++k) match = p[k] == s_needle[k];
-            } else if (match) {  // contains
-                match = m == 0;
-                const uint8_t first = s_needle[0];
-                for (u64 at = 0; at + m <= n && !match; ++at) {
-                    if (p[at] != first) continue;
-                    u32 k = 1;
-                    while (k < m && p[at + k] == s_needle[k]) ++k;
-                    match = k == m;
+            if (mode != 2) {
+                // equals / starts with: the first m bytes, a word at a time
+                match = mode == 0 ? n == m : n >= m;
+                for (u32 k = 0; 8 * k < m && match; ++k) {
+                    const u32 left = m - 8 * k;
+                    const u64 mask = left >= 8 ? ~0ull : ((1ull << (8 * left)) - 1ull);
+                    match = ((load8_guarded(p + 8 * k, bytes_end) ^ s_needle[k]) & mask) == 0;
+                }
+            } else if (m == 0) {
+                match = true;
+            } else if (n >= m) {
+                // contains: every start position `at` sees the 8 bytes from it as a view of two loaded words — one
+                // load per 8 positions instead of one per byte; needles longer than 8 bytes verify the rest on a hit
+                const u64 last = n - m;  // last start position
+                u64 cur = load8_guarded(p, bytes_end);
+                for (u64 base = 0; base <= last && !match; base += 8) {
+                    const u64 nxt = load8_guarded(p + base + 8, bytes_end);
+#pragma unroll
+                    for (u32 j = 0; j < 8; ++j) {
+                        const u64 view = j ? (cur >> (8 * j)) | (nxt << (64 - 8 * j)) : cur;
+                        if (base + j <= last && ((view ^ needle0) & head_mask) == 0) {
+                            bool ok = true;
+                            for (u32 k = 1; 8 * k < m && ok; ++k) {
+                                const u32 left = m - 8 * k;
+                                const u64 mask = left >= 8 ? ~0ull : ((1ull << (8 * left)) - 1ull);
+                                ok = ((load8_guarded(p + base + j + 8 * k, bytes_end) ^ s_needle[k]) & mask) == 0;
+                            }
+                            match = match || ok;
+                        }
+                    }
+                    cur = nxt;
                 }
             }
         }
@@ -418,12 +460,13 @@ hipError_t launch_freq_compact(const void* d_table, u64 slots, const void* dinde
     return hipGetLastError();
 }
 
-hipError_t launch_search(const void* dbytes, const void* dindex, u64 first_key, u64 jump, u64 n_rows, u32 field,
+hipError_t launch_search(const void* dbytes, u64 bytes_len, const void* dindex, u64 first_key, u64 jump, u64 n_rows, u32 field,
                          const void* d_needle, u32 needle_len, int mode, void* d_bitmap, void* d_count, hipStream_t stream) {
     if (n_rows == 0) return hipSuccess;
     const Column c = make_column(dbytes, dindex, first_key, jump, n_rows, field);
-    hipLaunchKernelGGL(search_kernel, dim3(grid_for(n_rows, 256, 8192)), dim3(256), 0, stream, c, (const uint8_t*)d_needle,
-                       needle_len, mode, (u64*)d_bitmap, (u64*)d_count);
+    hipLaunchKernelGGL(search_kernel, dim3(grid_for(n_rows, 256, 8192)), dim3(256), 0, stream, c,
+                       (const uint8_t*)dbytes + bytes_len, (const uint8_t*)d_needle, needle_len, mode, (u64*)d_bitmap,
+                       (u64*)d_count);
     return hipGetLastError();
 }
 

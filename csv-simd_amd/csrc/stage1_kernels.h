@@ -87,7 +87,7 @@ hipError_t launch_freq_verify(const void* dbytes, const void* dindex, uint64_t f
                               hipStream_t stream);
 hipError_t launch_freq_compact(const void* d_table, uint64_t slots, const void* dindex, uint64_t jump, uint32_t field,
                                void* d_out, uint64_t out_cap, void* d_status, hipStream_t stream);
-hipError_t launch_search(const void* dbytes, const void* dindex, uint64_t first_key, uint64_t jump, uint64_t n_rows,
+hipError_t launch_search(const void* dbytes, uint64_t bytes_len, const void* dindex, uint64_t first_key, uint64_t jump, uint64_t n_rows,
                          uint32_t field, const void* d_needle, uint32_t needle_len, int mode, void* d_bitmap, void* d_count,
                          hipStream_t stream);
 hipError_t launch_bitmap_select(const void* d_bitmap, uint64_t n_rows, uint64_t first_row, void* d_block_scratch,

@@ -298,12 +298,14 @@ int csvsimd_column_frequency_device(csvsimd_ctx* ctx, const void* dbytes, const 
                                     void* hip_stream);
 
 /* Search in column field_idx of one chunk: bit i of d_bitmap (uint64 words, (record_cnt + 63) / 64 of them,
- * bit i of word i / 64) is set iff the chunk's i-th record matches; *n_matches = how many do.  needle is HOST
+ * bit i of word i / 64) is set iff the chunk's i-th record matches; *n_matches = how many do.  dbytes[0..bytes_len)
+ * is the file (fields are read 8 bytes at a time, never past bytes_len).  needle is HOST
  * memory, at most 256 bytes.  Definitions checked against Python's ==, bytes.startswith, `needle in field`. */
 #define CSVSIMD_SEARCH_EQUALS 0
 #define CSVSIMD_SEARCH_STARTS_WITH 1
 #define CSVSIMD_SEARCH_CONTAINS 2
-int csvsimd_column_search_device(csvsimd_ctx* ctx, const void* dbytes, const void* dindex, uint64_t index_len,
+int csvsimd_column_search_device(csvsimd_ctx* ctx, const void* dbytes, uint64_t bytes_len, const void* dindex,
+                                 uint64_t index_len,
                                  uint32_t field_cnt, int new_line, const csvsimd_chunk* chunk, uint32_t field_idx,
                                  const void* needle, uint32_t needle_len, int mode, void* d_bitmap,
                                  uint64_t* n_matches, void* hip_stream);

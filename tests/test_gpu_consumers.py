@@ -89,12 +89,14 @@ def test_chunk_spans_frequency_and_search(ctx, pkg, oracle, torch_cuda, line_end
         for f, needle, mode in ((1, b"Oslo", pkg.SEARCH_EQUALS), (1, b"Os", pkg.SEARCH_STARTS_WITH),
                                 (3, b"needle", pkg.SEARCH_CONTAINS), (1, b"", pkg.SEARCH_EQUALS),
                                 (1, b"", pkg.SEARCH_CONTAINS), (2, b"qz", pkg.SEARCH_CONTAINS),
-                                (1, b'"Washington, D.C."', pkg.SEARCH_EQUALS), (3, b"yy", pkg.SEARCH_CONTAINS)):
+                                (1, b'"Washington, D.C."', pkg.SEARCH_EQUALS), (3, b"yy", pkg.SEARCH_CONTAINS),
+                                (1, b"ashington, D.C", pkg.SEARCH_CONTAINS), (1, b'"Washington', pkg.SEARCH_STARTS_WITH),
+                                (3, b"hayy", pkg.SEARCH_CONTAINS), (3, b"xneedleyy", pkg.SEARCH_CONTAINS)):
             for ch in chunks:
                 want = oracle.column_search(dt.data, dt.index, field_cnt, dt.crlf, ch, f, needle, mode)
                 words = (ch[3] + 63) // 64
                 bm = torch.zeros(words + 1, dtype=torch.int64, device="cuda:0")
-                n = pkg.column_search_device(ctx, dbytes, dindex, index_len, field_cnt, new_line, ch, f, needle, mode,
+                n = pkg.column_search_device(ctx, dbytes, len(dt.data), dindex, index_len, field_cnt, new_line, ch, f, needle, mode,
                                              bm.data_ptr())
                 assert n == len(want), (needle, mode, ch)
                 first_record = ch[1] // dt.tape.record_jump_size - 1
@@ -196,10 +198,10 @@ def test_consumers_on_the_synthetic_corpus_at_scale(ctx, pkg, oracle, torch_cuda
     needle = oracle.seek_field(host, hindex, cols, False, 1000, 5)
     bm = torch.zeros((nrec + 63) // 64 + 1, dtype=torch.int64, device="cuda:0")
     whole = (0, jump, rows * jump, nrec)
-    assert pkg.column_search_device(ctx, dbytes.data_ptr(), dindex.data_ptr(), index_len, cols, "LF", whole, 5, needle,
+    assert pkg.column_search_device(ctx, dbytes.data_ptr(), n, dindex.data_ptr(), index_len, cols, "LF", whole, 5, needle,
                                     pkg.SEARCH_EQUALS, bm.data_ptr()) == want[needle]
     hits = oracle.column_search(host, hindex, cols, False, whole, 5, needle[3:9], pkg.SEARCH_CONTAINS)
-    assert pkg.column_search_device(ctx, dbytes.data_ptr(), dindex.data_ptr(), index_len, cols, "LF", whole, 5, needle[3:9],
+    assert pkg.column_search_device(ctx, dbytes.data_ptr(), n, dindex.data_ptr(), index_len, cols, "LF", whole, 5, needle[3:9],
                                     pkg.SEARCH_CONTAINS, bm.data_ptr()) == len(hits) >= 1
     scratch2 = torch.empty(pkg.bitmap_select_scratch_bytes(nrec), dtype=torch.uint8, device="cuda:0")
     ids = torch.zeros(len(hits), dtype=torch.int64, device="cuda:0")
