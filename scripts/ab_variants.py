@@ -31,7 +31,9 @@ for spec in sys.argv[2].split(","):
         assert rc == 0, rc
         best = min(best, ms.value)
     cnt = int(dres[0])
-    out[spec] = [round(best, 4), round(n / best / 1e6 / 8000 * 100, 2), cnt]
+    chk = torch.zeros(2, dtype=torch.int64, device="cuda:0")
+    assert L.csvsimd_tape_checksum_device(vp(dtape.data_ptr()), u64(cnt), u64(1), vp(chk.data_ptr()), None) == 0
+    out[spec] = [round(best, 4), round(n / best / 1e6 / 8000 * 100, 2), cnt, "%016x" % (int(chk[0]) & (2**64 - 1))]
     del dtape, dbuf
 print(json.dumps(out))
 '''
