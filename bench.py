@@ -586,10 +586,14 @@ def main():
         s_ = sb.stream()
         ms_r = sb.ctx.hbm_probe_device(sb.dbuf.data_ptr(), sb.n, sb.dtape.data_ptr(), 0, s_, 1, 5)
         ms_rw = sb.ctx.hbm_probe_device(sb.dbuf.data_ptr(), sb.n, sb.dtape.data_ptr(), 4, s_, 1, 5)
+        ms_rw2 = sb.ctx.hbm_probe_device(sb.dbuf.data_ptr(), sb.n, sb.dtape.data_ptr(), 4, s_, 1, 5, blocks_per_cu=2)
         probed = {"read_only_GBps": round(sb.n / (ms_r * 1e-3) / 1e9, 1),
                   "read_with_quarter_written_GBps": round(sb.n / (ms_rw * 1e-3) / 1e9, 1),
-                  "note": "bare nt stream of the same buffer, 16 waves/CU (csvsimd_hbm_probe_device); "
-                          "the 64x31 corpus writes 8 B of tape per 32 B read"}
+                  "read_with_quarter_written_8_waves_per_cu_GBps": round(sb.n / (ms_rw2 * 1e-3) / 1e9, 1),
+                  "kernel_vs_probe": round(achieved / (sb.n / (ms_rw * 1e-3) / 1e9), 3),
+                  "note": "bare nt stream of the same buffer with none of the work (csvsimd_hbm_probe_device), at the "
+                          "kernel's 16 waves/CU and at the 8 waves/CU where a bare stream peaks; the 64x31 corpus "
+                          "writes 8 B of tape per 32 B read"}
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": load_traffic(args.workload, sb.n),
@@ -656,6 +660,17 @@ def main():
                                "GiB/s": round(del_sb.n / (ms * 1e-3) / 2**30, 2),
                                "hbm_read_frac": round(del_sb.n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                                "read_plus_tape_write_GBps": round((del_sb.n + 8 * r.count) / (ms * 1e-3) / 1e9, 1)}
+                if name == "1024x4_dense":
+                    # what a bare stream reaches with this corpus's write share (1.6 B of tape per byte read)
+                    pm = del_sb.ctx.hbm_probe_device(del_sb.dbuf.data_ptr(), del_sb.n, del_sb.dtape.data_ptr(), 25,
+                                                     del_sb.stream(), 1, 5)
+                    pm2 = del_sb.ctx.hbm_probe_device(del_sb.dbuf.data_ptr(), del_sb.n, del_sb.dtape.data_ptr(), 25,
+                                                      del_sb.stream(), 1, 5, blocks_per_cu=2)
+                    extra[name]["probed_stream"] = {
+                        "hbm_read_frac_16_waves_per_cu": round(del_sb.n / (pm * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                        "hbm_read_frac_8_waves_per_cu": round(del_sb.n / (pm2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                        "note": "bare nt stream writing 25/16 B per byte read, no work at all: the ceiling of this "
+                                "traffic mix on this GPU — a read fraction of 0.30 is out of reach of ANY kernel"}
                 if not args.no_verify:
                     del_sb.run_pass(0)
                     ok, _, _ = torch_reference_compare(del_sb, 0, r.count)

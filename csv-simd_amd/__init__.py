@@ -127,7 +127,7 @@ _PROTOTYPES = {
     "csvsimd_utf8_validate_device_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "csvsimd_utf8_validate_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Utf8Result),
                                                C.c_void_p]),
-    "csvsimd_hbm_probe_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p,
+    "csvsimd_hbm_probe_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                            C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "csvsimd_tape_record_spans_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint64,
                                                    C.c_uint64, C.c_void_p, C.c_void_p, _u64p, C.c_void_p]),
@@ -276,12 +276,12 @@ class Context:
                                                                in_quote_in, dtape or None, tape_cap, d_result,
                                                                stream or None))
 
-    def hbm_probe_device(self, dbuf: int, length: int, dout: int, write_div: int = 0, stream: int = 0,
-                         warmup: int = 2, iters: int = 10) -> float:
-        """ms per pass of the bare HBM stream (read only, or read + 1/4 written)."""
+    def hbm_probe_device(self, dbuf: int, length: int, dout: int, write_per16: int = 0, stream: int = 0,
+                         warmup: int = 2, iters: int = 10, blocks_per_cu: int = 4) -> float:
+        """ms per pass of the bare HBM stream: write_per16 bytes written per 16 read (0, 4 or 25)."""
         ms = C.c_float()
-        _check(lib().csvsimd_hbm_probe_device(self._h, dbuf, length, dout, write_div, stream or None, warmup, iters,
-                                              C.byref(ms)))
+        _check(lib().csvsimd_hbm_probe_device(self._h, dbuf, length, dout, write_per16, blocks_per_cu, stream or None,
+                                              warmup, iters, C.byref(ms)))
         return float(ms.value)
 
     def utf8_validate_device(self, dbuf: int, length: int, stream: int = 0) -> Optional[int]:

@@ -1075,16 +1075,17 @@ uint32_t csvsimd_build_has_probes(void) {
 }
 
 int csvsimd_hbm_probe_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len, void* dout, int write_div,
-                             void* hip_stream, int warmup, int iters, float* avg_ms) {
+                             int blocks_per_cu, void* hip_stream, int warmup, int iters, float* avg_ms) {
     if (!ctx || !dbuf || !avg_ms || iters <= 0 || iters > 4096 || ((uintptr_t)dbuf & 15)) return CSVSIMD_ERR_INVALID_ARG;
-    if (write_div != 0 && write_div != 4) return CSVSIMD_ERR_INVALID_ARG;
+    if ((write_div != 0 && write_div != 4 && write_div != 25) || blocks_per_cu < 1 || blocks_per_cu > 8)
+        return CSVSIMD_ERR_INVALID_ARG;
     if (!dout || ((uintptr_t)dout & 15) || len < 131072) return CSVSIMD_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)hip_stream;
     int rc = csvsimd_ctx_reserve(ctx, 1 << 20);  // the probe's ticket pair lives in the context's control block
     ctx->last_stream = s;
     ctx->launched = true;
     if (rc != CSVSIMD_OK) return rc;
-    const uint32_t blocks = (uint32_t)ctx->n_cus * 4u;  // 16 waves per CU, like the stage-1 kernel
+    const uint32_t blocks = (uint32_t)ctx->n_cus * (uint32_t)blocks_per_cu;  // 4-wave workgroups: 4 per CU = the stage-1 kernel's 16 waves
     for (int i = 0; i < warmup; ++i)
         HIP_TRY(csvsimd::launch_hbm_probe(dbuf, len, dout, write_div, ctx->scratch, blocks, s));
     EventBatch eb;

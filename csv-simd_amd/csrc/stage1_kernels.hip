@@ -1128,9 +1128,11 @@ __global__ void checksum_kernel(const u64* tape, u64 n, u64 first_index, u64* ou
 
 // HBM streaming probe with the stage-1 traffic shape and none of its work: the achievable ceiling
 // the roofline fraction can be read against (bench.py reports it next to the 8 TB/s spec peak).
-// 128-KiB tiles from an atomic ticket, 4 waves x 8 rounds x 4 KiB, non-temporal both ways; WRITE_DIV 0
-// = read only, 4 = one byte written per four read (the 64x31 corpus writes 8 B per 32 B).
-template <int WRITE_DIV>
+// 128-KiB tiles from an atomic ticket, 4 waves x 8 rounds x 4 KiB, non-temporal both ways, line-aligned 1-KiB
+// wave stores.  WR16 = bytes written per 16 bytes read: 0 = read only, 4 = the 64x31 corpus (8 B of tape per
+// 32 B), 25 = the dense corpus (1024 x 4: 8 B of tape per 5 B read = 25.6 / 16; 25 keeps the output inside a
+// tape-sized buffer).
+template <int WR16>
 __global__ __launch_bounds__(256) void hbm_probe_kernel(const uint8_t* __restrict__ in, uint4* __restrict__ out,
                                                         Control* ctl, u32 num_tiles) {
     __shared__ u32 s_tile;
@@ -1144,6 +1146,9 @@ __global__ __launch_bounds__(256) void hbm_probe_kernel(const uint8_t* __restric
         if (tile >= num_tiles) break;
         const u64 tile0 = (u64)tile * 131072;
         const rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(in) + tile0, 0, 131072, 0x00020000);
+        constexpr u32 kOutKiBPerSpan = WR16 * 2;  // this wave's output per 32-KiB span, in 1-KiB wave stores
+        uint4* const obase = out + ((u64)tile * 4 + w) * (kOutKiBPerSpan * 64);
+#pragma unroll
         for (int r0 = 0; r0 < 8; r0 += 2) {
             uint4 v[2][4];
 #pragma unroll
@@ -1161,17 +1166,20 @@ __global__ __launch_bounds__(256) void hbm_probe_kernel(const uint8_t* __restric
                 o.y = v[d][0].y ^ v[d][1].y ^ v[d][2].y ^ v[d][3].y;
                 o.z = v[d][0].z ^ v[d][1].z ^ v[d][2].z ^ v[d][3].z;
                 o.w = v[d][0].w ^ v[d][1].w ^ v[d][2].w ^ v[d][3].w;
-                if (WRITE_DIV == 4) {
-                    const u32x4 x = {o.x, o.y, o.z, o.w};
-                    __builtin_nontemporal_store(
-                        x, reinterpret_cast<u32x4*>(out + tile0 / 64 + (w * 32768u + (u32)(r0 + d) * 4096u) / 64 + lane));
-                } else {
+                if (WR16 == 0) {
                     acc.x ^= o.x; acc.y ^= o.y; acc.z ^= o.z; acc.w ^= o.w;
+                } else {
+                    // 1-KiB stores due after this round: [from, upto)
+                    const u32 from = (u32)(r0 + d) * kOutKiBPerSpan / 8, upto = (u32)(r0 + d + 1) * kOutKiBPerSpan / 8;
+                    for (u32 q = from; q < upto; ++q) {
+                        const u32x4 x = {o.x + q, o.y, o.z, o.w};
+                        __builtin_nontemporal_store(x, reinterpret_cast<u32x4*>(obase + q * 64 + lane));
+                    }
                 }
             }
         }
     }
-    if (WRITE_DIV == 0 && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) out[0] = acc;  // keeps the loads alive
+    if (WR16 == 0 && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) out[0] = acc;  // keeps the loads alive
     // the last workgroup out leaves the ticket pair ready for the next launch (as stage1_kernel does)
     if (t == 0 && atomicAdd(&ctl->probe_done, 1u) == gridDim.x - 1u) {
         ctl->probe_ticket = 0;
@@ -1383,6 +1391,9 @@ hipError_t launch_hbm_probe(const void* din, u64 len, void* dout, int write_div,
     Control* const ctl = reinterpret_cast<Control*>(scratch_base);
     if (write_div == 4)
         hipLaunchKernelGGL(hbm_probe_kernel<4>, dim3(blocks), dim3(256), 0, stream, (const uint8_t*)din, (uint4*)dout,
+                           ctl, tiles);
+    else if (write_div == 25)
+        hipLaunchKernelGGL(hbm_probe_kernel<25>, dim3(blocks), dim3(256), 0, stream, (const uint8_t*)din, (uint4*)dout,
                            ctl, tiles);
     else
         hipLaunchKernelGGL(hbm_probe_kernel<0>, dim3(blocks), dim3(256), 0, stream, (const uint8_t*)din, (uint4*)dout,

@@ -364,13 +364,15 @@ const char* csvsimd_stage1_kernel_name(int emit, const csvsimd_dialect* dialect)
  * csvsimd_stage1_time_device, scripts/probe*.py): never the product library; bench.py refuses such a build. */
 uint32_t csvsimd_build_has_probes(void);
 
-/* HBM streaming probe: the stage-1 traffic shape with none of its work, so bench.py can report
- * the ceiling this GPU actually reaches next to the 8 TB/s spec peak.  Reads dbuf[0..len) (16-byte
- * aligned, len a multiple of 128 KiB is what gets streamed) with non-temporal loads; write_div 0 =
- * read only, 4 = also writes len / 4 bytes to dout (>= len / 4 bytes, 16-byte aligned).  Average ms
- * of `iters` launches by hipEvents on hip_stream. */
-int csvsimd_hbm_probe_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len, void* dout, int write_div,
-                             void* hip_stream, int warmup, int iters, float* avg_ms);
+/* HBM streaming probe: the stage-1 traffic shape with none of its work, so bench.py can report the
+ * ceiling this GPU actually reaches next to the 8 TB/s spec peak.  Reads dbuf[0..len) (16-byte aligned; whole
+ * 128-KiB tiles are streamed) with non-temporal loads and writes write_per16 bytes per 16 bytes read to dout
+ * (>= len * write_per16 / 16 bytes, 16-byte aligned) in line-aligned 1-KiB wave stores: 0 = read only, 4 = the
+ * 64-col corpus's share of tape writes, 25 = the dense corpus's (1.56 B written per byte read).
+ * blocks_per_cu x 4 waves per CU (4 = the stage-1 kernel's 16 waves; 2 is where a bare stream peaks).
+ * Average ms of `iters` launches by hipEvents on hip_stream. */
+int csvsimd_hbm_probe_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len, void* dout, int write_per16,
+                             int blocks_per_cu, void* hip_stream, int warmup, int iters, float* avg_ms);
 
 #ifdef __cplusplus
 }
