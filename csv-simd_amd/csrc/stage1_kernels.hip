@@ -639,6 +639,24 @@ struct KernelArgs {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// Window slot of entry k (opt-in build knob, default off).  A lane scatters its stripe's entries to consecutive
+// ranks, so in one ds_write_b16 the 64 lanes hit ranks that are `entries per stripe` apart: on a regular dense file
+// (1024 x 4: 12.8 per stripe) that is a stride of 6.4 dwords, i.e. only five of the 32 banks (SQ_LDS_BANK_CONFLICT =
+// 43.6 M per GiB, profiles/r02_pmc_1024x4_dense_1GiB.json).  XOR-ing the bank bits (1..5 of the u16 index) with
+// the next five index bits removes the conflicts (profiles/r02_pmc_dense_swizzled_window.json) — and changes the
+// kernel time by less than 1 %: the scatter is not what bounds the dense corpus (its HBM write share is, DESIGN.md
+// §4), and the three extra VALU per entry cost the sparse corpora 1-3 %.  Measured, kept as a knob, not the default.
+#ifndef CSVSIMD_WINDOW_SWIZZLE
+#define CSVSIMD_WINDOW_SWIZZLE 0
+#endif
+__device__ __forceinline__ u32 comp_slot(u32 k) {
+#if CSVSIMD_WINDOW_SWIZZLE
+    return k ^ (((k >> 6) & 31u) << 1);
+#else
+    return k;
+#endif
+}
+
 // Writes window entries comp[0, n) (u16 offsets relative to the span) to tape[run, run + n) as
 // fully coalesced non-temporal stores, 16 bytes (two entries) per lane wherever the address allows.
 template <bool NOSTORE = false>
@@ -655,12 +673,13 @@ __device__ __forceinline__ void flush_window(const KernelArgs& args, const unsig
     // corpus, whose tape offsets are not a multiple of the line.
     u32 head = (0u - (u32)(((uintptr_t)tape >> 3) + run)) & (u32)(kStoreAlignEntries - 1);
     head = head < n ? head : n;
-    if (lane < head && run + lane < tape_cap) __builtin_nontemporal_store(span_off + comp[lane], tape + run + lane);
+    if (lane < head && run + lane < tape_cap)
+        __builtin_nontemporal_store(span_off + comp[comp_slot(lane)], tape + run + lane);
     const u32 npairs = (n - head) >> 1;
     for (u32 i = lane; i < npairs; i += 64) {
         const u32 k = head + 2 * i;
         const u64 idx = run + k;
-        const u64 e0 = span_off + comp[k], e1 = span_off + comp[k + 1];
+        const u64 e0 = span_off + comp[comp_slot(k)], e1 = span_off + comp[comp_slot(k + 1)];
         if (idx + 1 < tape_cap) {
             const u32x4 x = {(u32)e0, (u32)(e0 >> 32), (u32)e1, (u32)(e1 >> 32)};
             __builtin_nontemporal_store(x, reinterpret_cast<u32x4*>(tape + idx));
@@ -670,7 +689,7 @@ __device__ __forceinline__ void flush_window(const KernelArgs& args, const unsig
     }
     if (((n - head) & 1u) && lane == 0) {
         const u64 idx = run + n - 1;
-        if (idx < tape_cap) __builtin_nontemporal_store(span_off + comp[n - 1], tape + idx);
+        if (idx < tape_cap) __builtin_nontemporal_store(span_off + comp[comp_slot(n - 1)], tape + idx);
     }
 }
 
@@ -687,13 +706,13 @@ __device__ __forceinline__ void scatter_bits(unsigned short* comp, u64 R, u32 p,
     while (lo) {
         const u32 b = (u32)__builtin_ctz(lo);
         lo &= lo - 1;
-        if (p < (u32)kCompCap) comp[p] = (unsigned short)(stripe_rel + b);
+        if (p < (u32)kCompCap) comp[comp_slot(p)] = (unsigned short)(stripe_rel + b);
         ++p;
     }
     while (hi) {
         const u32 b = (u32)__builtin_ctz(hi) + 32u;
         hi &= hi - 1;
-        if (p < (u32)kCompCap) comp[p] = (unsigned short)(stripe_rel + b);
+        if (p < (u32)kCompCap) comp[comp_slot(p)] = (unsigned short)(stripe_rel + b);
         ++p;
     }
 }
@@ -1132,6 +1151,8 @@ __global__ void checksum_kernel(const u64* tape, u64 n, u64 first_index, u64* ou
 // wave stores.  WR16 = bytes written per 16 bytes read: 0 = read only, 4 = the 64x31 corpus (8 B of tape per
 // 32 B), 25 = the dense corpus (1024 x 4: 8 B of tape per 5 B read = 25.6 / 16; 25 keeps the output inside a
 // tape-sized buffer).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wpass-failed"  // the WR16 == 0 instantiation has nothing to unroll in its store loop
 template <int WR16>
 __global__ __launch_bounds__(256) void hbm_probe_kernel(const uint8_t* __restrict__ in, uint4* __restrict__ out,
                                                         Control* ctl, u32 num_tiles) {
@@ -1186,6 +1207,8 @@ __global__ __launch_bounds__(256) void hbm_probe_kernel(const uint8_t* __restric
         ctl->probe_done = 0;
     }
 }
+
+#pragma clang diagnostic pop
 
 // self-test of the wavefront primitives against plain loops (one wave); out[0] = failure bits
 __global__ void selftest_kernel(u32* out) {

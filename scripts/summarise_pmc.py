@@ -33,7 +33,8 @@ def main():
                 per_counter[row["Counter_Name"]][key] += float(row["Counter_Value"])
     counters = {c: {"dispatches": len(v), "avg": sum(v.values()) / len(v)} for c, v in sorted(per_counter.items())}
     d = {"command": "rocprofv3 --pmc <one counter group per pass> --output-format csv -- python3 bench.py --steps 10 "
-                    "--warmup 2 --no-extra --no-cpu-baseline",
+                    "--warmup 2 --no-extra --no-cpu-baseline --no-verify --no-q10-check --no-ingest "
+                    "(scripts/collect_profiles_r02.sh)",
          "kernel": sorted(name_seen), "workload": workload, "counters": counters}
     g = lambda c: counters[c]["avg"] if c in counters else None
     der = {}
