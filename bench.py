@@ -641,7 +641,7 @@ def main():
                                  "GiB/s": round(sbq.total * k / dtq / 2**30, 2), "verified": vq}
         if rank == 0 and world == 1:
             ms = sbq.ctx.stage1_time_device(sbq.dbuf.data_ptr(), sbq.n, sbq.dtape.data_ptr(), sbq.cap,
-                                            sbq.d_result.data_ptr(), sbq.stream(), 2, 5)
+                                            sbq.d_result.data_ptr(), sbq.stream(), 3, 10)
             out["q10_skew_check"]["kernel_ms"] = round(ms, 4)
             out["q10_skew_check"]["hbm_read_frac"] = round(sbq.n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
         del sbq
