@@ -111,7 +111,6 @@ _PROTOTYPES = {
     "csvsimd_tile_bytes": (C.c_uint32, []),
     "csvsimd_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "csvsimd_ctx_destroy": (None, [C.c_void_p]),
-    "csvsimd_ctx_set_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "csvsimd_ctx_reserve": (C.c_int, [C.c_void_p, C.c_uint64]),
     "csvsimd_stage1_index_device_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32,
                                                     C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
@@ -231,13 +230,6 @@ class Context:
         _check(lib().csvsimd_ctx_create(device, C.byref(h)))
         self._h = h
         self.device = device
-        v = os.environ.get("CSVSIMD_TEST_VARIANT")   # tests only: run a whole suite on the other kernel structure
-        if v:
-            self.set_variant(int(v))
-
-    def set_variant(self, variant: int) -> None:
-        """0 = paired workgroups (two per CU), 1 = streaming (one per CU); same results bit for bit."""
-        _check(lib().csvsimd_ctx_set_variant(self._h, variant))
 
     def reserve(self, max_len: int) -> None:
         _check(lib().csvsimd_ctx_reserve(self._h, max_len))

@@ -122,7 +122,6 @@ struct csvsimd_ctx {
     int device = 0;
     void* scratch = nullptr;
     uint64_t scratch_bytes = 0;
-    int variant = 0;                    // kernel structure for the reference dialect (stage1_kernels.h)
     hipStream_t last_stream = nullptr;  // stream of the most recent launch that used the scratch
     bool launched = false;
     uint32_t max_blocks = 0;
@@ -207,12 +206,6 @@ int csvsimd_ctx_create(int device, csvsimd_ctx** out) {
     return rc;
 }
 
-int csvsimd_ctx_set_variant(csvsimd_ctx* ctx, int variant) {
-    if (!ctx || (variant != CSVSIMD_VARIANT_PAIRED && variant != CSVSIMD_VARIANT_STREAMING)) return CSVSIMD_ERR_INVALID_ARG;
-    ctx->variant = variant;
-    return CSVSIMD_OK;
-}
-
 void csvsimd_ctx_destroy(csvsimd_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
@@ -292,8 +285,6 @@ static int stage1_async_impl(csvsimd_ctx* ctx, const csvsimd_dialect* dialect, c
     L.d_result = (csvsimd_shard_result*)d_result;
     L.bind_scratch(ctx->scratch);
     L.max_blocks = ctx->max_blocks;
-    L.stream_blocks = (uint32_t)ctx->n_cus;
-    L.variant = ctx->variant;
     L.d_state = d_state;
     if (dialect) {
         L.delimiter = dialect->delimiter;
@@ -993,8 +984,6 @@ int csvsimd_stage1_time_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len,
     L.d_result = (csvsimd_shard_result*)d_result;
     L.bind_scratch(ctx->scratch);
     L.max_blocks = ctx->max_blocks;
-    L.stream_blocks = (uint32_t)ctx->n_cus;
-    L.variant = ctx->variant;
 #ifdef CSVSIMD_DEV_PROBES
     // development builds only (libcsvsimd_probes.so for scripts/probe*.py): the product library has neither
     // these hooks nor the kernel instantiations behind them
@@ -1013,7 +1002,6 @@ int csvsimd_stage1_time_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len,
             L.escape = (uint8_t)e;
         }
     }
-    if (const char* e = getenv("CSVSIMD_PROBE_VARIANT")) L.variant = atoi(e);
     if (const char* e = getenv("CSVSIMD_PROBE_EMIT_DELAY")) L.pace_emit_delay = atoi(e);
     if (const char* e = getenv("CSVSIMD_PROBE_COUNT_PRIO")) L.pace_count_prio = atoi(e);
     if (L.debug_mode == 8) HIP_TRY(hipMemsetAsync(L.scratch_prof, 0, 17 * 8, s));
@@ -1062,9 +1050,7 @@ int csvsimd_stage1_time_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len,
         const double nwg = h[16] ? (double)h[16] : 1.0;
         fprintf(stderr, "PROF %llu workgroup runs over %d launches (normalising by the former)\n",
                 (unsigned long long)h[16], warmup + iters);
-        static const char* names_paired[6] = {"ticket+barrier T", "count phase", "barrier A", "publish+resolve", "barrier B", "emit"};
-        static const char* names_stream[6] = {"flush", "count phase", "barrier A", "publish+resolve", "barrier B", "scatter"};
-        const char* const* names = L.variant == 1 ? names_stream : names_paired;
+        static const char* names[6] = {"ticket+barrier T", "count phase", "barrier A", "publish+resolve", "barrier B", "emit"};
         for (int wv = 0; wv < 2; ++wv)
             for (int k = 0; k < 6; ++k)
                 fprintf(stderr, "PROF wave%d %-16s %.2f us per workgroup (sum over its tiles)\n", wv, names[k],

@@ -46,8 +46,6 @@ struct Stage1Launch {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     int debug_mode = 0;  // development probes (-DCSVSIMD_DEV_PROBES builds only; see stage1_kernel's DBG)
     int pace_emit_delay = -1, pace_count_prio = -1;  // -1 = chosen from the launch size (launch_stage1)
-    int variant = 0;             // 0 = two workgroups per CU (stage1_kernel), 1 = streaming, one per CU (reference dialect only)
-    uint32_t stream_blocks = 256;  // grid of the streaming variant: one workgroup per CU
     // dialect extension (csvsimd_dialect): the defaults are the reference's hard-wired dialect
     uint8_t delimiter = ',', quote = '"', escape = 0;
     uint32_t escape_in = 0;

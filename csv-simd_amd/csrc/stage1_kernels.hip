@@ -297,11 +297,8 @@ __device__ __forceinline__ void publish_aggregate(u64* desc, u32 tile, u32 epoch
 // publishes its inclusive word.  Whole wave; every poll looks at 256 predecessors (4 per lane):
 // on MI355X a cross-XCD poll costs 1-2 us while tiles complete every ~30 ns chip-wide, so the
 // nearest inclusive word is routinely > 64 tiles back.
-// PRE: the first window (positions 4 * lane .. + 3 behind `tile`) was polled earlier, from inside the count phase of the
-// streaming kernel, and arrives in `pre`; if it does not resolve the tile the loop continues with live polls.
-template <bool PRE = false>
 __device__ __forceinline__ void resolve(u64* desc, u32 tile, u32 epoch, Desc agg, u32 in_quote_in, u32 lane,
-                                        u32& pin_out, u64& base_out, u32& err, const u64* pre = nullptr) {
+                                        u32& pin_out, u64& base_out, u32& err) {
     u32 pin = in_quote_in;
     u64 base = 0;
     // acc = composition of the tiles in (hi, tile): function of the state entering tile hi+1
@@ -313,7 +310,7 @@ __device__ __forceinline__ void resolve(u64* desc, u32 tile, u32 epoch, Desc agg
     // before this tile and normally publishes last of the ~100 tiles the window needs; 1024 control
     // waves each re-reading 256 words every few hundred cycles would cost more fabric bandwidth than
     // the CSV stream itself (measured: -20 % chip throughput).
-    if (!PRE && tile != 0) {
+    if (tile != 0) {
         for (;;) {
             u64 x;
             const u32 st = decode_desc(load_desc(desc + (tile - 1)), epoch, x);
@@ -322,7 +319,6 @@ __device__ __forceinline__ void resolve(u64* desc, u32 tile, u32 epoch, Desc agg
             if (++spins > kSpinLimit) { err = 1; break; }
         }
     }
-    bool use_pre = PRE;
     for (;;) {
         // lane k holds window positions 4k .. 4k+3 (position 0 = nearest predecessor)
         u64 d[4], x[4];
@@ -332,9 +328,8 @@ __device__ __forceinline__ void resolve(u64* desc, u32 tile, u32 epoch, Desc agg
             const int64_t j = hi - (int64_t)(4 * lane + i);
             // virtual tile -1 = inclusive (in_quote_in, 0): the shard's entering state
             d[i] = encode_desc(kStatusInc, epoch, (u64)in_quote_in);
-            if (j >= 0) d[i] = (PRE && use_pre) ? pre[i] : load_desc(desc + j);
+            if (j >= 0) d[i] = load_desc(desc + j);
         }
-        use_pre = false;
 #pragma unroll
         for (int i = 3; i >= 0; --i) {
             const u32 status = decode_desc(d[i], epoch, x[i]);
@@ -638,8 +633,7 @@ struct KernelArgs {
     u32 emit_delay;  // x 640 cycles of s_sleep between barrier B and the emit phase
     u32 count_prio;  // 1: count phases run at s_setprio 3
 #ifdef CSVSIMD_DEV_PROBES
-    u64* prof;    // timing build: per-phase stamp sums
-    u32 profile;  // streaming kernel: 1 = take the stamps
+    u64* prof;  // timing build: per-phase stamp sums
 #endif
 };
 
@@ -782,7 +776,7 @@ __device__ __forceinline__ void emit_span(const KernelArgs& args, const RoundMas
 
 // The end of a launch (wave 0 of every workgroup): count this workgroup done; the workgroup whose add completes the
 // count writes the result record from the last tile's inclusive word and leaves the control block ready for the next
-// launch.  Shared by both kernel structures.
+// launch.
 template <int DIALECT, bool NO_LOOKBACK>
 __device__ __forceinline__ void finish_launch(const KernelArgs& args, u32 epoch, u32 inq_in, u64 wg_tot, u32 err, u32 lane) {
     Control* const ctl = args.ctl;
@@ -1097,369 +1091,6 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// The STREAMING structure (round 2): ONE 8-wave workgroup per CU that never stops loading.
-//
-// Why: a bare non-temporal stream of the 64-col traffic mix is 7-9 % faster at 8 waves per CU than at the 16 the
-// two-workgroups-per-CU kernel above needs (bench.py: roofline.probed_stream), and that kernel's workgroups spend
-// two thirds of every tile in phases that issue no loads (barrier waits, look-back, emit), relying on the partner
-// workgroup to fill the gap.  Here the gap is filled by the workgroup itself:
-//   * every wave keeps a RING of four 4-KiB LDS images; the DMAs of rounds r+4 are issued as round r is consumed,
-//     and — the point — the first four rounds of the NEXT tile are requested right after barrier A of the current
-//     one, so they stream in during the look-back wait and the scatter of the previous tile;
-//   * the ticket of the next tile is therefore drawn one iteration early (wave 0, right after barrier B, so the
-//     atomic's latency hides behind the scatter);
-//   * gfx950 counts loads and stores in ONE in-order vmcnt, so a tape store issued between a prefetch and its
-//     consumption would make "wait for round r" inexpressible.  The emit phase is split: tile i-1 is SCATTERED into
-//     a dedicated LDS window after barrier B of iteration i, and its final FLUSH (the stores) is issued after the
-//     count phase of iteration i+1, before the next prefetch goes out — every store is older than every DMA that
-//     is still awaited, and all vmcnt waits are static;
-//   * 1 workgroup per CU = 2 waves per SIMD: 256 VGPRs per lane, nothing spills, both tiles' masks stay in
-//     registers; LDS: 128 KiB of rings + 24 KiB of windows.
-// Everything else — classification, descriptor algebra, look-back, tape order, finish protocol, tile size (so the
-// host code and the scratch layout) — is shared with stage1_kernel.
-// ---------------------------------------------------------------------------------------------
-static constexpr int kRing = 4;            // rounds in flight per wave
-static constexpr int kStreamWin = 1536;    // u16 entries of a wave's dedicated emit window
-
-struct TileView {
-    rsrc_t rsrc;
-    u32 lo_rel, hi_rel;
-};
-__device__ __forceinline__ TileView tile_view(const KernelArgs& args, u32 tile) {
-    TileView v;
-    const u64 tile0 = (u64)tile * kTileBytes;
-    const u64 hi16 = (args.hi + 15) & ~15ull;
-    const u64 avail = hi16 - tile0;
-    v.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(args.abase) + tile0, 0,
-                                               (int)(avail < (u64)kTileBytes ? avail : (u64)kTileBytes), 0x00020000);
-    v.lo_rel = args.lo > tile0 ? (u32)(args.lo - tile0) : 0u;
-    v.hi_rel = args.hi - tile0 < (u64)kTileBytes ? (u32)(args.hi - tile0) : (u32)kTileBytes;
-    return v;
-}
-
-// rounds 0 .. kRing-1 of a tile into the wave's ring
-__device__ __forceinline__ void prefetch_tile(rsrc_t rsrc, u32 lane, u32 w, uint4 (*ring)[kRoundBytes / 16]) {
-    u32 l_ = lane;
-    asm volatile("" : "+v"(l_));
-    u32 voff = w * (u32)kSpanBytes + stage_addr_of_lane(l_).src;
-#pragma unroll
-    for (int r = 0; r < kRing; ++r) {
-        dma_round(rsrc, voff, ring[r]);
-        voff += (u32)kRoundBytes;
-        asm volatile("" : "+v"(voff));
-    }
-}
-
-// Count phase over a ring that never drains.  On entry rounds 0..3 of this tile are in flight or landed (requested
-// during the previous tile); as round r is consumed its image is re-requested at once: rounds r + 4 of this tile for
-// r < 4, rounds r - 4 of the NEXT tile (`nxt`, drawn one iteration ahead by wave 0) for r >= 4.
-// vmcnt schedule: when round r is consumed, exactly three younger DMA groups (12 instructions) have been issued behind
-// it — R(r+1)..R(r+3) counting through into the next tile — plus, older than all awaited rounds >= 4 and younger only than
-// long-landed prefetched rounds, the flush stores of the previous tile and wave 0's atomic: `vmcnt(12)` is sufficient for
-// every round (it can only over-wait on operations that are older).  A workgroup without a next tile issues its four
-// groups against an empty buffer descriptor (no memory traffic, zeros deposited) so that the schedule stays static.
-__device__ __forceinline__ void count_phase_stream(const KernelArgs& args, rsrc_t rsrc, u32 lane, u32 w, const EdgeKeep& ek,
-                                                   uint4 (*ring)[kRoundBytes / 16], RoundMasks (&m)[kRounds], u32& carry,
-                                                   u32& cnt_a, u32& cnt_t, u32 nxt, bool do_poll, u32 poll_tile,
-                                                   u64 (&pre)[4]) {
-    u32 l_ = lane;
-    asm volatile("" : "+v"(l_));
-    const StageAddr sa = stage_addr_of_lane(l_);
-    const u32 voff0 = w * (u32)kSpanBytes + sa.src;
-    u32 voff = voff0 + (u32)kRing * kRoundBytes;  // the next round of THIS tile to request
-    const u32 rslot = sa.rslot;
-    rsrc_t nrsrc = rsrc;
-    u32 nvoff = voff0;
-#pragma unroll
-    for (int r = 0; r < kRounds; ++r) {
-        uint4* const stage = ring[r % kRing];
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        uint4 stripe[kRows];
-#pragma unroll
-        for (int k = 0; k < kRows; ++k) stripe[k] = stage[rslot ^ (u32)k];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        if (r + kRing < kRounds) {
-            dma_round(rsrc, voff, stage);
-            voff += (u32)kRoundBytes;
-            asm volatile("" : "+v"(voff));
-        } else {
-            if (r + kRing == kRounds) {
-                // the next tile: wave 0's ticket has returned (see above); everybody else waits for this iteration's tag
-                {
-                    // one descriptor either way (an empty one if there is no next tile): selecting between two
-                    // 128-bit descriptors would go through VGPRs
-                    const bool valid = nxt < args.num_tiles;
-                    const u64 tile0 = valid ? (u64)nxt * kTileBytes : 0ull;
-                    const u64 hi16 = (args.hi + 15) & ~15ull;
-                    const u64 avail = hi16 - tile0;
-                    const u32 size = valid ? (u32)(avail < (u64)kTileBytes ? avail : (u64)kTileBytes) : 0u;
-                    nrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(args.abase) + tile0, 0, (int)size,
-                                                              0x00020000);
-                }
-            }
-            dma_round(nrsrc, nvoff, stage);
-            nvoff += (u32)kRoundBytes;
-            asm volatile("" : "+v"(nvoff));
-            if (r + kRing == kRounds && do_poll) {
-                // wave 0: the first look-back window of the HELD tile, requested now (younger than every DMA this
-                // phase still waits for, so no vmcnt wait of the phase depends on it) and consumed after barrier A: the
-                // 3-5 us a poll takes behind the CU's streaming loads are spent here instead of between two barriers
-#pragma unroll
-                for (int i = 3; i >= 0; --i) {
-                    const int64_t j = (int64_t)poll_tile - 1 - (int64_t)(4 * lane + i);
-                    pre[i] = 0;
-                    if (j >= 0) pre[i] = load_desc(args.desc + j);
-                }
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        u32 st16[kRows], q16[kRows];
-#pragma unroll
-        for (int k = 0; k < kRows; ++k) classify16(stripe[k], st16[k], q16[k]);
-        u64 keep = ek.back_round == (u32)r ? ek.back_keep : ~0ull;
-        if (r == 0) keep &= ek.front_keep;
-        const u64 st = ((u64)(st16[0] | (st16[1] << 16)) | ((u64)(st16[2] | (st16[3] << 16)) << 32)) & keep;
-        u64 x = ((u64)(q16[0] | (q16[1] << 16)) | ((u64)(q16[2] | (q16[3] << 16)) << 32)) & keep;
-        x ^= x << 1;
-        x ^= x << 2;
-        x ^= x << 4;
-        x ^= x << 8;
-        x ^= x << 16;
-        x ^= x << 32;
-        const u64 par = __ballot((x >> 63) != 0);
-        const u32 enter = (mbcnt64(par) ^ carry) & 1u;
-        carry ^= (u32)__builtin_popcountll(par) & 1u;
-        m[r].st = st;
-        m[r].s = x ^ (enter ? ~0ull : 0ull);
-        cnt_a += (u32)__builtin_popcountll(m[r].st & ~m[r].s);
-        cnt_t += (u32)__builtin_popcountll(m[r].st);
-        asm volatile("" : "+v"(m[r].st), "+v"(m[r].s), "+v"(cnt_a), "+v"(cnt_t));
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// Scatter of one wave span into the wave's dedicated window; full windows are flushed on the way (dense files), the
-// LAST window's flush is left to the caller: (fill, run) describe what is still waiting in the window.
-__device__ __forceinline__ void scatter_span_deferred(const KernelArgs& args, const RoundMasks (&m)[kRounds], u32 lane,
-                                                      u64 span_off, u32 wstate, u64 run_in, unsigned short* comp,
-                                                      u32& fill_out, u64& run_out) {
-    const u64 flipall = wstate ? ~0ull : 0ull;
-    u32 fill = 0;
-    u64 run = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(run_in >> 32)) << 32) |
-              (u32)__builtin_amdgcn_readfirstlane((int)(u32)run_in);
-#pragma unroll
-    for (int r = 0; r < kRounds; ++r) {
-        const u64 R = m[r].st & ~(m[r].s ^ flipall);
-        const u32 c = (u32)__builtin_popcountll(R);
-        const u32 incl = wave_incl_scan_add(c);
-        const u32 n_r = (u32)__builtin_amdgcn_readlane((int)incl, 63);
-        const u32 excl = incl - c;
-        const u32 stripe_rel = (u32)r * kRoundBytes + lane * 64u;
-        if (fill + n_r > (u32)kStreamWin) {
-            wave_lds_fence();
-            flush_window(args, comp, fill, run, span_off, lane);
-            wave_lds_fence();
-            run += fill;
-            fill = 0;
-        }
-        if (n_r <= (u32)kStreamWin) {
-            u32 lo = (u32)R, hi = (u32)(R >> 32), p = fill + excl;
-            while (lo) {
-                comp[p++] = (unsigned short)(stripe_rel + (u32)__builtin_ctz(lo));
-                lo &= lo - 1;
-            }
-            while (hi) {
-                comp[p++] = (unsigned short)(stripe_rel + 32u + (u32)__builtin_ctz(hi));
-                hi &= hi - 1;
-            }
-            fill += n_r;
-        } else {
-            // more than a third of this round's bytes are structural: several window passes
-            for (u32 win = 0; win < n_r; win += kStreamWin) {
-                u32 lo = (u32)R, hi = (u32)(R >> 32), p = excl - win;
-                while (lo) {
-                    if (p < (u32)kStreamWin) comp[p] = (unsigned short)(stripe_rel + (u32)__builtin_ctz(lo));
-                    ++p;
-                    lo &= lo - 1;
-                }
-                while (hi) {
-                    if (p < (u32)kStreamWin) comp[p] = (unsigned short)(stripe_rel + 32u + (u32)__builtin_ctz(hi));
-                    ++p;
-                    hi &= hi - 1;
-                }
-                wave_lds_fence();
-                const u32 n_win = (n_r - win) < (u32)kStreamWin ? (n_r - win) : (u32)kStreamWin;
-                flush_window(args, comp, n_win, run, span_off, lane);
-                wave_lds_fence();
-                run += n_win;
-            }
-        }
-        asm volatile("" : "+s"(fill), "+s"(run));
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    fill_out = fill;
-    run_out = run;
-}
-
-template <bool EMIT>
-__global__ __launch_bounds__(kThreads, 2) void stage1_stream_kernel(const KernelArgs args) {
-    __shared__ u32 s_tile;
-    __shared__ u32 s_next[2];  // prologue only: the first two tiles
-    __shared__ u32 s_wdesc[kWaves][3];
-    __shared__ u32 s_pin;
-    __shared__ u64 s_base;
-    __shared__ uint4 s_ring[kWaves][kRing][kRoundBytes / 16];
-    __shared__ unsigned short s_win[kWaves][kStreamWin];
-
-    const u32 t = threadIdx.x;
-    const u32 lane = t & 63u;
-    const u32 w = (u32)__builtin_amdgcn_readfirstlane((int)(t >> 6));
-    u32 err = 0;
-
-    u32 inq_in = args.in_quote_in;
-    if (args.state_ptr) {
-        const u32 st = (u32)__builtin_amdgcn_readfirstlane(
-            (int)__hip_atomic_load(args.state_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        if (st == 0u) return;
-        inq_in = 1u;
-    }
-    const u32 epoch_v = __hip_atomic_load(&args.ctl->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-
-    // prologue: the first tile with its first four rounds, and the ticket of the tile after it
-    if (t == 0) {
-        const u32 first = atomicAdd(&args.ctl->ticket, 1u);
-        s_next[0] = first;
-        s_next[1] = first < args.num_tiles ? atomicAdd(&args.ctl->ticket, 1u) : 0xffffffffu;
-    }
-    wg_barrier();
-    u32 cur = (u32)__builtin_amdgcn_readfirstlane((int)s_next[0]);
-    u32 nxt = (u32)__builtin_amdgcn_readfirstlane((int)s_next[1]);
-    if (cur < args.num_tiles) prefetch_tile(tile_view(args, cur).rsrc, lane, w, s_ring[w]);
-
-    RoundMasks held[kRounds];
-    Desc held_agg = {0, 0, 0}, held_before = {0, 0, 0};
-    u32 held_tile = 0;
-    bool have_held = false;
-    u64 wg_tot = 0;
-    // what still waits in this wave's window (scattered, not yet stored)
-    u32 pend_fill = 0;
-    u64 pend_run = 0, pend_off = 0;
-#ifdef CSVSIMD_DEV_PROBES
-    // timing build: per-phase s_memrealtime sums of waves 0 and 1 -> args.prof[w * 8 + k], workgroup count -> [16]
-    u64 prof[6] = {0, 0, 0, 0, 0, 0};
-    u64 stamp = args.profile ? __builtin_amdgcn_s_memrealtime() : 0;
-#define STREAM_STAMP(k)                                          \
-    if (args.profile) {                                          \
-        const u64 now_ = __builtin_amdgcn_s_memrealtime();       \
-        prof[k] += now_ - stamp;                                 \
-        stamp = now_;                                            \
-    }
-#else
-#define STREAM_STAMP(k)
-#endif
-
-    for (;;) {
-        const bool have_cur = cur < args.num_tiles;
-        // the stores of the tile scattered in the previous iteration leave now: older than every DMA this iteration
-        // will wait for beyond the long-landed prefetched rounds
-        if (EMIT && pend_fill) {
-            wave_lds_fence();
-            flush_window(args, s_win[w], pend_fill, pend_run, pend_off, lane);
-            wave_lds_fence();
-            pend_fill = 0;
-        }
-        STREAM_STAMP(0)  // flush of the previous tile's window
-        if (!have_cur && !have_held) break;
-        RoundMasks m[kRounds];
-        Desc agg = {0, 0, 0}, before = {0, 0, 0};
-        u64 pre[4] = {0, 0, 0, 0};  // wave 0: pre-polled look-back window of the held tile
-        if (have_cur) {
-            const TileView tv = tile_view(args, cur);
-            u32 carry = 0, cnt_a = 0, cnt_t = 0;
-            const EdgeKeep ek = edge_keep_of_tile(lane, w, tv.lo_rel, tv.hi_rel, 0u);
-            count_phase_stream(args, tv.rsrc, lane, w, ek, s_ring[w], m, carry, cnt_a, cnt_t, nxt, w == 0 && have_held,
-                               held_tile, pre);
-            const u32 wave_a = wave_sum(cnt_a);
-            const u32 wave_t = wave_sum(cnt_t);
-            if (lane == 0) {
-                s_wdesc[w][0] = carry;
-                s_wdesc[w][1] = wave_a;
-                s_wdesc[w][2] = wave_t - wave_a;
-            }
-        }
-        STREAM_STAMP(1)  // count phase
-        wg_barrier();  // barrier A
-        STREAM_STAMP(2)
-        const u32 epoch = (u32)__builtin_amdgcn_readfirstlane((int)epoch_v) & kEpochMask;
-        if (have_cur) {
-#pragma unroll
-            for (int k = 0; k < kWaves; ++k) {
-                Desc d = {s_wdesc[k][0], s_wdesc[k][1], s_wdesc[k][2]};
-                if ((u32)k == w) before = agg;
-                agg = compose(agg, d);
-            }
-        }
-        if (w == 0) {
-            // the ticket of the tile after `nxt`: drawn one iteration ahead so that `nxt`'s first rounds can be requested
-            // from inside the next count phase; its latency hides behind the look-back below
-            u32 ticket_v = 0xffffffffu;
-            if (lane == 0 && nxt < args.num_tiles) ticket_v = atomicAdd(&args.ctl->ticket, 1u);
-            if (have_cur) {
-                if (lane == 0) publish_aggregate(args.desc, cur, epoch, agg);
-                wg_tot += (u64)(u32)__builtin_amdgcn_readfirstlane((int)(agg.a + agg.b));
-            }
-            if (have_held) {
-                u32 pin = 0;
-                u64 base = 0;
-                if (have_cur)
-                    resolve<true>(args.desc, held_tile, epoch, held_agg, inq_in, lane, pin, base, err, pre);
-                else
-                    resolve(args.desc, held_tile, epoch, held_agg, inq_in, lane, pin, base, err);
-                if (lane == 0) {
-                    s_pin = pin;
-                    s_base = base;
-                }
-            }
-            if (lane == 0) s_tile = ticket_v;
-        }
-        STREAM_STAMP(3)  // publish + look-back (wave 0)
-        wg_barrier();  // barrier B
-        STREAM_STAMP(4)
-        const u32 after_nxt = (u32)__builtin_amdgcn_readfirstlane((int)s_tile);
-        if (EMIT && have_held) {
-            const u32 pin = s_pin;
-            const u32 wstate = pin ^ held_before.p;
-            const u64 run = s_base + (pin ? held_before.b : held_before.a);
-            const u64 span0 = (u64)held_tile * kTileBytes + (u64)w * kSpanBytes;
-            pend_off = args.base_off + span0 - args.lo;
-            scatter_span_deferred(args, held, lane, pend_off, wstate, run, s_win[w], pend_fill, pend_run);
-        }
-        STREAM_STAMP(5)  // scatter
-        have_held = have_cur;
-        held_tile = cur;
-        held_agg = agg;
-        held_before = before;
-#pragma unroll
-        for (int r = 0; r < kRounds; ++r) held[r] = m[r];
-        cur = nxt;
-        nxt = after_nxt;
-    }
-#ifdef CSVSIMD_DEV_PROBES
-    if (args.profile && lane == 0 && w < 2) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) atomicAdd((unsigned long long*)(args.prof + w * 8 + k), (unsigned long long)prof[k]);
-        if (w == 0) atomicAdd((unsigned long long*)(args.prof + 16), 1ull);
-    }
-#endif
-#undef STREAM_STAMP
-    if (w != 0) return;
-    finish_launch<0, false>(args, (u32)__builtin_amdgcn_readfirstlane((int)epoch_v) & kEpochMask, inq_in, wg_tot, err, lane);
-}
-
-// ---------------------------------------------------------------------------------------------
 // utilities: synthetic corpus, checksum, self-test
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ u64 splitmix64(u64 x) {
@@ -1712,7 +1343,6 @@ hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream) {
     a.emit_delay = L.pace_emit_delay >= 0 ? (u32)L.pace_emit_delay : (long_launch ? 8u : 0u);
     a.count_prio = L.pace_count_prio >= 0 ? (u32)L.pace_count_prio : (long_launch ? 0u : 1u);
 #ifdef CSVSIMD_DEV_PROBES
-    a.profile = L.debug_mode == 8 ? 1u : 0u;
     a.prof = L.scratch_prof;
 #endif
     // 0 = the reference dialect (the tuned LUT classification), 1 = other delimiter / quote, 2 = + escape
@@ -1725,7 +1355,6 @@ hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream) {
     if (L.ev_begin && (e = hipEventRecord(L.ev_begin, stream)) != hipSuccess) return e;
     bool launched = false;
 #ifdef CSVSIMD_DEV_PROBES
-    if (!(L.variant == 1 && dialect == 0)) {
     CSVSIMD_PROBE_LAUNCH(1, false)
     CSVSIMD_PROBE_LAUNCH(4, false)
     CSVSIMD_PROBE_LAUNCH(6, false)
@@ -1734,16 +1363,8 @@ hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream) {
     CSVSIMD_PROBE_LAUNCH(8, true)
     CSVSIMD_PROBE_LAUNCH(40, true)
     CSVSIMD_PROBE_LAUNCH(8, false)
-    }
 #endif
     if (launched) {
-    } else if (L.variant == 1 && dialect == 0) {
-        // the streaming structure: one workgroup per CU
-        const u32 sgrid = want < L.stream_blocks ? want : L.stream_blocks;
-        if (a.tape)
-            hipLaunchKernelGGL((stage1_stream_kernel<true>), dim3(sgrid), dim3(kThreads), 0, stream, a);
-        else
-            hipLaunchKernelGGL((stage1_stream_kernel<false>), dim3(sgrid), dim3(kThreads), 0, stream, a);
     } else if (dialect == 2 && a.tape)
         hipLaunchKernelGGL((stage1_kernel<true, 0, 2>), dim3(grid), dim3(kThreads), 0, stream, a);
     else if (dialect == 2)

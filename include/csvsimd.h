@@ -55,13 +55,7 @@ uint32_t csvsimd_tile_bytes(void);
 typedef struct csvsimd_ctx csvsimd_ctx;
 int csvsimd_ctx_create(int device, csvsimd_ctx** out);
 void csvsimd_ctx_destroy(csvsimd_ctx* ctx);
-/* Which of the two structures of the stage-1 kernel this context launches for the reference dialect (same results,
- * bit for bit): PAIRED = two 8-wave workgroups per CU that overlap each other's phases; STREAMING = one
- * 8-wave workgroup per CU that prefetches the next tile through its own look-back and emit.  Dialect variants always
- * use PAIRED. */
-#define CSVSIMD_VARIANT_PAIRED 0
-#define CSVSIMD_VARIANT_STREAMING 1
-int csvsimd_ctx_set_variant(csvsimd_ctx* ctx, int variant);
+
 
 /* What one stage-1 pass over a shard reports (device- or host-resident, 64 bytes).
  * (quote_parity, count_enter_outside, count_enter_inside) is the composable shard descriptor
