@@ -2,6 +2,7 @@
 // shard stitch, tape accessors, csv_simd::create().  Compiled with hipcc (HIP runtime API only;
 // the kernels live in stage1_kernels.hip).  There is no CPU fallback anywhere in this file.
 #include <fcntl.h>
+#include <sched.h>
 #include <hip/hip_runtime.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -108,12 +109,18 @@ private:
 };
 
 int ingest_workers() {
-    if (const char* e = getenv("CSVSIMD_INGEST_THREADS")) {
+    const char* e = getenv("CSVSIMD_INGEST_THREADS");
+    if (e && *e) {
         const int n = atoi(e);
         return std::min(std::max(n, 1), 32) - 1;  // the calling thread is one of them
     }
-    const unsigned hw = std::thread::hardware_concurrency();
-    return (int)std::min<unsigned>(std::max<unsigned>(hw / 4, 2), 6) - 1;  // 2..6 copying threads, caller included
+    // Measured on the MI355X host (scripts/probe_ingest.py, 2 GiB, GiB/s PCIe-inclusive by copying threads):
+    // 1: 20.5, 4: 41, 6: 45, 8: 50.4, 10: 47-50, 12: 41 (the container's CPU share is 16 of the host's 256 threads,
+    // which neither hardware_concurrency nor the affinity mask reveals: both say 256) -> 8, fewer on small machines.
+    unsigned cpus = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) cpus = (unsigned)CPU_COUNT(&set);
+    return (int)std::min<unsigned>(std::max<unsigned>(cpus / 2, 2), 8) - 1;  // 2..8 copying threads, caller included
 }
 
 }  // namespace
