@@ -350,7 +350,8 @@ def test_host_ingest_pipeline_multi_chunk(ctx, pkg, oracle, tmp_path, monkeypatc
 def test_async_entry_point_is_graph_capturable(ctx, torch_cuda, pkg, oracle):
     # include/csvsimd.h promises: no allocation and no synchronisation inside
     # csvsimd_stage1_index_device_async once the scratch is reserved -> it can be captured into a
-    # hipGraph (memset nodes + kernel nodes) and replayed on new contents of the same buffers.
+    # hipGraph (one kernel node per launch: the launch clears nothing and reduces nothing outside itself) and replayed on
+    # new contents of the same buffers.
     torch = torch_cuda
     rng = np.random.default_rng(12)
     n = 3 * pkg.tile_bytes() + 4321
@@ -751,3 +752,51 @@ def test_device_stitch_and_reemit_three_shards_one_gpu(pkg, torch_cuda, oracle):
         finally:
             for c in ctxs:
                 c.close()
+
+
+def test_sharded_device_chain_is_graph_capturable(pkg, torch_cuda, oracle):
+    # the part of a sharded step that runs on the device — speculative launch, stitch kernel, re-emit launch — holds no
+    # allocation, no synchronisation and no host decision, so it can be captured into ONE hipGraph and replayed on new
+    # bytes (the all-gather between launch and stitch is the caller's: here the record is simply shard 0 of 1, and the
+    # file-level entering state is what makes the re-emit fire or not)
+    torch = torch_cuda
+    from csv_simd_amd import sharded
+    rng = np.random.default_rng(808)
+    n = 2 * pkg.tile_bytes() + 777
+    c = pkg.Context(0)
+    try:
+        c.reserve(n)
+        dbuf = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
+        dtape = torch.full((n + 8,), -1, dtype=torch.int64, device="cuda:0")
+        d_rec = torch.zeros(8, dtype=torch.int64, device="cuda:0")
+        d_st = torch.zeros(sharded.STITCH_WORDS, dtype=torch.int64, device="cuda:0")
+        for file_inq in (0, 1):
+            def chain(stream):
+                c.stage1_index_device_async(dbuf.data_ptr(), n, 11, 0, dtape.data_ptr(), dtape.numel(), d_rec.data_ptr(), stream)
+                pkg.stitch_shards_device_async(d_rec.data_ptr(), 1, 0, file_inq, d_st.data_ptr(), stream)
+                c.stage1_reemit_device_async(dbuf.data_ptr(), n, 11, d_st.data_ptr(), dtape.data_ptr(), dtape.numel(),
+                                             d_rec.data_ptr(), stream)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                chain(side.cuda_stream)          # warm-up outside the capture
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                chain(torch.cuda.current_stream().cuda_stream)
+            for rep in range(4):
+                d = random_csvish(rng, n, 0.04)
+                dbuf.copy_(torch.from_numpy(d))
+                dtape.fill_(-1)
+                g.replay()
+                torch.cuda.synchronize()
+                want, q = oracle.scalar_index(d, base_off=11, in_quote_in=file_inq)
+                rec = sharded.result_from_words(d_rec.cpu().tolist())
+                st = sharded.stitch_from_words(d_st.cpu().tolist())
+                assert (st.in_quote_in, st.count, st.in_quote_final, st.error) == (file_inq, want.size, q, 0), (file_inq, rep)
+                assert (rec.count, rec.in_quote_out, rec.error) == (want.size, q, 0)
+                assert np.array_equal(dtape[: rec.count].cpu().numpy().view(np.uint64), want), (file_inq, rep)
+            del g
+    finally:
+        c.close()
