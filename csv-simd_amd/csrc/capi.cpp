@@ -1009,6 +1009,7 @@ int csvsimd_stage1_time_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len,
             L.escape = (uint8_t)e;
         }
     }
+    if (const char* e = getenv("CSVSIMD_PROBE_CU_TOKEN")) L.pace_cu_token = atoi(e);
     if (const char* e = getenv("CSVSIMD_PROBE_EMIT_DELAY")) L.pace_emit_delay = atoi(e);
     if (const char* e = getenv("CSVSIMD_PROBE_COUNT_PRIO")) L.pace_count_prio = atoi(e);
     if (L.debug_mode == 8) HIP_TRY(hipMemsetAsync(L.scratch_prof, 0, 17 * 8, s));

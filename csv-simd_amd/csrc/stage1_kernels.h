@@ -25,9 +25,11 @@ namespace csvsimd {
 // scratch block layout (zeroed ONCE, when it is allocated; every launch leaves it ready for the next):
 //   [0, 64)            control block (stage1_kernels.hip: struct Control): ticket, epoch, done/total, ...
 //   [64, 528)          development builds only: per-phase timing slots
-//   [528, ...)         one u64 look-back descriptor per tile, tagged with the launch epoch
+//   [528, 8720)        one u32 count-phase token per physical CU (XCC id x HW_ID cu/sh/se bits); 0 = free
+//   [8720, ...)        one u64 look-back descriptor per tile, tagged with the launch epoch
 #define CSVSIMD_SCRATCH_CTL_BYTES 64
-#define CSVSIMD_SCRATCH_DESC_OFFSET 528
+#define CSVSIMD_SCRATCH_TOKEN_OFFSET 528            /* 8 x 256 u32: one count-phase token per physical CU */
+#define CSVSIMD_SCRATCH_DESC_OFFSET (528 + 8192)
 struct Stage1Launch {
     const void* dbuf;
     uint64_t len;
@@ -46,6 +48,7 @@ struct Stage1Launch {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     int debug_mode = 0;  // development probes (-DCSVSIMD_DEV_PROBES builds only; see stage1_kernel's DBG)
     int pace_emit_delay = -1, pace_count_prio = -1;  // -1 = chosen from the launch size (launch_stage1)
+    int pace_cu_token = -1;      // 1 = the two workgroups of a CU take turns in the count phase
     // dialect extension (csvsimd_dialect): the defaults are the reference's hard-wired dialect
     uint8_t delimiter = ',', quote = '"', escape = 0;
     uint32_t escape_in = 0;

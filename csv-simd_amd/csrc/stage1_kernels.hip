@@ -632,6 +632,8 @@ struct KernelArgs {
     // pacing knobs, chosen by the host from the launch size
     u32 emit_delay;  // x 640 cycles of s_sleep between barrier B and the emit phase
     u32 count_prio;  // 1: count phases run at s_setprio 3
+    u32* cu_token;   // non-null: the workgroups that share a CU take turns in the count phase (one u32 per CU)
+    u32 token_mode;  // 1 = token, then ticket; 2 = both atomics in flight together
 #ifdef CSVSIMD_DEV_PROBES
     u64* prof;  // timing build: per-phase stamp sums
 #endif
@@ -938,13 +940,46 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
 #define CSVSIMD_TRACE(k, tid)
 #endif
 
+    // the physical CU this workgroup runs on (fixed for its lifetime): XCC id x the cu/sh/se bits of HW_ID
+    u32* const my_token = args.cu_token
+        ? args.cu_token + ((__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u) << 8) +
+              ((__builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11))) & 0xffu)
+        : nullptr;
+    bool hold_token = false;
+
     for (u32 iter = 0;; ++iter) {
-        if (t == 0) s_tile = (DBG & 2) ? blockIdx.x + iter * gridDim.x : atomicAdd(&args.ctl->ticket, 1u);
+        if (t == 0) {
+            if (my_token && args.token_mode == 2) {
+                // both atomics in flight together (one round trip instead of two); a workgroup that then has to wait
+                // for the token does so holding its ticket — its aggregate is late by at most one count phase
+                const u32 tk = atomicAdd(&args.ctl->ticket, 1u);
+                u32 got = atomicCAS(my_token, 0u, 1u);
+                u32 spins = 0;
+                while (got != 0u && ++spins < (1u << 16)) {
+                    __builtin_amdgcn_s_sleep(8);
+                    got = atomicCAS(my_token, 0u, 1u);
+                }
+                s_tile = tk;
+            } else {
+                if (my_token) {
+                    // one workgroup per CU in the count phase at a time: taken BEFORE the ticket, so a waiting
+                    // workgroup holds no tile anybody could depend on; released after barrier A.  Bounded spin.
+                    u32 spins = 0;
+                    while (atomicCAS(my_token, 0u, 1u) != 0u && ++spins < (1u << 16)) __builtin_amdgcn_s_sleep(8);
+                }
+                s_tile = (DBG & 2) ? blockIdx.x + iter * gridDim.x : atomicAdd(&args.ctl->ticket, 1u);
+            }
+        }
+        hold_token = my_token != nullptr;
         wg_barrier();  // barrier T
         CSVSIMD_STAMP(0)
         const u32 tile = (u32)__builtin_amdgcn_readfirstlane((int)s_tile);
         CSVSIMD_TRACE(0, tile)
         const bool have_cur = tile < args.num_tiles;
+        if (hold_token && !have_cur) {  // nothing to count: the partner workgroup need not wait for this one
+            if (t == 0) __hip_atomic_store(my_token, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hold_token = false;
+        }
         if (!have_cur && !have_held) break;
 
         RoundMasks m[kRounds];
@@ -1013,6 +1048,7 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
         CSVSIMD_STAMP(1)  // count phase
         CSVSIMD_TRACE(1, tile)
         wg_barrier();     // barrier A
+        if (hold_token && t == 0) __hip_atomic_store(my_token, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         CSVSIMD_STAMP(2)
         CSVSIMD_TRACE(2, tile)
 
@@ -1335,13 +1371,22 @@ hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream) {
     a.quote = L.quote;
     a.escape = L.escape;
     a.escape_in = (L.escape && L.escape_in) ? 1u : 0u;
-    // Pacing.  Measured on MI355X (scripts/ab_variants.py, gpurun_out/r2b): on launches long enough to reach a
-    // steady state (64 tiles per workgroup at 8 GiB) a ~2 us pause before each emit phase is worth +3..5 %
-    // (1.80 -> 1.72-1.73 ms at 8 GiB) and count-phase priority costs 2 %; on short launches (8 tiles per
-    // workgroup at 1 GiB) the pause does nothing and the priority is worth +2 % (0.249 -> 0.243 ms).
-    const bool long_launch = L.len >= (2ull << 30);
-    a.emit_delay = L.pace_emit_delay >= 0 ? (u32)L.pace_emit_delay : (long_launch ? 8u : 0u);
-    a.count_prio = L.pace_count_prio >= 0 ? (u32)L.pace_count_prio : (long_launch ? 0u : 1u);
+    // Pacing: the two workgroups of a CU take turns in the count phase (a token per physical CU in the scratch block,
+    // taken by thread 0 before it draws the ticket, released after barrier A), and count phases run at s_setprio 3.
+    // Measured on MI355X (scripts/sweep_token.sh, probe build; kernel ms: 8 GiB / 2 GiB 64x31, 1 GiB 16x32, 1 GiB dense):
+    //   no token, no pause            1.848  -      0.2506  0.528   both workgroups often count at once: they share the
+    //   no token, ~2 us pause before  1.739  0.463  0.2504  0.530   SIMDs' issue slots and double the loads in flight — the
+    //     emit (interim default)                                    bare stream, too, is fastest at 8 waves per CU
+    //   token + priority              1.681  0.439  0.2315  0.522   <- default: 63.9 / 61.1 / 58.0 / 25.7 % of 8 TB/s
+    //   token + priority + pause      1.691  0.442  0.2332  0.518
+    //   token, both atomics at once   1.789  0.463  0.2413  0.526   (a workgroup may then wait for the token holding a ticket)
+    // The pause knob stays (0 by default); the probe build's environment hooks override all three per launch.
+    a.emit_delay = L.pace_emit_delay >= 0 ? (u32)L.pace_emit_delay : 0u;
+    a.count_prio = L.pace_count_prio >= 0 ? (u32)L.pace_count_prio : 1u;
+    const int token_mode = L.pace_cu_token >= 0 ? L.pace_cu_token : 1;
+    a.cu_token = token_mode > 0
+        ? reinterpret_cast<u32*>(reinterpret_cast<char*>(L.scratch_base) + CSVSIMD_SCRATCH_TOKEN_OFFSET) : nullptr;
+    a.token_mode = (u32)token_mode;
 #ifdef CSVSIMD_DEV_PROBES
     a.prof = L.scratch_prof;
 #endif
