@@ -30,6 +30,7 @@
 //     u16 offsets into a wave-private LDS window (rounds batched), flushed as fully coalesced
 //     non-temporal 16-byte stores.
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "stage1_kernels.h"
@@ -41,6 +42,8 @@ namespace csvsimd {
 // ---------------------------------------------------------------------------------------------
 typedef uint32_t u32;
 typedef uint64_t u64;
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 static constexpr int kWaves = CSVSIMD_COMPUTE_WAVES;    // waves per workgroup (one 32-KiB span each)
 static constexpr int kThreads = kWaves * 64;
@@ -251,6 +254,9 @@ __device__ __forceinline__ Desc compose(Desc e, Desc l) {
 // lanes hold f_k for sequence position (-k) (lane 0 = latest); lanes >= m are ignored.
 // Returns in lane 0 the composition earliest..latest over lanes [0, m).
 __device__ __forceinline__ Desc wave_compose_ordered(Desc f, u32 lane, u32 m) {
+    // opaque: the six `lane + d >= 64` predicates below are loop invariant, and hoisted out of the tile loop they hold
+    // twelve SGPRs for the whole kernel — of a uniform state that already exceeds what a wave has
+    asm volatile("" : "+v"(lane));
     if (lane >= m) { f.p = 0; f.a = 0; f.b = 0; }
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -297,8 +303,40 @@ __device__ __forceinline__ void publish_aggregate(u64* desc, u32 tile, u32 epoch
 // publishes its inclusive word.  Whole wave; every poll looks at 256 predecessors (4 per lane):
 // on MI355X a cross-XCD poll costs 1-2 us while tiles complete every ~30 ns chip-wide, so the
 // nearest inclusive word is routinely > 64 tiles back.
-__device__ __forceinline__ void resolve(u64* desc, u32 tile, u32 epoch, Desc agg, u32 in_quote_in, u32 lane,
-                                        u32& pin_out, u64& base_out, u32& err) {
+// PRE: the first window (positions 4 * lane .. + 3 behind `tile`) was requested earlier and arrives in `pre`; the loads'
+// latency was spent on other work.  If that window does not resolve the tile, live polls follow.
+//
+// lookback_issue: the 256 words behind `tile` — desc[tile - 256, tile), 2 KiB — are copied to LDS by eight LDS-DMA
+// instructions (buffer_load_dword ... lds, sc1: like the relaxed agent-scope loads of the live polls they bypass the
+// CU's L1; a word's two halves may come from different versions, which the tag in both halves was made for): no VGPR is
+// held while the requests are in flight.  Words before desc[0] are out of the descriptor's range and arrive as 0.
+// lookback_fetch (after s_waitcnt vmcnt(0)): lane l picks up positions 4l .. 4l+3 = words [252 - 4l, 255 - 4l] of the copy.
+__device__ __forceinline__ void lookback_issue(const u64* desc, u32 tile, u32 lane, uint4* lds) {
+    const rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u64*>(desc), 0, (int)(tile * 8u), 0x00020000);
+    // byte offset of dword (64 q + lane) of the window; "negative" offsets wrap to out-of-range
+    u32 voff = (tile - 256u) * 8u + lane * 4u;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(reinterpret_cast<u32*>(lds) + 64 * q), 4, (int)voff, 0, 0,
+                                                 16 /* sc1 */);
+        voff += 256u;
+    }
+}
+__device__ __forceinline__ void lookback_fetch(const uint4* lds, u32 tile, u32 lane, u64 (&pre)[4]) {
+    asm volatile("" : "+v"(lane));               // the address is recomputed per tile, not held across the loop
+    const uint4 lo = lds[126u - 2u * lane];      // words 252 - 4l, 253 - 4l
+    const uint4 hi = lds[127u - 2u * lane];      // words 254 - 4l, 255 - 4l
+    pre[3] = ((u64)lo.y << 32) | lo.x;
+    pre[2] = ((u64)lo.w << 32) | lo.z;
+    pre[1] = ((u64)hi.y << 32) | hi.x;
+    pre[0] = ((u64)hi.w << 32) | hi.z;
+    (void)tile;
+}
+
+template <bool PRE = false>
+__device__ __forceinline__ void resolve(u64* desc, u32 tile, u32 epoch, Desc agg, u32 in_quote_in, u32 lane_in,
+                                        u32& pin_out, u64& base_out, u32& err, const u64* pre = nullptr) {
+    const u32 lane = lane_in;
     u32 pin = in_quote_in;
     u64 base = 0;
     // acc = composition of the tiles in (hi, tile): function of the state entering tile hi+1
@@ -310,7 +348,7 @@ __device__ __forceinline__ void resolve(u64* desc, u32 tile, u32 epoch, Desc agg
     // before this tile and normally publishes last of the ~100 tiles the window needs; 1024 control
     // waves each re-reading 256 words every few hundred cycles would cost more fabric bandwidth than
     // the CSV stream itself (measured: -20 % chip throughput).
-    if (tile != 0) {
+    if (!PRE && tile != 0) {
         for (;;) {
             u64 x;
             const u32 st = decode_desc(load_desc(desc + (tile - 1)), epoch, x);
@@ -319,6 +357,7 @@ __device__ __forceinline__ void resolve(u64* desc, u32 tile, u32 epoch, Desc agg
             if (++spins > kSpinLimit) { err = 1; break; }
         }
     }
+    bool use_pre = PRE;
     for (;;) {
         // lane k holds window positions 4k .. 4k+3 (position 0 = nearest predecessor)
         u64 d[4], x[4];
@@ -328,8 +367,9 @@ __device__ __forceinline__ void resolve(u64* desc, u32 tile, u32 epoch, Desc agg
             const int64_t j = hi - (int64_t)(4 * lane + i);
             // virtual tile -1 = inclusive (in_quote_in, 0): the shard's entering state
             d[i] = encode_desc(kStatusInc, epoch, (u64)in_quote_in);
-            if (j >= 0) d[i] = load_desc(desc + j);
+            if (j >= 0) d[i] = (PRE && use_pre) ? pre[i] : load_desc(desc + j);
         }
+        use_pre = false;
 #pragma unroll
         for (int i = 3; i >= 0; --i) {
             const u32 status = decode_desc(d[i], epoch, x[i]);
@@ -407,7 +447,6 @@ struct RoundMasks {
     u64 s;   // in-string mask relative to the wave span's start (span entered outside a string)
 };
 
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ void load_round(rsrc_t rsrc, u32 voff, uint4 (&v)[kRows]) {
     // The whole tile-relative offset lives in voff: the hardware range check covers
     // voffset + immediate only (soffset is excluded from bounds checking), and the check is what
@@ -475,7 +514,6 @@ __device__ __forceinline__ StageAddr stage_addr_of_lane(u32 lane) {
     return a;
 }
 
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
 __device__ __forceinline__ void dma_round(rsrc_t rsrc, u32 voff, uint4* stage) {
     // The whole tile-relative offset lives in voff (+ j * 1024 added in a VGPR): the hardware
     // range check covers voffset + immediate only, and the check is what makes reading "past the
@@ -842,6 +880,28 @@ __device__ __forceinline__ void finish_launch(const KernelArgs& args, u32 epoch,
     }
 }
 
+// Speculative scatter of a whole wave span into the window, done BEFORE the tile is resolved (while wave 0's look-back
+// polls are in flight): the entering state is guessed as "tile entered outside a string" (true for every tile of a
+// quote-free file and for ~90 % of the tiles of the quoted corpora); only the tape index base is still missing, and the
+// window does not need it.  The caller makes sure the span's entries fit one window.
+__device__ __forceinline__ void scatter_span_spec(const RoundMasks (&m)[kRounds], u32 lane, u32 wstate, unsigned short* comp) {
+    const u64 flipall = wstate ? ~0ull : 0ull;
+    u32 fill = 0;
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+        const u64 R = m[r].st & ~(m[r].s ^ flipall);
+        const u32 c = (u32)__builtin_popcountll(R);
+        const u32 incl = wave_incl_scan_add(c);
+        const u32 n_r = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        u32 roff = (u32)r * kRoundBytes;
+        asm volatile("" : "+s"(roff));
+        scatter_bits(comp, R, fill + incl - c, roff + lane * 64u);
+        fill += n_r;
+        asm volatile("" : "+s"(fill));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // Workgroup barrier that also drains this wave's LDS traffic first.  hipcc (ROCm 7.2) was observed to
 // emit a bare s_barrier for __syncthreads() when the preceding ds_write sits in a predecessor block
 // across a loop back-edge; the released waves' ds_reads then overtook the write (1 tile in ~10^5
@@ -915,7 +975,7 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
 
     RoundMasks held[kRounds];
     Desc held_agg = {0, 0, 0}, held_before = {0, 0, 0};
-    u32 held_tile = 0;
+    u32 held_tile = 0, held_wa = 0, held_wb = 0;  // wa / wb: this wave's own entry counts (entered outside / inside)
     bool have_held = false;
     u64 wg_tot = 0;  // wave 0: comma/CR/LF bytes in this workgroup's tiles
 
@@ -948,7 +1008,7 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
     bool hold_token = false;
 
     for (u32 iter = 0;; ++iter) {
-        if (t == 0) {
+        if (w == 0 && lane == 0) {  // (not `t == 0`: threadIdx.x itself would have to stay live through the loop)
             if (my_token && args.token_mode == 2) {
                 // both atomics in flight together (one round trip instead of two); a workgroup that then has to wait
                 // for the token does so holding its ticket — its aggregate is late by at most one count phase
@@ -977,13 +1037,14 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
         CSVSIMD_TRACE(0, tile)
         const bool have_cur = tile < args.num_tiles;
         if (hold_token && !have_cur) {  // nothing to count: the partner workgroup need not wait for this one
-            if (t == 0) __hip_atomic_store(my_token, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (w == 0 && lane == 0) __hip_atomic_store(my_token, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             hold_token = false;
         }
         if (!have_cur && !have_held) break;
 
         RoundMasks m[kRounds];
         Desc agg = {0, 0, 0}, before = {0, 0, 0};
+        u32 cur_wa = 0, cur_wb = 0;
         if (have_cur) {
             const u64 tile0 = (u64)tile * kTileBytes;  // relative to abase
             // descriptor over this tile's valid bytes, rounded up to whole 16-byte chunks (a chunk
@@ -1039,6 +1100,8 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
             }
             const u32 wave_a = wave_sum(cnt_a);
             const u32 wave_t = wave_sum(cnt_t);
+            cur_wa = wave_a;
+            cur_wb = wave_t - wave_a;
             if (lane == 0) {
                 s_wdesc[w][0] = carry;
                 s_wdesc[w][1] = wave_a;
@@ -1048,7 +1111,8 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
         CSVSIMD_STAMP(1)  // count phase
         CSVSIMD_TRACE(1, tile)
         wg_barrier();     // barrier A
-        if (hold_token && t == 0) __hip_atomic_store(my_token, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (hold_token && w == 0 && lane == 0)
+            __hip_atomic_store(my_token, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         CSVSIMD_STAMP(2)
         CSVSIMD_TRACE(2, tile)
 
@@ -1063,19 +1127,36 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
             }
         }
 
+        // Wave 0 publishes this tile's aggregate and REQUESTS the look-back window of the held tile; then every wave
+        // scatters its span of the held tile speculatively (see scatter_span_spec) — the 3-5 us the polls take behind the
+        // CU's streaming loads used to be seven idle waves at barrier B — and only then does wave 0 consume the window.
         if (w == 0) {
             if (have_cur) {
                 if (!(DBG & 4) && lane == 0) publish_aggregate(args.desc, tile, epoch, agg);
                 wg_tot += (u64)(u32)__builtin_amdgcn_readfirstlane((int)(agg.a + agg.b));
             }
-            if (have_held) {
-                u32 pin = 0;
-                u64 base = 0;
-                if (!(DBG & 4)) resolve(args.desc, held_tile, epoch, held_agg, inq_in, lane, pin, base, err);
-                if (lane == 0) {
-                    s_pin = pin;
-                    s_base = base;
-                }
+            // into wave 0's second stage image: idle until the next count phase
+            if (have_held && !(DBG & 4)) lookback_issue(args.desc, held_tile, lane, s_stage_b[0]);
+        }
+        bool spec_done = false;
+        const u32 spec_state = held_before.p;                        // this wave's entering state if the tile's is 0
+        const u32 spec_n = spec_state ? held_wb : held_wa;           // ... and its entry count under it
+        if (EMIT && have_held && !(DBG & 16) && spec_n <= (u32)kCompCap) {
+            scatter_span_spec(held, lane, spec_state, reinterpret_cast<unsigned short*>(s_stage[w]));
+            spec_done = true;
+        }
+        if (w == 0 && have_held) {
+            u32 pin = 0;
+            u64 base = 0;
+            if (!(DBG & 4)) {
+                u64 pre[4];
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                lookback_fetch(s_stage_b[0], held_tile, lane, pre);
+                resolve<true>(args.desc, held_tile, epoch, held_agg, inq_in, lane, pin, base, err, pre);
+            }
+            if (lane == 0) {
+                s_pin = pin;
+                s_base = base;
             }
         }
         CSVSIMD_STAMP(3)  // publish + resolve (wave 0)
@@ -1091,7 +1172,18 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
             const u32 wstate = pin ^ held_before.p;
             const u64 run = s_base + (pin ? held_before.b : held_before.a);
             const u64 span0 = (u64)held_tile * kTileBytes + (u64)w * kSpanBytes;
-            emit_span<(DBG & 16) != 0>(args, held, lane, span0, wstate, run, reinterpret_cast<unsigned short*>(s_stage[w]));
+            if (spec_done && pin == 0) {
+                // the guess was right: the window already holds the span's entries, only the stores are left
+                wave_lds_fence();
+                flush_window(args, reinterpret_cast<unsigned short*>(s_stage[w]), spec_n,
+                             ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(run >> 32)) << 32) |
+                                 (u32)__builtin_amdgcn_readfirstlane((int)(u32)run),
+                             args.base_off + span0 - args.lo, lane);
+                wave_lds_fence();
+            } else {
+                emit_span<(DBG & 16) != 0>(args, held, lane, span0, wstate, run,
+                                           reinterpret_cast<unsigned short*>(s_stage[w]));
+            }
         }
         if (have_held) { CSVSIMD_TRACE(5, held_tile) }
 #ifdef CSVSIMD_DEV_PROBES
@@ -1105,6 +1197,8 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
         held_tile = tile;
         held_agg = agg;
         held_before = before;
+        held_wa = cur_wa;
+        held_wb = cur_wb;
 #pragma unroll
         for (int r = 0; r < kRounds; ++r) held[r] = m[r];
         CSVSIMD_STAMP(5)  // emit
@@ -1123,7 +1217,10 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
     // ---- this workgroup is done; the last one to get here completes the launch --------------------
     if (w != 0) return;
     finish_launch<DIALECT, (DBG & 4) != 0>(args, (u32)__builtin_amdgcn_readfirstlane((int)epoch_v) & kEpochMask, inq_in,
-                                           wg_tot, err, lane);
+                                           wg_tot, err,
+                                           // the lane id again, from the execution mask: `lane` as derived from threadIdx.x
+                                           // would otherwise have to survive the tile loop in a register the loop needs
+                                           __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
 }
 
 // ---------------------------------------------------------------------------------------------
