@@ -597,22 +597,25 @@ __device__ __forceinline__ void count_phase(rsrc_t rsrc, u32 lane, u32 w, const 
         if (DIALECT == 2) {
             u64 bs = ((u64)(e16[0] | (e16[1] << 16)) | ((u64)(e16[2] | (e16[3] << 16)) << 32)) & keep;
             if (r == 0) bs |= ek.front_esc;
-            // does this stripe END inside an odd run of escape bytes (O), or is it one whole run (A)?
-            // The carry into every lane is then the carry chain of the scalar add (O|A) + O + carry-in:
-            // O generates, A propagates.
-            const u64 nb = ~bs;
-            const u32 lead = nb ? (u32)__builtin_clzll(nb) : 64u;
-            const u64 gen = __ballot(lead < 64u && (lead & 1u));
-            const u64 prop = __ballot(lead == 64u);
-            const u64 a = gen | prop;
-            const u64 s1 = a + gen;
-            const u64 s2 = s1 + esc_carry;
-            const u64 into = s2 ^ prop;  // bit l = the first byte of lane l's stripe is escaped
-            esc_carry = (u32)__builtin_amdgcn_readfirstlane((int)((u32)(s1 < a) | (u32)(s2 < s1)));
-            const u64 escaped = escaped_mask(bs, (u32)(into >> lane) & 1u);
-            st &= ~escaped;
-            x &= ~escaped;
-            asm volatile("" : "+s"(esc_carry));
+            // escape bytes are rare: a round whose 4 KiB hold none, entered with no pending escape, skips the rest
+            // (wave-uniform; ~40 of the round's ~360 VALU)
+            if (__ballot(bs != 0) != 0 || esc_carry != 0) {
+                // does this stripe END inside an odd run of escape bytes (O), or is it one whole run (A)?
+                // The carry into every lane is then the carry chain of the scalar add (O|A) + O + carry-in:
+                // O generates, A propagates.
+                const u64 nb = ~bs;
+                const u32 lead = nb ? (u32)__builtin_clzll(nb) : 64u;
+                const u64 gen = __ballot(lead < 64u && (lead & 1u));
+                const u64 prop = __ballot(lead == 64u);
+                const u64 a = gen | prop;
+                const u64 s1 = a + gen;
+                const u64 s2 = s1 + esc_carry;
+                const u64 into = s2 ^ prop;  // bit l = the first byte of lane l's stripe is escaped
+                esc_carry = (u32)__builtin_amdgcn_readfirstlane((int)((u32)(s1 < a) | (u32)(s2 < s1)));
+                const u64 escaped = escaped_mask(bs, (u32)(into >> lane) & 1u);
+                st &= ~escaped;
+                x &= ~escaped;
+            }
         }
         // inclusive prefix-xor over the stripe's 64 bits (src/avx/stage1.rs:342-361 does this
         // with one PCLMULQDQ; CDNA has no carry-less multiply)
@@ -631,7 +634,10 @@ __device__ __forceinline__ void count_phase(rsrc_t rsrc, u32 lane, u32 w, const 
         cnt_a += (u32)__builtin_popcountll(m[r].st & ~m[r].s);
         cnt_t += (u32)__builtin_popcountll(m[r].st);
         // anchor this round's results here: an opaque asm cannot be sunk or re-ordered
-        asm volatile("" : "+v"(m[r].st), "+v"(m[r].s), "+v"(cnt_a), "+v"(cnt_t), "+s"(carry));
+        if (DIALECT == 2)  // (an "s" operand downstream of the round's uniform branch does not compile: hipcc 7.2)
+            asm volatile("" : "+v"(m[r].st), "+v"(m[r].s), "+v"(cnt_a), "+v"(cnt_t));
+        else
+            asm volatile("" : "+v"(m[r].st), "+v"(m[r].s), "+v"(cnt_a), "+v"(cnt_t), "+s"(carry));
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -881,9 +887,11 @@ __device__ __forceinline__ void finish_launch(const KernelArgs& args, u32 epoch,
 }
 
 // Speculative scatter of a whole wave span into the window, done BEFORE the tile is resolved (while wave 0's look-back
-// polls are in flight): the entering state is guessed as "tile entered outside a string" (true for every tile of a
-// quote-free file and for ~90 % of the tiles of the quoted corpora); only the tape index base is still missing, and the
-// window does not need it.  The caller makes sure the span's entries fit one window.
+// polls are in flight): the tile's entering state is GUESSED — as the one of the two hypotheses under which the tile
+// has more entries (both counts are in its aggregate: read with the wrong quote parity, text outside strings looks
+// quoted and nearly every separator disappears; a quote-free tile has no entries at all "entered inside") — and only
+// the tape index base is still missing, which the window does not need.  A wrong guess costs the tile the ordinary
+// emit after the look-back, never correctness.  The caller makes sure the span's entries fit one window.
 __device__ __forceinline__ void scatter_span_spec(const RoundMasks (&m)[kRounds], u32 lane, u32 wstate, unsigned short* comp) {
     const u64 flipall = wstate ? ~0ull : 0ull;
     u32 fill = 0;
@@ -1139,8 +1147,9 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
             if (have_held && !(DBG & 4)) lookback_issue(args.desc, held_tile, lane, s_stage_b[0]);
         }
         bool spec_done = false;
-        const u32 spec_state = held_before.p;                        // this wave's entering state if the tile's is 0
-        const u32 spec_n = spec_state ? held_wb : held_wa;           // ... and its entry count under it
+        const u32 spec_pin = held_agg.b > held_agg.a ? 1u : 0u;      // the guess: the hypothesis with more entries
+        const u32 spec_state = spec_pin ^ held_before.p;             // this wave's entering state under it
+        const u32 spec_n = spec_state ? held_wb : held_wa;           // ... and its entry count
         if (EMIT && have_held && !(DBG & 16) && spec_n <= (u32)kCompCap) {
             scatter_span_spec(held, lane, spec_state, reinterpret_cast<unsigned short*>(s_stage[w]));
             spec_done = true;
@@ -1172,7 +1181,7 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
             const u32 wstate = pin ^ held_before.p;
             const u64 run = s_base + (pin ? held_before.b : held_before.a);
             const u64 span0 = (u64)held_tile * kTileBytes + (u64)w * kSpanBytes;
-            if (spec_done && pin == 0) {
+            if (spec_done && pin == (held_agg.b > held_agg.a ? 1u : 0u)) {
                 // the guess was right: the window already holds the span's entries, only the stores are left
                 wave_lds_fence();
                 flush_window(args, reinterpret_cast<unsigned short*>(s_stage[w]), spec_n,
