@@ -31,6 +31,7 @@ never part of `value`.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -63,6 +64,9 @@ def refuse_probe_environment(pkg):
         sys.exit("bench.py refuses a library built with -DCSVSIMD_DEV_PROBES")
 
 
+PIPELINE_DEPTH = 2   # steps in flight: step i + 1 is enqueued before step i's records are read (see run_sharded)
+
+
 class ShardBench:
     """One rank's shard: device buffer, tape shard, context.  Shards are contiguous byte ranges of one
     file of world * n bytes (n = whole rows); with skew every interior cut moves `skew` bytes to the right,
@@ -86,10 +90,15 @@ class ShardBench:
         # the bench sizes the tape from the known shape: no retry, no count pre-pass in a step (a quoted
         # corpus holds up to three comma/LF bytes per quoted field; a wrong speculation may count them all)
         self.cap = int(self.n // (width + 1) * (1.25 if q else 1.0)) + 1024
-        self.dtape = torch.empty(self.cap, dtype=torch.int64, device=device)
-        self.d_result = torch.zeros(8, dtype=torch.int64, device=device)
-        self.h_result = torch.zeros(8, dtype=torch.int64).pin_memory()
-        self.h_words = self.h_result.numpy()              # the same pinned bytes, cheap to read per step
+        # two tape buffers: consecutive steps alternate between them, as a caller that indexes batch after batch
+        # would, so that a step can be enqueued while the previous step's tape is still being consumed
+        self.dtapes = [torch.empty(self.cap, dtype=torch.int64, device=device) for _ in range(PIPELINE_DEPTH)]
+        self.dtape = self.dtapes[0]                       # what launch() writes and the verification reads
+        self.d_results = torch.zeros(PIPELINE_DEPTH, 8, dtype=torch.int64, device=device)
+        self.h_results = torch.zeros(PIPELINE_DEPTH, 8, dtype=torch.int64).pin_memory()
+        self.events = [torch.cuda.Event() for _ in range(PIPELINE_DEPTH)]
+        self.d_result, self.h_result = self.d_results[0], self.h_results[0]
+        self.h_words = self.h_results.numpy()             # the same pinned bytes, cheap to read per step
         self.ctx = pkg.Context(device.index)
         self.ctx.reserve(self.n)
         torch.cuda.synchronize(device)
@@ -112,16 +121,30 @@ class ShardBench:
             raise RuntimeError(f"stage1 failed: error={r.error} count={r.count} cap={self.cap}")
         return r
 
-    def run_pass(self, in_quote_in):
-        """Single-GPU step: launch, then read the result record back (the only synchronisation)."""
+    def use_slot(self, slot):
+        """Steps alternate between the tape buffers; launch() / reemit() / the verification use the current one."""
+        self.dtape = self.dtapes[slot]
+
+    def enqueue_pass(self, in_quote_in, slot=0):
+        """Single-GPU step, first half: launch into tape buffer `slot`, request the record's copy-out."""
+        self.use_slot(slot)
+        self.launch(in_quote_in, self.d_results[slot])
+        self.h_results[slot].copy_(self.d_results[slot], non_blocking=True)
+        self.events[slot].record(torch.cuda.current_stream(self.device))
+
+    def collect_pass(self, slot=0):
+        """Second half: wait for that step (its only synchronisation) and check its record."""
         from csv_simd_amd import sharded
-        self.launch(in_quote_in)
-        self.h_result.copy_(self.d_result, non_blocking=True)
-        torch.cuda.current_stream(self.device).synchronize()
-        w = self.h_words
+        self.events[slot].synchronize()
+        w = self.h_words[slot]
         if (int(w[4]) & 0xFFFFFFFF) or int(w[0]) > self.cap:   # error flag / more entries than the tape holds
-            return self.check(sharded.result_from_words(self.h_result.tolist()))
+            return self.check(sharded.result_from_words(self.h_results[slot].tolist()))
         return w
+
+    def run_pass(self, in_quote_in):
+        """Single-GPU step, unpipelined: launch, then read the result record back."""
+        self.enqueue_pass(in_quote_in, 0)
+        return self.collect_pass(0)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -267,16 +290,41 @@ def mid_row_cuts(oracle, pkg, workload, shard_bytes, world):
     return cuts + [world * per]
 
 
-def time_steps(step, steps, warmup, device, dist_on):
+# An MI355X that has been idle runs its first ~10 ms of load through a power-management transient: launches issued 2-10 ms
+# after the load starts take 5-8 % longer than the ones before and after (scripts/per_launch_times.py: 8 GiB launches
+# 1.66 1.71 1.80 1.76 1.70 then 1.645 flat; 1 GiB launches 0.225 x9, 0.25 x25, then 0.226 flat).  Every timed region
+# below is therefore preceded by SETTLE_MS of the same, untimed, load — in addition to the W warm-up steps.
+SETTLE_MS = 25.0
+
+
+def settle_count(bytes_per_launch, cap=400):
+    """Launches that make up SETTLE_MS of load; from the byte count alone, so every rank gets the same number."""
+    return max(1, min(cap, int(math.ceil(SETTLE_MS * 1e-3 / (bytes_per_launch / 4.5e12)))))
+
+
+def kernel_time_ms(sb, iters):
+    """Average duration of `iters` back-to-back launches of the product kernel (HIP events on its stream), in steady
+    state (see SETTLE_MS)."""
+    return sb.ctx.stage1_time_device(sb.dbuf.data_ptr(), sb.n, sb.dtape.data_ptr(), sb.cap, sb.d_result.data_ptr(),
+                                     sb.stream(), warmup=max(2, settle_count(sb.n)), iters=iters)
+
+
+def time_steps(step, steps, warmup, device, dist_on, settle=0, drain=None):
+    """`drain` (pipelined steps): collects whatever is still in flight — before the clock starts and, for the timed
+    steps, before it stops: all K steps are complete, and their records checked, inside the timed region."""
     import torch.distributed as dist
-    for _ in range(warmup):
+    for _ in range(settle + warmup):
         step()
+    if drain:
+        drain()
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    if drain:
+        drain()
     torch.cuda.synchronize(device)
     if dist_on:
         dist.barrier()
@@ -442,10 +490,45 @@ def consumers_leg(pkg, oracle, device):
 
 
 def run_sharded(pkg, sb, device, dist_on, rehearsal, comm, steps, warmup):
-    """Times `steps` steps of the workload in `sb`; returns (dt, state of the last step)."""
+    """Times `steps` steps of the workload in `sb`; returns (dt, state of the last step).
+
+    Steps are pipelined PIPELINE_DEPTH deep: a step's launches, its collective and its copy-out are enqueued, and only
+    then is the PREVIOUS step's record waited for and checked — the host's per-step work (launch latency, the
+    read-back, Python) overlaps the GPU's, as in a caller that indexes one batch after another.  Consecutive steps
+    write alternate tape buffers.  Every step's record is checked inside the timed region; CSVSIMD_BENCH_PIPELINE=0
+    restores one step at a time.  (The native-RCCL entry point is one blocking C call per step: not pipelined.)"""
     from csv_simd_amd import sharded
     state = {}
-    stepper = sharded.ShardedStep(device, gather_via_host=rehearsal) if (dist_on and comm is None) else None
+    depth = PIPELINE_DEPTH if os.environ.get("CSVSIMD_BENCH_PIPELINE", "1") != "0" and comm is None else 1
+    stepper = (sharded.ShardedStep(device, gather_via_host=rehearsal, depth=depth)
+               if (dist_on and comm is None) else None)
+    inflight = []          # slots enqueued and not yet collected, oldest first
+    counter = [0]
+
+    def enqueue(slot):
+        if dist_on:
+            d_res = stepper.slots[slot].d_result
+            sb.use_slot(slot)
+            tape = sb.dtape   # bound now: the re-emit must hit the same buffer as the speculative pass
+            stepper.enqueue(lambda inq: sb.launch(inq, d_res), lambda p: sb.reemit(p, d_res), slot=slot)
+            assert sb.dtape is tape
+        else:
+            sb.enqueue_pass(0, slot)
+
+    def collect(slot):
+        if dist_on:
+            st, final, _ = stepper.collect(slot)
+            sb.check(final)
+            assert final.count == st.count
+            state.update(count=st.count, inq=st.in_quote_in, base=st.tape_index_base, total=st.total_entries,
+                         final=st.in_quote_final, slot=slot)
+        else:
+            w = sb.collect_pass(slot)
+            state.update(count=int(w[0]), inq=0, base=1, total=int(w[0]) + 1, final=(int(w[3]) >> 32) & 1, slot=slot)
+
+    def drain():
+        while inflight:
+            collect(inflight.pop(0))
 
     def step():
         if comm is not None:
@@ -453,19 +536,21 @@ def run_sharded(pkg, sb, device, dist_on, rehearsal, comm, steps, warmup):
                                        sb.stream())
             sb.check(r)
             state.update(count=st.count, inq=st.in_quote_in, base=st.tape_index_base, total=st.total_entries,
-                         final=st.in_quote_final)
-        elif dist_on:
-            st, final, _ = stepper.run(lambda inq: sb.launch(inq, stepper.d_result),
-                                       lambda p: sb.reemit(p, stepper.d_result))
-            sb.check(final)
-            assert final.count == st.count
-            state.update(count=st.count, inq=st.in_quote_in, base=st.tape_index_base, total=st.total_entries,
-                         final=st.in_quote_final)
-        else:
-            w = sb.run_pass(0)
-            state.update(count=int(w[0]), inq=0, base=1, total=int(w[0]) + 1, final=(int(w[3]) >> 32) & 1)
+                         final=st.in_quote_final, slot=0)
+            return
+        slot = counter[0] % depth
+        counter[0] += 1
+        if len(inflight) == depth:      # the slot about to be reused holds the oldest step
+            collect(inflight.pop(0))
+        enqueue(slot)
+        inflight.append(slot)
+        if depth == 1:
+            drain()
 
-    dt = time_steps(step, steps, warmup, device, dist_on)
+    dt = time_steps(step, steps, warmup, device, dist_on, settle=settle_count(sb.total // max(sb.world, 1)),
+                    drain=drain)
+    sb.use_slot(state.get("slot", 0))   # the tape the last step wrote is the one the verification reads
+    state["pipeline_depth"] = depth
     return dt, state
 
 
@@ -574,9 +659,7 @@ def main():
     verified = None if args.no_verify else verify_everything(oracle, sb, state, dist_on, rank, world)
 
     # ---- roofline leg: the stage-1 kernel alone, HIP events on its own stream -------------------
-    kern_ms = sb.ctx.stage1_time_device(sb.dbuf.data_ptr(), sb.n, sb.dtape.data_ptr(), sb.cap,
-                                        sb.d_result.data_ptr(), sb.stream(),
-                                        warmup=2, iters=max(5, min(args.steps, 50)))
+    kern_ms = kernel_time_ms(sb, max(5, min(args.steps, 50)))
     achieved = sb.n / (kern_ms * 1e-3) / 1e9
     entries = state["count"]
     # what this GPU's HBM actually streams with the same traffic shape and no work at all (the tape
@@ -614,6 +697,7 @@ def main():
                                f"{sb.n / 2**30:.3f} GiB per GPU (BASELINE config 4's per-GPU shard shape)",
                    "bytes_per_gpu": sb.n, "total_bytes": total_bytes, "tape_entries": int(state["total"]),
                    "skew": args.skew,
+                   "steps_in_flight": state["pipeline_depth"],   # 2: step i+1 enqueued before step i's record is read
                    "parallelism": f"chunk-sharded x{world}, one all-gather of shard descriptors, stitch + "
                                   "conditional re-emit on the device"
                                   + (" (native RCCL from the C ABI)" if comm is not None else "")
@@ -640,8 +724,7 @@ def main():
                                  "ms_per_step": round(dtq / k * 1e3, 4), "steps": k,
                                  "GiB/s": round(sbq.total * k / dtq / 2**30, 2), "verified": vq}
         if rank == 0 and world == 1:
-            ms = sbq.ctx.stage1_time_device(sbq.dbuf.data_ptr(), sbq.n, sbq.dtape.data_ptr(), sbq.cap,
-                                            sbq.d_result.data_ptr(), sbq.stream(), 3, 10)
+            ms = kernel_time_ms(sbq, 10)
             out["q10_skew_check"]["kernel_ms"] = round(ms, 4)
             out["q10_skew_check"]["hbm_read_frac"] = round(sbq.n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
         del sbq
@@ -654,8 +737,7 @@ def main():
             for name in ("16x32_noquote", "16x32_q10", "1024x4_dense"):
                 del_sb = ShardBench(pkg, device, name, 1 << 30, 0, 1)
                 r = sharded.result_from_words(del_sb.run_pass(0).tolist())
-                ms = del_sb.ctx.stage1_time_device(del_sb.dbuf.data_ptr(), del_sb.n, del_sb.dtape.data_ptr(),
-                                                   del_sb.cap, del_sb.d_result.data_ptr(), del_sb.stream(), 2, 10)
+                ms = kernel_time_ms(del_sb, 20)
                 extra[name] = {"bytes": del_sb.n, "entries": r.count, "kernel_ms": round(ms, 4),
                                "GiB/s": round(del_sb.n / (ms * 1e-3) / 2**30, 2),
                                "hbm_read_frac": round(del_sb.n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),

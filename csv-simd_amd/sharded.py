@@ -69,6 +69,24 @@ def stitch_from_words(h) -> Stitch:
     return st
 
 
+class _StepSlot:
+    """Device block + pinned host image + completion event of one step in flight."""
+
+    def __init__(self, device: torch.device, world: int):
+        # one device block so a single copy carries everything the host wants: [mine 8 | stitch 8 | all 8w]
+        self.d_block = torch.zeros(8 + STITCH_WORDS + 8 * world, dtype=torch.int64, device=device)
+        self.d_result = self.d_block[0:8]
+        self.d_stitch = self.d_block[8:8 + STITCH_WORDS]
+        self.d_all = self.d_block[8 + STITCH_WORDS:]
+        self.h_block = torch.zeros_like(self.d_block, device="cpu")
+        self.event = None
+        if device.type == "cuda":
+            self.h_block = self.h_block.pin_memory()
+            self.event = torch.cuda.Event()
+        self.err = None
+        self.pending = False
+
+
 class ShardedStep:
     """Buffers of one rank's sharded step, allocated once: the step itself allocates nothing and never
     waits for the host until its single copy-out at the end.
@@ -79,9 +97,14 @@ class ShardedStep:
         reemit(d_stitch)               stage-1 launch that reads its entering state from device memory and
                                        returns at once unless it is 1                     (caller's C-ABI call)
         copy-out                       [final record | stitch | all records] -> pinned host, one synchronise
+
+    run() is the whole step.  enqueue() / collect() are its two halves: everything up to the copy-out is enqueued
+    without waiting for the host, so with depth >= 2 the next step (another file, or the next batch of this one, into
+    another tape buffer) can be enqueued before the previous one's records are read — the GPU never idles between
+    steps.  Every rank must enqueue and collect in the same order (the all-gather is a collective).
     """
 
-    def __init__(self, device: torch.device, group=None, gather_via_host: bool = False):
+    def __init__(self, device: torch.device, group=None, gather_via_host: bool = False, depth: int = 1):
         # gather_via_host: development rehearsal on a one-GPU box (several ranks share the card, the group is
         # gloo): the records make the trip through host memory; stitch kernel and re-emit launch are the real ones
         self.gather_via_host = gather_via_host
@@ -89,64 +112,81 @@ class ShardedStep:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.device = device
-        w = self.world
-        # one device block so a single copy carries everything the host wants: [mine 8 | stitch 8 | all 8w]
-        self.d_block = torch.zeros(8 + STITCH_WORDS + 8 * w, dtype=torch.int64, device=device)
-        self.d_result = self.d_block[0:8]
-        self.d_stitch = self.d_block[8:8 + STITCH_WORDS]
-        self.d_all = self.d_block[8 + STITCH_WORDS:]
-        self.h_block = torch.zeros_like(self.d_block, device="cpu")
-        if device.type == "cuda":
-            self.h_block = self.h_block.pin_memory()
+        self.slots = [_StepSlot(device, self.world) for _ in range(max(1, depth))]
+        # slot 0 under the names a depth-1 caller uses
+        s0 = self.slots[0]
+        self.d_block, self.d_result, self.d_stitch, self.d_all, self.h_block = (s0.d_block, s0.d_result, s0.d_stitch,
+                                                                                s0.d_all, s0.h_block)
 
-    def stitch_via_host(self, file_in_quote_in: int = 0) -> None:
+    def stitch_via_host(self, file_in_quote_in: int = 0, slot: int = 0) -> None:
         """CPU rehearsal of the stitch kernel (gloo groups, tensors in host memory): the same arithmetic
         through csvsimd_stitch_shards, written where the kernel would write it."""
-        host = self.d_all.tolist()
+        sl = self.slots[slot]
+        host = sl.d_all.tolist()
         results = [result_from_words(host[8 * i: 8 * i + 8]) for i in range(self.world)]
         st = stitch_shards(results, self.rank, file_in_quote_in)
-        self.d_stitch.copy_(torch.tensor([st.in_quote_in | (st.in_quote_final << 32), st.count, st.tape_index_base,
-                                          st.total_entries, st.error, 0, 0, 0], dtype=torch.int64))
+        sl.d_stitch.copy_(torch.tensor([st.in_quote_in | (st.in_quote_final << 32), st.count, st.tape_index_base,
+                                        st.total_entries, st.error, 0, 0, 0], dtype=torch.int64))
 
-    def run(self, launch: Callable[[int], None], reemit: Callable[[int], None], file_in_quote_in: int = 0,
-            rehearsal: bool = False) -> Tuple[Stitch, ShardResult, List[ShardResult]]:
-        """launch(0) must enqueue the speculative pass with its record going to self.d_result;
-        reemit(d_stitch_ptr) must enqueue csvsimd_stage1_reemit_device_async into the same tape / record.
-        Returns (stitch, this rank's final record, every rank's speculative record)."""
+    def enqueue(self, launch: Callable[[int], None], reemit: Callable[[int], None], file_in_quote_in: int = 0,
+                rehearsal: bool = False, slot: int = 0) -> None:
+        """Everything of a step except waiting for it.  launch(0) must enqueue the speculative pass with its record
+        going to self.slots[slot].d_result; reemit(d_stitch_ptr) must enqueue csvsimd_stage1_reemit_device_async
+        into the same tape / record."""
         from . import stitch_shards_device_async
-        err = None
+        sl = self.slots[slot]
+        if sl.pending:
+            raise RuntimeError("ShardedStep: slot enqueued again before it was collected")
+        sl.err = None
         try:
             launch(0)
         except Exception as e:  # still join the collective: the peers are about to block in it
-            err = e
-            self.d_result.zero_()
-            self.d_result[4] = 1  # error flag set: every rank will report the failure
+            sl.err = e
+            sl.d_result.zero_()
+            sl.d_result[4] = 1  # error flag set: every rank will report the failure
         if self.gather_via_host:
             h_all = torch.empty(8 * self.world, dtype=torch.int64)
-            dist.all_gather_into_tensor(h_all, self.d_result.cpu(), group=self.group)
-            self.d_all.copy_(h_all)
+            dist.all_gather_into_tensor(h_all, sl.d_result.cpu(), group=self.group)
+            sl.d_all.copy_(h_all)
         else:
-            dist.all_gather_into_tensor(self.d_all, self.d_result, group=self.group)
+            dist.all_gather_into_tensor(sl.d_all, sl.d_result, group=self.group)
         if rehearsal:
-            self.stitch_via_host(file_in_quote_in)
+            self.stitch_via_host(file_in_quote_in, slot)
         else:
             stream = torch.cuda.current_stream(self.device).cuda_stream
-            stitch_shards_device_async(self.d_all.data_ptr(), self.world, self.rank, file_in_quote_in,
-                                       self.d_stitch.data_ptr(), stream)
-        if err is None:
-            reemit(self.d_stitch.data_ptr())
-        self.h_block.copy_(self.d_block, non_blocking=True)
-        if self.device.type == "cuda":
-            torch.cuda.current_stream(self.device).synchronize()   # the step's only synchronisation
-        if err is not None:
-            raise err
-        h = self.h_block.tolist()
+            stitch_shards_device_async(sl.d_all.data_ptr(), self.world, self.rank, file_in_quote_in,
+                                       sl.d_stitch.data_ptr(), stream)
+        if sl.err is None:
+            reemit(sl.d_stitch.data_ptr())
+        sl.h_block.copy_(sl.d_block, non_blocking=True)
+        if sl.event is not None:
+            sl.event.record(torch.cuda.current_stream(self.device))
+        sl.pending = True
+
+    def collect(self, slot: int = 0) -> Tuple[Stitch, ShardResult, List[ShardResult]]:
+        """Waits for the step enqueued in `slot` (its only synchronisation) and returns
+        (stitch, this rank's final record, every rank's speculative record)."""
+        sl = self.slots[slot]
+        if not sl.pending:
+            raise RuntimeError("ShardedStep: nothing enqueued in this slot")
+        if sl.event is not None:
+            sl.event.synchronize()
+        sl.pending = False
+        if sl.err is not None:
+            raise sl.err
+        h = sl.h_block.tolist()
         st = stitch_from_words(h[8:8 + STITCH_WORDS])
         final = result_from_words(h[0:8])
         if st.error or final.error:
             raise RuntimeError("stage 1 reported an internal error on some rank (no rank has a valid tape)")
         return st, final, [result_from_words(h[8 + STITCH_WORDS + 8 * i: 16 + STITCH_WORDS + 8 * i])
                            for i in range(self.world)]
+
+    def run(self, launch: Callable[[int], None], reemit: Callable[[int], None], file_in_quote_in: int = 0,
+            rehearsal: bool = False) -> Tuple[Stitch, ShardResult, List[ShardResult]]:
+        """One whole step in slot 0: enqueue, then collect."""
+        self.enqueue(launch, reemit, file_in_quote_in, rehearsal, 0)
+        return self.collect(0)
 
 
 def index_sharded(launch: Callable[[int], None], d_result: torch.Tensor, group=None,
