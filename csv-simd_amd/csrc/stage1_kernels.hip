@@ -1211,6 +1211,13 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
 #pragma unroll
         for (int r = 0; r < kRounds; ++r) held[r] = m[r];
         CSVSIMD_STAMP(5)  // emit
+        // the tickets are exhausted for good and nothing is held any more: leave without another trip through the token
+        // and the ticket counter.  Measured and rejected around this hand-off (ab_variants, 8 GiB / 1 GiB):
+        //  * reading the ticket counter next to the token CAS, so that a workgroup with nothing left to count never
+        //    waits for its partner's count phase: the extra load sits on the count phases' critical path, -35 %;
+        //  * drawing the NEXT ticket right after barrier A, so that only the token is left to wait for at the loop
+        //    top: -0.5 ... -2 % (a shorter hand-off does not help: the steady state is bound by HBM, not by this chain).
+        if (!have_cur) break;
     }
 #ifdef CSVSIMD_DEV_PROBES
     if ((DBG & 8) && lane == 0 && w < 2) {

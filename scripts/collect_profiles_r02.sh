@@ -34,6 +34,27 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS
     echo "dense pmc pass $i done: $grp"
 done
 python3 $REPO/scripts/summarise_pmc.py "$OUT/dense" "$OUT/pmc_1024x4_dense_1GiB.json" 1073740800 1717985280 "1024x4_dense 1 GiB"
+# per-launch durations of the stage-1 kernel, in launch order (the stats average includes bench.py's settle launches,
+# i.e. the power-management transient after idle; the last launches are the ones bench.py's HIP events time)
+python3 - "$OUT" <<'PY'
+import csv, glob, os, sys
+out = sys.argv[1]
+for tag, sub in (("64x31_8GiB", "stats"), ("1024x4_dense_1GiB", "stats_dense")):
+    rows = []
+    for path in glob.glob(os.path.join(out, sub, "**", "*kernel_trace.csv"), recursive=True):
+        with open(path, newline="") as f:
+            for r in csv.DictReader(f):
+                if "stage1_kernel" in r["Kernel_Name"]:
+                    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    rows.sort()
+    d = [x[1] / 1e6 for x in rows]
+    with open(os.path.join(out, f"launch_durations_{tag}.txt"), "w") as f:
+        f.write(f"# stage1_kernel launches in order, ms (rocprofv3 --kernel-trace); n = {len(d)}\n")
+        f.write(" ".join("%.4f" % x for x in d) + "\n")
+        for k in (10, 20):
+            if len(d) >= k:
+                f.write(f"# mean of the last {k}: {sum(d[-k:]) / k:.4f} ms; of all: {sum(d) / len(d):.4f} ms\n")
+PY
 # keep what travels back small: the raw traces stay on the box
 find "$OUT" -name "*kernel_trace.csv" -delete
 find "$OUT" -name "*counter_collection.csv" -delete
