@@ -49,15 +49,42 @@ def worker(rank, world, port, n, seed, p_quote, skew, outdir, device_flow=False)
         if device_flow:
             # the control flow bench.py and the native C entry point drive on GPUs (stitch in "device"
             # memory, re-emit launch that reads its entering state from there), rehearsed on host tensors
-            step = sharded.ShardedStep(torch.device("cpu"))
-            d_result = step.d_result
+            depth = 2 if device_flow == 2 else 1
+            step = sharded.ShardedStep(torch.device("cpu"), depth=depth)
 
-            def reemit(d_stitch_ptr):
-                assert d_stitch_ptr == step.d_stitch.data_ptr()
-                if int(step.d_stitch[0]) & 0xFFFFFFFF:   # what the kernel reads when it starts
-                    run_pass(1)
+            def callbacks(slot):
+                sl = step.slots[slot]
 
-            st, final, records = step.run(run_pass, reemit, rehearsal=True)
+                def launch(inq):
+                    nonlocal d_result
+                    d_result = sl.d_result
+                    run_pass(inq)
+
+                def reemit(d_stitch_ptr):
+                    nonlocal d_result
+                    assert d_stitch_ptr == sl.d_stitch.data_ptr()
+                    if int(sl.d_stitch[0]) & 0xFFFFFFFF:   # what the kernel reads when it starts
+                        d_result = sl.d_result
+                        run_pass(1)
+                return launch, reemit
+
+            if depth == 1:
+                st, final, records = step.run(*callbacks(0), rehearsal=True)
+            else:
+                # two steps in flight, as bench.py drives them: both enqueued before either is collected
+                step.enqueue(*callbacks(0), rehearsal=True, slot=0)
+                step.enqueue(*callbacks(1), rehearsal=True, slot=1)
+                try:
+                    step.enqueue(*callbacks(0), rehearsal=True, slot=0)
+                    raise AssertionError("a slot must not be enqueued again before it is collected")
+                except RuntimeError:
+                    pass
+                st, final, records = step.collect(0)
+                st1, final1, records1 = step.collect(1)
+                assert (st1.in_quote_in, st1.count, st1.tape_index_base, st1.total_entries, st1.in_quote_final) == \
+                    (st.in_quote_in, st.count, st.tape_index_base, st.total_entries, st.in_quote_final)
+                assert final1.count == final.count and len(records1) == len(records)
+                passes[:] = passes[:len(passes) // 2]   # the second step repeated the first one's passes
             re_emitted = bool(st.in_quote_in)
             assert len(records) == world and records[rank].count_enter_outside + records[rank].count_enter_inside \
                 == int(np.isin(shard, (0x2C, 0x0A, 0x0D)).sum())

@@ -58,7 +58,7 @@ def test_stitch_host_arithmetic(pkg, oracle):
 
 @pytest.mark.parametrize("world,p_quote,skew,device_flow",
                          [(2, 0.0, 0, False), (2, 0.06, 0, False), (2, 0.06, 777, False), (3, 0.1, 13, False),
-                          (2, 0.06, 777, True), (4, 0.1, 13, True)])
+                          (2, 0.06, 777, True), (4, 0.1, 13, True), (2, 0.1, 777, 2), (3, 0.06, 13, 2)])
 def test_gloo_sharded_stitch(pkg, oracle, tmp_path, world, p_quote, skew, device_flow):
     import torch.multiprocessing as mp
     n, seed = 40000, 4242
