@@ -7,6 +7,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <emmintrin.h>
 
 #include <algorithm>
 #include <condition_variable>
@@ -39,6 +40,37 @@ int fail_hip(hipError_t e, const char* what) {
         if (_e != hipSuccess) return fail_hip(_e, #expr);     \
     } while (0)
 
+// Streaming copy for the ingest pipeline's slices: 4 MiB per thread is below the size at which glibc's memcpy switches
+// to non-temporal stores, so memcpy reads the DESTINATION lines too (read-for-ownership) — a third of the memory
+// traffic of a copy whose destination nobody on the CPU is going to read (the DMA engine reads the staging slot, the
+// caller reads the tape later).  Non-temporal stores leave that out and keep the caches for the copying threads'
+// neighbours.  SSE2 only (x86-64 baseline): 16-byte streams fill whole write-combining lines just as well.
+static void copy_streaming(char* dst, const char* src, size_t n) {
+#ifdef CSVSIMD_DEV_PROBES
+    static const bool plain = getenv("CSVSIMD_PROBE_PLAIN_MEMCPY") != nullptr;
+    if (plain) {
+        memcpy(dst, src, n);
+        return;
+    }
+#endif
+    const size_t head = std::min<size_t>(n, (size_t)(-(uintptr_t)dst & 63u));  // up to the next 64-byte line of dst
+    if (head) memcpy(dst, src, head);
+    dst += head, src += head, n -= head;
+    const size_t body = n & ~(size_t)63;
+    for (size_t i = 0; i < body; i += 64) {
+        const __m128i a = _mm_loadu_si128((const __m128i*)(src + i));
+        const __m128i b = _mm_loadu_si128((const __m128i*)(src + i + 16));
+        const __m128i c = _mm_loadu_si128((const __m128i*)(src + i + 32));
+        const __m128i d = _mm_loadu_si128((const __m128i*)(src + i + 48));
+        _mm_stream_si128((__m128i*)(dst + i), a);
+        _mm_stream_si128((__m128i*)(dst + i + 16), b);
+        _mm_stream_si128((__m128i*)(dst + i + 32), c);
+        _mm_stream_si128((__m128i*)(dst + i + 48), d);
+    }
+    _mm_sfence();
+    if (n - body) memcpy(dst + body, src + body, n - body);
+}
+
 // Host-side copies of the ingest pipeline (user buffer -> pinned staging, pinned tape -> user tape).
 // One thread moves ~10-20 GB/s, less than the PCIe link it feeds, so the copies are sliced over a few
 // persistent workers (measured on the MI355X host: 22 -> 39 GiB/s host buffer to tape).
@@ -60,7 +92,7 @@ public:
         constexpr size_t kMinSlice = 2u << 20;
         const size_t parts = std::min<size_t>(threads_.size() + 1, std::max<size_t>(1, n / kMinSlice));
         if (parts <= 1) {
-            memcpy(dst, src, n);
+            copy_streaming((char*)dst, (const char*)src, n);
             return;
         }
         const size_t slice = ((n / parts) + 4095) & ~(size_t)4095;
@@ -72,7 +104,7 @@ public:
             }
         }
         cv_work_.notify_all();
-        memcpy(dst, src, std::min(slice, n));  // the calling thread takes the first slice
+        copy_streaming((char*)dst, (const char*)src, std::min(slice, n));  // the calling thread takes the first slice
         std::unique_lock<std::mutex> g(m_);
         cv_done_.wait(g, [this] { return pending_ == 0; });
     }
@@ -93,7 +125,7 @@ private:
                 j = jobs_.back();
                 jobs_.pop_back();
             }
-            memcpy(j.dst, j.src, j.n);
+            copy_streaming(j.dst, j.src, j.n);
             {
                 std::lock_guard<std::mutex> g(m_);
                 if (--pending_ == 0) cv_done_.notify_all();

@@ -22,4 +22,24 @@ for name in ("64x31_noquote", "16x32_q10"):
         assert rc == 0 and cnt == n // (width + 1) + 1
         best = min(best, dt)
     out[name] = {"bytes": n, "entries": cnt, "s": round(best, 4), "GiB/s_pcie_inclusive": round(n / best / 2**30, 2)}
+def numa_facts():
+    import ctypes
+    f = {"cpu_now": ctypes.CDLL(None).sched_getcpu()}
+    try:
+        bus = torch.cuda.get_device_properties(0).pci_bus_id
+        f["pci_bus"] = bus
+    except Exception as e:
+        f["pci_bus"] = str(e)[:40]
+    try:
+        import glob
+        nodes = {}
+        for nd in sorted(glob.glob("/sys/devices/system/node/node[0-9]*")):
+            nodes[os.path.basename(nd)] = open(nd + "/cpulist").read().strip()
+        f["nodes"] = nodes
+        for d in glob.glob("/sys/class/drm/card*/device/numa_node"):
+            f.setdefault("gpu_numa", {})[d.split("/")[4]] = open(d).read().strip()
+    except Exception as e:
+        f["err"] = str(e)[:60]
+    return f
+out["numa"] = numa_facts()
 print(json.dumps(out))
