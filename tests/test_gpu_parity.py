@@ -151,6 +151,58 @@ def test_adversarial_densities(ctx, torch_cuda, pkg, oracle):
         assert np.array_equal(got, want), name
 
 
+def test_speculative_scatter_guesses(ctx, torch_cuda, pkg, oracle):
+    """The emit phase scatters a tile into its window BEFORE the look-back has resolved it, under the guess "the
+    entering state with more entries" (stage1_kernels.hip: scatter_span_spec).  Tiles built so that the guess is
+    right with either state and wrong with either state, sparse enough (<= one entry per 16 bytes) that every span
+    fits one window, i.e. the speculation really happens; the tape must be the oracle's in every case."""
+    T = pkg.tile_bytes()
+    row = b"aaaaaaaaaaaaaaaaaaa,bbbbbbbbbbbbbbbbbbb\n"          # 40 bytes, 2 entries
+
+    def rows(nbytes):
+        return (row * (nbytes // len(row) + 1))[:nbytes]
+
+    def plain():                 # entered outside, stays outside: guess "outside", right
+        return rows(T)
+
+    def opens_at_end():          # ... and ends inside a string
+        b = bytearray(rows(T))
+        b[T - 24:T] = b',"unterminated text .....'[:24]
+        return bytes(b)
+
+    def closes_at_start():       # truly entered INSIDE; the string closes at once: guess "inside", right
+        b = bytearray(rows(T))
+        b[0:12] = b'still text",'
+        return bytes(b)
+
+    def quoted_body():           # entered outside; nearly the whole tile is ONE quoted field full of commas:
+        b = bytearray(b"y" * T)  # "outside" has 3 entries, "inside" thousands -> guess "inside", WRONG
+        b[0:6] = b"ab,cd\n"
+        b[6] = 0x22
+        for i in range(8, T - 32, 24):
+            b[i] = 0x2C
+        b[T - 2] = 0x22
+        b[T - 1] = 0x0A
+        return bytes(b)
+
+    def quoted_body_entered_inside():   # truly entered inside and stays inside a comma-rich text until the very end:
+        b = bytearray(b"z" * T)         # "inside" has no entries, "outside" thousands -> guess "outside", WRONG
+        for i in range(8, T - 32, 24):
+            b[i] = 0x2C
+        b[T - 1] = 0x22                 # the string closes with the tile
+        return bytes(b)
+
+    seq = [plain(), opens_at_end(), closes_at_start(), quoted_body(), plain(), opens_at_end(),
+           quoted_body_entered_inside(), plain(), quoted_body(), opens_at_end(), closes_at_start(), plain()]
+    for tail in (0, 1, 4097):
+        d = np.frombuffer(b"".join(seq) + rows(tail), dtype=np.uint8)
+        for inq in (0, 1):
+            got, r = gpu_index(ctx, torch_cuda, d, in_quote_in=inq, base_off=3)
+            want, q = oracle.scalar_index(d, base_off=3, in_quote_in=inq)
+            assert r.count == want.size and r.in_quote_out == q, (tail, inq)
+            assert np.array_equal(got, want), (tail, inq)
+
+
 def test_tape_capacity_and_count_only(ctx, torch_cuda, pkg, oracle):
     rng = np.random.default_rng(8)
     d = random_csvish(rng, 300000, 0.01)
