@@ -1098,9 +1098,8 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
                 }
                 cnt_a = acc & 1u;
             } else {
-                // pacing (host-chosen per launch size, measured: DESIGN.md §4 "Pacing"): short launches give
-                // the phase that keeps HBM loads in flight the SIMD's issue priority over the partner
-                // workgroup's emit phase
+                // pacing (DESIGN.md §4 "Pacing"): the phase that keeps HBM loads in flight gets the SIMD's issue
+                // priority over the partner workgroup's resolve / emit phase
                 if (args.count_prio) __builtin_amdgcn_s_setprio(3);
                 count_phase<DIALECT>(rsrc, lane, w, ek, s_stage[w], s_stage_b[w], m, carry, cnt_a, cnt_t, dr,
                                      esc_carry);
@@ -1174,7 +1173,7 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
         CSVSIMD_STAMP(4)
         if (have_held) { CSVSIMD_TRACE(4, held_tile) }
         if (EMIT && have_held) {
-            // pacing, long launches: ~2 us between barrier B and the emit phase (see DESIGN.md §4 "Pacing")
+            // pacing knob, 0 by default since the per-CU token: a pause between barrier B and the flush
             for (u32 z = 0; z < args.emit_delay; ++z) __builtin_amdgcn_s_sleep(10);
             const u32 pin = s_pin;
             // state entering this wave's span and tape index of its first entry
@@ -1493,6 +1492,8 @@ hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream) {
     //   token + priority              1.681  0.439  0.2315  0.522   <- default: 63.9 / 61.1 / 58.0 / 25.7 % of 8 TB/s
     //   token + priority + pause      1.691  0.442  0.2332  0.518
     //   token, both atomics at once   1.789  0.463  0.2413  0.526   (a workgroup may then wait for the token holding a ticket)
+    // (taken before the speculative scatter went in; with it the default row reads 1.645 / 0.427 / 0.2235 / 0.523 =
+    // 65.3 / 62.9 / 60.0 / 25.6 %, and the ordering of the rows is unchanged.)
     // The pause knob stays (0 by default); the probe build's environment hooks override all three per launch.
     a.emit_delay = L.pace_emit_delay >= 0 ? (u32)L.pace_emit_delay : 0u;
     a.count_prio = L.pace_count_prio >= 0 ? (u32)L.pace_count_prio : 1u;
