@@ -604,6 +604,9 @@ def main():
     ap.add_argument("--native-rccl", action="store_true",
                     help="do the sharded step inside the C ABI (csvsimd_stage1_index_sharded: ncclAllGather "
                          "from C++) instead of torch.distributed.all_gather_into_tensor")
+    ap.add_argument("--only-consumers", action="store_true",
+                    help="development / profiling: run the `consumers` leg alone and print its record (not the "
+                         "contract line)")
     args = ap.parse_args()
     if os.environ.get("CSVSIMD_BENCH_WATCHDOG"):   # development: where is a stuck run stuck?
         import faulthandler
@@ -641,6 +644,9 @@ def main():
     refuse_probe_environment(pkg)
     from csv_simd_amd import sharded
     oracle = graft.load_oracle() if not (args.no_verify and args.no_cpu_baseline) else None
+    if args.only_consumers:
+        print(json.dumps({"consumers": consumers_leg(pkg, oracle or graft.load_oracle(), device)}))
+        return
 
     shard_bytes = int(args.gib_per_gpu * 2**30)
     sb = ShardBench(pkg, device, args.workload, shard_bytes, rank, world, args.skew)
