@@ -1215,7 +1215,10 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
         //  * reading the ticket counter next to the token CAS, so that a workgroup with nothing left to count never
         //    waits for its partner's count phase: the extra load sits on the count phases' critical path, -35 %;
         //  * drawing the NEXT ticket right after barrier A, so that only the token is left to wait for at the loop
-        //    top: -0.5 ... -2 % (a shorter hand-off does not help: the steady state is bound by HBM, not by this chain).
+        //    top: -0.5 ... -2 % (a shorter hand-off does not help: the steady state is bound by HBM, not by this chain);
+        //  * resolving and emitting a tile that is among the last gridDim.x of the shard in the iteration that counted
+        //    it (un-lagged, right behind the held one) so that the launch drains in two back-to-back resolves: 0 ... -0.5 %
+        //    (the un-lagged look-back waits for the predecessors that are still counting), and 2 VGPR spills.
         if (!have_cur) break;
     }
 #ifdef CSVSIMD_DEV_PROBES
