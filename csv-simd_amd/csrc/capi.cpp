@@ -23,12 +23,21 @@
 #include <vector>
 
 #include "../host/csv_simd.hpp"
+#include "abi_guard.h"
 #include "csvsimd.h"
 #include "stage1_kernels.h"
 
 namespace {
 
 thread_local std::string g_last_error;
+}  // namespace
+void csvsimd_set_last_error_noexcept(const char* what) noexcept {
+    try {
+        g_last_error = what ? what : "";
+    } catch (...) {  // not even the message could be stored: the error code still tells the caller
+    }
+}
+namespace {
 
 int fail_hip(hipError_t e, const char* what) {
     g_last_error = std::string(what) + ": " + hipGetErrorString(e);
@@ -217,6 +226,7 @@ uint32_t csvsimd_abi_version(void) { return 2; }
 uint32_t csvsimd_tile_bytes(void) { return CSVSIMD_TILE_BYTES; }
 
 int csvsimd_ctx_create(int device, csvsimd_ctx** out) {
+    return csvsimd_guarded([&]() -> int {
     if (!out) return CSVSIMD_ERR_INVALID_ARG;
     *out = nullptr;
     const int n = csvsimd_device_count();
@@ -243,6 +253,7 @@ int csvsimd_ctx_create(int device, csvsimd_ctx** out) {
         *out = nullptr;
     }
     return rc;
+    });
 }
 
 void csvsimd_ctx_destroy(csvsimd_ctx* ctx) {
@@ -581,13 +592,17 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
 
 int csvsimd_stage1_index(csvsimd_ctx* ctx, const uint8_t* buf, uint64_t len, uint64_t* tape, uint64_t tape_cap,
                          uint64_t* tape_len, uint32_t* in_quote_out) {
+    return csvsimd_guarded([&]() -> int {
     return stage1_index_host_impl(ctx, nullptr, buf, len, tape, tape_cap, tape_len, in_quote_out);
+    });
 }
 
 int csvsimd_stage1_index_dialect(csvsimd_ctx* ctx, const csvsimd_dialect* dialect, const uint8_t* buf, uint64_t len,
                                  uint64_t* tape, uint64_t tape_cap, uint64_t* tape_len, uint32_t* in_quote_out) {
+    return csvsimd_guarded([&]() -> int {
     if (!dialect) return CSVSIMD_ERR_INVALID_ARG;
     return stage1_index_host_impl(ctx, dialect, buf, len, tape, tape_cap, tape_len, in_quote_out);
+    });
 }
 
 int csvsimd_stitch_shards(const csvsimd_shard_result* results, uint32_t n_shards, uint32_t rank,
@@ -635,6 +650,7 @@ extern "C" {
 
 int csvsimd_tape_create(const uint8_t* bytes, uint64_t len, const uint64_t* index, uint64_t index_len,
                         csvsimd_tape** out) {
+    return csvsimd_guarded([&]() -> int {
     if (!bytes || !index || !out) return CSVSIMD_ERR_INVALID_ARG;
     *out = nullptr;
     csv_simd::Header h;
@@ -646,6 +662,7 @@ int csvsimd_tape_create(const uint8_t* bytes, uint64_t len, const uint64_t* inde
     if (e != csv_simd::StructureError::Ok) return (int)e;
     *out = t.release();
     return CSVSIMD_OK;
+    });
 }
 
 void csvsimd_tape_destroy(csvsimd_tape* t) { delete t; }
@@ -668,6 +685,7 @@ int64_t csvsimd_tape_header_name(const csvsimd_tape* t, uint32_t i, char* dst, u
 }
 
 int csvsimd_tape_seek_record(const csvsimd_tape* t, uint32_t record_idx, uint64_t* begin, uint64_t* end, int* found) {
+    return csvsimd_guarded([&]() -> int {
     if (!t || !begin || !end || !found) return CSVSIMD_ERR_INVALID_ARG;
     std::optional<std::pair<uint64_t, uint64_t>> span;
     const auto e = csv_simd::RecordSource<csv_simd::Tape>::seek_record(t->tape, record_idx, span);
@@ -675,10 +693,12 @@ int csvsimd_tape_seek_record(const csvsimd_tape* t, uint32_t record_idx, uint64_
     *found = span ? 1 : 0;
     if (span) { *begin = span->first; *end = span->second; }
     return CSVSIMD_OK;
+    });
 }
 
 int csvsimd_tape_seek_field(const csvsimd_tape* t, uint32_t record_idx, uint32_t field_idx, uint64_t* begin,
                             uint64_t* end, int* found) {
+    return csvsimd_guarded([&]() -> int {
     if (!t || !begin || !end || !found) return CSVSIMD_ERR_INVALID_ARG;
     std::optional<std::pair<uint64_t, uint64_t>> span;
     const auto e = csv_simd::RecordSource<csv_simd::Tape>::seek_field(t->tape, record_idx, field_idx, span);
@@ -686,18 +706,22 @@ int csvsimd_tape_seek_field(const csvsimd_tape* t, uint32_t record_idx, uint32_t
     *found = span ? 1 : 0;
     if (span) { *begin = span->first; *end = span->second; }
     return CSVSIMD_OK;
+    });
 }
 
 int csvsimd_boundaries(uint32_t task_size, uint8_t job_count, csvsimd_boundary* out, uint32_t* n_out) {
+    return csvsimd_guarded([&]() -> int {
     if (!out || !n_out) return CSVSIMD_ERR_INVALID_ARG;
     const auto b = csv_simd::boundaries(task_size, job_count);
     if (!b) return CSVSIMD_ERR_INVALID_STATE;
     *n_out = (uint32_t)b->size();
     for (size_t i = 0; i < b->size(); ++i) out[i] = csvsimd_boundary{(*b)[i].start, (*b)[i].len};
     return CSVSIMD_OK;
+    });
 }
 
 int csvsimd_tape_chunks(const csvsimd_tape* t, uint8_t num, csvsimd_chunk* out, uint32_t* n_out) {
+    return csvsimd_guarded([&]() -> int {
     if (!t || !out || !n_out) return CSVSIMD_ERR_INVALID_ARG;
     std::vector<csv_simd::Chunk> c;
     const auto e = t->tape.chunks(num, c);
@@ -705,6 +729,7 @@ int csvsimd_tape_chunks(const csvsimd_tape* t, uint8_t num, csvsimd_chunk* out, 
     *n_out = (uint32_t)c.size();
     for (size_t i = 0; i < c.size(); ++i) out[i] = csvsimd_chunk{c[i].id, c[i].start, c[i].end, c[i].record_cnt};
     return CSVSIMD_OK;
+    });
 }
 
 const uint64_t* csvsimd_tape_index(const csvsimd_tape* t, uint64_t* index_len) {
@@ -718,6 +743,7 @@ const uint8_t* csvsimd_tape_bytes(const csvsimd_tape* t, uint64_t* len) {
 
 // csv_simd::create (src/lib.rs:61-74): open, mmap, Header::new, reader::read (GPU), tape
 int csvsimd_create(csvsimd_ctx* ctx, const char* filename, csvsimd_tape** out) {
+    return csvsimd_guarded([&]() -> int {
     if (!ctx || !filename || !out) return CSVSIMD_ERR_INVALID_ARG;
     *out = nullptr;
     const int fd = open(filename, O_RDONLY);
@@ -752,6 +778,7 @@ int csvsimd_create(csvsimd_ctx* ctx, const char* filename, csvsimd_tape** out) {
     if (e != csv_simd::StructureError::Ok) return (int)e;
     *out = t.release();
     return CSVSIMD_OK;
+    });
 }
 
 /* ---- utilities ------------------------------------------------------------------------------ */
@@ -856,6 +883,7 @@ int csvsimd_column_frequency_device(csvsimd_ctx* ctx, const void* dbytes, const 
                                     uint32_t field_cnt, int new_line, const csvsimd_chunk* chunks, uint32_t n_chunks,
                                     uint32_t field_idx, void* d_scratch, uint64_t table_slots, void* d_entries,
                                     uint64_t entries_cap, csvsimd_freq_status* status, void* hip_stream) {
+    return csvsimd_guarded([&]() -> int {
     if (!ctx || !dbytes || !dindex || !chunks || !n_chunks || !d_scratch || !status || (entries_cap && !d_entries))
         return CSVSIMD_ERR_INVALID_ARG;
     if (table_slots < 64 || (table_slots & (table_slots - 1)) || ((uintptr_t)d_scratch & 15) || ((uintptr_t)d_entries & 7))
@@ -894,6 +922,7 @@ int csvsimd_column_frequency_device(csvsimd_ctx* ctx, const void* dbytes, const 
     }
     if (status->n_distinct > entries_cap) return CSVSIMD_ERR_TAPE_CAPACITY;  // status->n_distinct = the size needed
     return CSVSIMD_OK;
+    });
 }
 
 int csvsimd_column_search_device(csvsimd_ctx* ctx, const void* dbytes, uint64_t bytes_len, const void* dindex, uint64_t index_len,
@@ -1009,6 +1038,7 @@ struct EventBatch {
 
 int csvsimd_stage1_time_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len, void* dtape, uint64_t tape_cap,
                                void* d_result, void* hip_stream, int warmup, int iters, float* avg_ms) {
+    return csvsimd_guarded([&]() -> int {
     if (!ctx || !avg_ms || iters <= 0 || iters > 4096 || !d_result || !len) return CSVSIMD_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)hip_stream;
     int rc = csvsimd_ctx_reserve(ctx, len);
@@ -1098,6 +1128,7 @@ int csvsimd_stage1_time_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len,
     }
 #endif
     return CSVSIMD_OK;
+    });
 }
 
 const char* csvsimd_stage1_kernel_name(int emit, const csvsimd_dialect* dialect) {
@@ -1116,6 +1147,7 @@ uint32_t csvsimd_build_has_probes(void) {
 
 int csvsimd_hbm_probe_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len, void* dout, int write_div,
                              int blocks_per_cu, void* hip_stream, int warmup, int iters, float* avg_ms) {
+    return csvsimd_guarded([&]() -> int {
     if (!ctx || !dbuf || !avg_ms || iters <= 0 || iters > 4096 || ((uintptr_t)dbuf & 15)) return CSVSIMD_ERR_INVALID_ARG;
     if ((write_div != 0 && write_div != 4 && write_div != 25) || blocks_per_cu < 1 || blocks_per_cu > 8)
         return CSVSIMD_ERR_INVALID_ARG;
@@ -1139,6 +1171,7 @@ int csvsimd_hbm_probe_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len, v
     HIP_TRY(hipEventElapsedTime(&ms, eb.ev[0], eb.ev[1]));
     *avg_ms = ms / (float)iters;
     return CSVSIMD_OK;
+    });
 }
 
 }  // extern "C"

@@ -20,6 +20,7 @@
 #include <string>
 #include <vector>
 
+#include "abi_guard.h"
 #include "csvsimd.h"
 
 namespace {
@@ -73,6 +74,7 @@ struct csvsimd_comm {
 extern "C" {
 
 int csvsimd_comm_unique_id(uint8_t id[CSVSIMD_COMM_ID_BYTES]) {
+    return csvsimd_guarded([&]() -> int {
     static_assert(CSVSIMD_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size must match RCCL's");
     if (!id) return CSVSIMD_ERR_INVALID_ARG;
     RcclApi& api = rccl();
@@ -81,9 +83,11 @@ int csvsimd_comm_unique_id(uint8_t id[CSVSIMD_COMM_ID_BYTES]) {
     if (api.GetUniqueId(&u) != ncclSuccess) return CSVSIMD_ERR_RCCL;
     memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
     return CSVSIMD_OK;
+    });
 }
 
 int csvsimd_comm_create(const uint8_t id[CSVSIMD_COMM_ID_BYTES], int rank, int world, int device, csvsimd_comm** out) {
+    return csvsimd_guarded([&]() -> int {
     if (!id || !out || world < 1 || rank < 0 || rank >= world) return CSVSIMD_ERR_INVALID_ARG;
     *out = nullptr;
     RcclApi& api = rccl();
@@ -110,6 +114,7 @@ int csvsimd_comm_create(const uint8_t id[CSVSIMD_COMM_ID_BYTES], int rank, int w
     c->h_rec[1].error = 1;
     *out = c;
     return CSVSIMD_OK;
+    });
 }
 
 void csvsimd_comm_destroy(csvsimd_comm* c) {
@@ -137,6 +142,7 @@ void csvsimd_comm_destroy(csvsimd_comm* c) {
 int csvsimd_stage1_index_sharded(csvsimd_ctx* ctx, csvsimd_comm* c, const void* dbuf, uint64_t len, uint64_t base_off,
                                  uint32_t file_in_quote_in, void* dtape, uint64_t tape_cap,
                                  csvsimd_shard_result* result, csvsimd_stitch* stitch, void* hip_stream) {
+    return csvsimd_guarded([&]() -> int {
     if (!ctx || !c || !result || !stitch) return CSVSIMD_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)hip_stream;
     int local = csvsimd_ctx_reserve(ctx, len);  // may allocate: never inside the stream-ordered part
@@ -162,6 +168,7 @@ int csvsimd_stage1_index_sharded(csvsimd_ctx* ctx, csvsimd_comm* c, const void* 
     if (stitch->error || result->error) return CSVSIMD_ERR_INTERNAL;  // some rank's pass failed: no rank has a tape
     if (dtape && result->count > tape_cap) return CSVSIMD_ERR_TAPE_CAPACITY;
     return CSVSIMD_OK;
+    });
 }
 
 }  // extern "C"

@@ -39,7 +39,9 @@ extern "C" {
 #define CSVSIMD_ERR_NO_DEVICE (-13)
 #define CSVSIMD_ERR_INTERNAL (-14) /* in-kernel look-back spin bound hit (~1 s without progress of a
                                       predecessor tile: never seen; conceivable only if the GPU is
-                                      preempted for that long by another process — retry) */
+                                      preempted for that long by another process — retry); also a host-side
+                                      C++ exception (out of host memory, thread creation) caught at the ABI:
+                                      csvsimd_last_error() has the text */
 #define CSVSIMD_ERR_RCCL (-15)     /* librccl missing or a collective failed */
 
 const char* csvsimd_strerror(int code);
