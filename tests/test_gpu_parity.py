@@ -195,7 +195,7 @@ def test_speculative_scatter_guesses(ctx, torch_cuda, pkg, oracle):
     seq = [plain(), opens_at_end(), closes_at_start(), quoted_body(), plain(), opens_at_end(),
            quoted_body_entered_inside(), plain(), quoted_body(), opens_at_end(), closes_at_start(), plain()]
     for tail in (0, 1, 4097):
-        d = np.frombuffer(b"".join(seq) + rows(tail), dtype=np.uint8)
+        d = np.frombuffer(b"".join(seq) + rows(tail), dtype=np.uint8).copy()
         for inq in (0, 1):
             got, r = gpu_index(ctx, torch_cuda, d, in_quote_in=inq, base_off=3)
             want, q = oracle.scalar_index(d, base_off=3, in_quote_in=inq)
