@@ -21,6 +21,11 @@ truths.  On the default workload a second, untimed-for-`value` leg runs the QUOT
 (--skew 777 semantics: shards start inside rows, some inside quoted fields) so that the re-emit path is
 exercised and verified whenever this file runs with N > 1 ("q10_skew_check").
 
+Timing hygiene: every timed region is preceded by 25 ms of the same, untimed, load (an idle MI355X runs its first
+~10 ms of work through a power-management transient, see SETTLE_MS) in addition to the W warm-up steps; steps are
+enqueued two deep over alternating tape buffers (step i + 1 is enqueued before step i's record is read back and
+checked; all K records are checked inside the timed region, which is bracketed by barrier + synchronise).
+
 Rank 0 prints ONE JSON line.  value = whole-job GiB/s (all ranks' bytes / max-over-ranks time).
 roofline: HBM-bound, algorithmic bytes = 1 byte read per CSV byte scanned (SURVEY.md §8d);
 duration = the stage-1 kernel's average launch time from HIP events recorded on its own stream
