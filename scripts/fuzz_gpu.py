@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""dev tool: time-bounded differential fuzz of the stage-1 device entry point against the CPU oracle (test
+infrastructure, allowed here: scripts/ never ship).  Every case: random size (1 B .. 48 MiB, biased to tile and span
+boundaries), a random mixture of generators (uniform random bytes over the special alphabet, CSV-like rows, blocks that
+make the speculative scatter guess right or wrong with either entering state, dense runs), random misalignment,
+base offset, entering state and tape capacity.  The whole tape, the count, the leaving state and the two hypothesis
+counts must equal the oracle's.  usage: fuzz_gpu.py [seconds] [seed]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft
+
+pkg = graft.load_package()
+oracle = graft.load_oracle()
+ALPHABET = np.frombuffer(b',"\n\ra \\\x00\xff', dtype=np.uint8)
+
+
+def gen_random(rng, n):
+    w = np.ones(ALPHABET.size)
+    w[1] = rng.choice([0.0, 0.01, 0.1, 1.0, 4.0])
+    w[4] = rng.choice([1.0, 20.0, 200.0])
+    return ALPHABET[rng.choice(ALPHABET.size, size=n, p=w / w.sum())].astype(np.uint8)
+
+
+def gen_rows(rng, n):
+    width = int(rng.integers(1, 60))
+    cols = int(rng.integers(1, 40))
+    field = b"x" * width
+    q = rng.random() < 0.5
+    row = b",".join((b'"' + field[:-2] + b',"' if (q and i % 3 == 1 and width > 3) else field) for i in range(cols))
+    row += b"\r\n" if rng.random() < 0.3 else b"\n"
+    return np.frombuffer((row * (n // len(row) + 1))[:n], dtype=np.uint8).copy()
+
+
+def gen_quoted_body(rng, n):
+    """one long quoted field full of separators: the speculation's guess is wrong for whoever enters it outside"""
+    b = np.full(n, ord("y"), dtype=np.uint8)
+    step = int(rng.integers(2, 40))
+    b[::step] = rng.choice([0x2C, 0x0A, 0x0D])
+    if n > 2:
+        b[int(rng.integers(0, min(n, 64)))] = 0x22
+        b[n - 1 - int(rng.integers(0, min(n - 1, 64)))] = 0x22
+    return b
+
+
+def gen_dense(rng, n):
+    return np.full(n, rng.choice([0x2C, 0x0A, 0x22, 0x61]), dtype=np.uint8)
+
+
+GENS = [gen_random, gen_rows, gen_quoted_body, gen_dense]
+
+
+def make_case(rng):
+    T = pkg.tile_bytes()
+    kind = rng.integers(0, 4)
+    if kind == 0:
+        n = int(rng.integers(1, 4096))
+    elif kind == 1:
+        n = int(rng.integers(1, 20)) * (T // 8) + int(rng.integers(-70, 70))
+    elif kind == 2:
+        n = int(rng.integers(1, 12)) * T + int(rng.integers(-5000, 5000))
+    else:
+        n = int(rng.integers(1, 48 << 20))
+    n = max(n, 1)
+    parts, left = [], n
+    while left > 0:
+        m = left if rng.random() < 0.3 else int(rng.integers(1, left + 1))
+        if rng.random() < 0.5:
+            m = min(left, max(1, (m // T) * T + int(rng.integers(0, 3)) * (T // 8)))
+        parts.append(GENS[int(rng.integers(0, len(GENS)))](rng, m))
+        left -= m
+    return np.concatenate(parts)
+
+
+def main():
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+    rng = np.random.default_rng(seed)
+    ctx = pkg.Context(0)
+    t_end = time.time() + seconds
+    cases = bytes_total = 0
+    bad = []
+    while time.time() < t_end and not bad:
+        d = make_case(rng)
+        n = d.size
+        mis = int(rng.integers(0, 128))
+        inq = int(rng.integers(0, 2))
+        base = int(rng.integers(0, 1 << 40))
+        want, q = oracle.scalar_index(d, base_off=base, in_quote_in=inq)
+        cap_kind = rng.integers(0, 3)
+        cap = want.size + 3 if cap_kind == 0 else (n + 1 if cap_kind == 1 else int(rng.integers(0, want.size + 1)))
+        dbuf = torch.full((n + 256,), 0x2C, dtype=torch.uint8, device="cuda:0")
+        dbuf[mis: mis + n] = torch.from_numpy(d)
+        dtape = torch.full((cap + 8,), -1, dtype=torch.int64, device="cuda:0")
+        r = ctx.stage1_index_device(dbuf.data_ptr() + mis, n, base, inq, dtape.data_ptr(), cap, allow_overflow=True)
+        torch.cuda.synchronize()
+        k = min(r.count, cap)
+        got = dtape[:k].cpu().numpy().view(np.uint64)
+        p, c0, c1 = oracle.shard_descriptor(d)
+        ok = (r.count == want.size and r.in_quote_out == q and r.written == k and np.array_equal(got, want[:k])
+              and bool((dtape[k:] == -1).all()) and r.error == 0
+              and (r.quote_parity, r.count_enter_outside, r.count_enter_inside) == (p, c0, c1))
+        if not ok:
+            bad.append({"case": cases, "n": n, "mis": mis, "inq": inq, "cap": cap, "count": int(r.count),
+                        "want": int(want.size)})
+            np.save(os.path.join(ROOT, "gpurun_out", f"fuzz_fail_{seed}_{cases}.npy"), d)
+        cases += 1
+        bytes_total += n
+        del dbuf, dtape
+    print(json.dumps({"seconds": seconds, "seed": seed, "cases": cases, "GiB": round(bytes_total / 2**30, 2), "bad": bad}))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
