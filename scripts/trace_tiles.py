@@ -70,3 +70,21 @@ sizes = np.bincount([len(v) for v in per_cu.values()])
 print("distinct (xcc, se/sh/cu) ids:", len(per_cu), " workgroups per id histogram:", sizes.tolist())
 pairs = [sorted(v) for v in per_cu.values() if len(v) == 2][:6]
 print("example co-resident workgroup pairs (blockIdx):", pairs)
+# the drain in detail: the workgroups that finish last — every stamp of their last two tiles
+last = np.argsort(us[:, 5])[-6:]
+print("the six tiles whose emit ends last:  tile  wg  pos | ticket counted  A  resolved  B  emit_end | same workgroup's previous tile: resolved emit_end")
+by_wg = {}
+for i in order:
+    by_wg.setdefault(int(blk[i]), []).append(int(i))
+for i in last:
+    seq = by_wg[int(blk[i])]
+    k = seq.index(int(i))
+    prev = seq[k - 1] if k > 0 else None
+    extra = f"{us[prev, 3]:8.1f} {us[prev, 5]:8.1f}" if prev is not None else ""
+    print(f"   {int(i):6d} {int(blk[i]):4d} {int(pos[i]):3d} | " + " ".join(f"{x:8.1f}" for x in us[i, :6]) + " | " + extra)
+cend = us[:, 1].max()
+late = us[:, 5] > cend
+print(f"after the last count phase ended ({cend:.1f} us): {int(late.sum())} tiles ({late.sum() * T / 2**20:.0f} MiB of input) still to emit, "
+      f"done at {us[:, 5].max():.1f} us")
+b = np.histogram(us[late, 5], bins=np.arange(cend, end + 5, 5))[0]
+print("tiles finishing per 5-us bucket after that:", b.tolist())
