@@ -26,6 +26,8 @@ for spec in sys.argv[2].split(","):
     torch.cuda.synchronize()
     ms = C.c_float()
     best = 1e9
+    # settle: an idle GPU runs its first ~10 ms of load through a power-management transient (DESIGN.md §4)
+    L.csvsimd_stage1_time_device(ctx, vp(dbuf.data_ptr()), u64(n), vp(dtape.data_ptr()), u64(cap), vp(dres.data_ptr()), None, 0, max(8, int(0.03 / (n / 4.5e12))), C.byref(ms))
     for _ in range(3):
         rc = L.csvsimd_stage1_time_device(ctx, vp(dbuf.data_ptr()), u64(n), vp(dtape.data_ptr()), u64(cap), vp(dres.data_ptr()), None, 2, 10, C.byref(ms))
         assert rc == 0, rc
