@@ -234,7 +234,7 @@ def true_entering_state(oracle, sb):
     return int(np.count_nonzero(part == 0x22)) & 1
 
 
-def verify_rank(oracle, sb, st_in_quote_in, count, tape_index_base, total_entries, in_quote_final):
+def verify_rank(oracle, sb, st_in_quote_in, count, tape_index_base, total_entries, in_quote_final, reemit=0):
     """Everything one rank can check about its own shard.  Returns a dict of booleans + facts."""
     t = sb.dtape[:count]
     truth_in = true_entering_state(oracle, sb)
@@ -249,7 +249,7 @@ def verify_rank(oracle, sb, st_in_quote_in, count, tape_index_base, total_entrie
         res["closed_form"] = bool(closed_form_compare(sb, count))
     facts = {"rank": sb.rank, "lo": sb.lo, "hi": sb.hi, "count": int(count), "ref_count": int(ref_count),
              "state_in": truth_in, "state_out": int(state_out), "base": int(tape_index_base),
-             "total": int(total_entries), "final": int(in_quote_final), "reemit": int(st_in_quote_in)}
+             "total": int(total_entries), "final": int(in_quote_final), "reemit": int(reemit)}
     return res, facts
 
 
@@ -264,7 +264,7 @@ def verify_job(all_facts):
     ok = ok and all(f["total"] == base and f["final"] == state for f in all_facts)
     for a, b in zip(all_facts, all_facts[1:]):
         ok = ok and a["hi"] == b["lo"]
-    return ok, sum(f["reemit"] for f in all_facts), base
+    return ok, sum(f["reemit"] for f in all_facts), base, sum(f["state_in"] for f in all_facts)
 
 
 def mid_row_cuts(oracle, pkg, workload, shard_bytes, world):
@@ -507,6 +507,13 @@ def run_sharded(pkg, sb, device, dist_on, rehearsal, comm, steps, warmup):
     depth = PIPELINE_DEPTH if os.environ.get("CSVSIMD_BENCH_PIPELINE", "1") != "0" and comm is None else 1
     stepper = (sharded.ShardedStep(device, gather_via_host=rehearsal, depth=depth)
                if (dist_on and comm is None) else None)
+    # rank 0 knows how the file starts; every other rank lets the kernel choose the entering state its first tile speaks
+    # for (CSVSIMD_ENTER_GUESS) — only a rank that chose wrong re-emits.  CSVSIMD_BENCH_NO_GUESS=1: speculate "outside"
+    # everywhere, as round 1 did (then every rank that really starts inside a string re-emits).
+    guess = os.environ.get("CSVSIMD_BENCH_NO_GUESS") != "1"
+    first_state = pkg.ENTER_GUESS if (guess and sb.rank > 0) else 0
+    state["first_pass"] = "rank 0: entering state known; ranks > 0: " + ("the kernel's guess from its first tile"
+                                                                        if guess else "speculated 'outside'")
     inflight = []          # slots enqueued and not yet collected, oldest first
     counter = [0]
 
@@ -515,7 +522,8 @@ def run_sharded(pkg, sb, device, dist_on, rehearsal, comm, steps, warmup):
             d_res = stepper.slots[slot].d_result
             sb.use_slot(slot)
             tape = sb.dtape   # bound now: the re-emit must hit the same buffer as the speculative pass
-            stepper.enqueue(lambda inq: sb.launch(inq, d_res), lambda p: sb.reemit(p, d_res), slot=slot)
+            stepper.enqueue(lambda inq: sb.launch(inq, d_res), lambda p: sb.reemit(p, d_res), slot=slot,
+                            first_state=first_state)
             assert sb.dtape is tape
         else:
             sb.enqueue_pass(0, slot)
@@ -526,7 +534,7 @@ def run_sharded(pkg, sb, device, dist_on, rehearsal, comm, steps, warmup):
             sb.check(final)
             assert final.count == st.count
             state.update(count=st.count, inq=st.in_quote_in, base=st.tape_index_base, total=st.total_entries,
-                         final=st.in_quote_final, slot=slot)
+                         final=st.in_quote_final, slot=slot, reemit=st.reemit)
         else:
             w = sb.collect_pass(slot)
             state.update(count=int(w[0]), inq=0, base=1, total=int(w[0]) + 1, final=(int(w[3]) >> 32) & 1, slot=slot)
@@ -541,7 +549,7 @@ def run_sharded(pkg, sb, device, dist_on, rehearsal, comm, steps, warmup):
                                        sb.stream())
             sb.check(r)
             state.update(count=st.count, inq=st.in_quote_in, base=st.tape_index_base, total=st.total_entries,
-                         final=st.in_quote_final, slot=0)
+                         final=st.in_quote_final, slot=0, reemit=st.reemit)
             return
         slot = counter[0] % depth
         counter[0] += 1
@@ -568,19 +576,21 @@ def verify_everything(oracle, sb, state, dist_on, rank, world):
         for r in range(world):
             if r == rank:
                 res, facts = verify_rank(oracle, sb, state["inq"], state["count"], state["base"], state["total"],
-                                         state["final"])
+                                         state["final"], state.get("reemit", 0))
                 torch.cuda.synchronize()
             dist.barrier()
     else:
-        res, facts = verify_rank(oracle, sb, state["inq"], state["count"], state["base"], state["total"], state["final"])
+        res, facts = verify_rank(oracle, sb, state["inq"], state["count"], state["base"], state["total"], state["final"],
+                                 state.get("reemit", 0))
     gathered = [None] * world
     if dist_on:
         dist.all_gather_object(gathered, (res, facts))
     else:
         gathered = [(res, facts)]
-    job_ok, reemits, total = verify_job([g[1] for g in gathered])
+    job_ok, reemits, total, inside = verify_job([g[1] for g in gathered])
     tape_ok = all(all(g[0].values()) for g in gathered)
-    out = {"tape": bool(tape_ok), "stitch": bool(job_ok), "reemits": int(reemits), "total_entries": int(total),
+    out = {"tape": bool(tape_ok), "stitch": bool(job_ok), "reemits": int(reemits),
+           "ranks_entered_inside_a_string": int(inside), "total_entries": int(total),
            "how": "every rank: whole tape shard == torch restatement of the definition on the same bytes"
                   + ("" if sb.q else " == closed form")
                   + f"; {WINDOW_ENTRIES} entries either side of each shard boundary + checksum == CPU oracle; "
@@ -709,6 +719,7 @@ def main():
                    "bytes_per_gpu": sb.n, "total_bytes": total_bytes, "tape_entries": int(state["total"]),
                    "skew": args.skew,
                    "steps_in_flight": state["pipeline_depth"],   # 2: step i+1 enqueued before step i's record is read
+                   "first_pass": state["first_pass"],
                    "parallelism": f"chunk-sharded x{world}, one all-gather of shard descriptors, stitch + "
                                   "conditional re-emit on the device"
                                   + (" (native RCCL from the C ABI)" if comm is not None else "")
@@ -730,8 +741,9 @@ def main():
         vq = verify_everything(oracle, sbq, stq, dist_on, rank, world)
         failed = failed or not (vq["tape"] and vq["stitch"])
         out["q10_skew_check"] = {"workload": "64x31_q10, interior cuts mid-row: odd ones inside a quoted field (that rank "
-                                             "must re-emit), even ones at +777 outside a string",
-                                 "cuts": cuts,
+                                             "really starts inside a string: it re-emits unless its first pass chose "
+                                             "that state itself), even ones at +777 outside a string",
+                                 "cuts": cuts, "first_pass": stq["first_pass"],
                                  "ms_per_step": round(dtq / k * 1e3, 4), "steps": k,
                                  "GiB/s": round(sbq.total * k / dtq / 2**30, 2), "verified": vq}
         if rank == 0 and world == 1:

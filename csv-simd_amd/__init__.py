@@ -48,8 +48,14 @@ class ShardResult(C.Structure):
         ("error", C.c_uint32),
         ("escape_out", C.c_uint32),
         ("written", C.c_uint64),
-        ("reserved1", C.c_uint64 * 2),
+        ("in_quote_in_used", C.c_uint32),   # the entering state the pass ran with (the kernel's own choice with ENTER_GUESS)
+        ("reserved0", C.c_uint32),
+        ("reserved1", C.c_uint64),
     ]
+
+
+# in_quote_in of the device entry points (include/csvsimd.h)
+ENTER_OUTSIDE, ENTER_INSIDE, ENTER_GUESS = 0, 1, 2
 
 
 class Dialect(C.Structure):
@@ -82,7 +88,7 @@ class Stitch(C.Structure):
         ("tape_index_base", C.c_uint64),
         ("total_entries", C.c_uint64),
         ("error", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("reemit", C.c_uint32),   # this shard's pass ran with another entering state than the true one
     ]
 
 

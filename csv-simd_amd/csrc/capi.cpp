@@ -320,7 +320,7 @@ static int stage1_async_impl(csvsimd_ctx* ctx, const csvsimd_dialect* dialect, c
     // a shard's entry count must fit the 39-bit field of a look-back word (288 GB of HBM is 2^38.1 bytes)
     if (len >= (1ull << 39)) return CSVSIMD_ERR_INVALID_ARG;
     if (((uintptr_t)dtape & 7) || ((uintptr_t)d_result & 15)) return CSVSIMD_ERR_INVALID_ARG;
-    if (dialect_check(dialect) != CSVSIMD_OK) return CSVSIMD_ERR_INVALID_ARG;
+    if (dialect_check(dialect) != CSVSIMD_OK || in_quote_in > CSVSIMD_ENTER_GUESS) return CSVSIMD_ERR_INVALID_ARG;
     if (csvsimd::Stage1Launch::scratch_bytes_for(len) > ctx->scratch_bytes) {
         const int rc = csvsimd_ctx_reserve(ctx, len);  // allocates + synchronises: not capturable
         if (rc != CSVSIMD_OK) return rc;
@@ -329,7 +329,7 @@ static int stage1_async_impl(csvsimd_ctx* ctx, const csvsimd_dialect* dialect, c
     L.dbuf = dbuf;
     L.len = len;
     L.base_off = base_off;
-    L.in_quote_in = in_quote_in ? 1u : 0u;
+    L.in_quote_in = in_quote_in;  // 0, 1 or CSVSIMD_ENTER_GUESS
     L.dtape = dtape;
     L.tape_cap = tape_cap;
     L.d_result = (csvsimd_shard_result*)d_result;
@@ -616,6 +616,7 @@ int csvsimd_stitch_shards(const csvsimd_shard_result* results, uint32_t n_shards
             out->in_quote_in = state;
             out->count = cnt;
             out->tape_index_base = idx;
+            out->reemit = (results[i].in_quote_in_used & 1u) != state ? 1u : 0u;
         }
         idx += cnt;
         state ^= results[i].quote_parity & 1u;
@@ -624,7 +625,6 @@ int csvsimd_stitch_shards(const csvsimd_shard_result* results, uint32_t n_shards
     out->in_quote_final = state;
     out->total_entries = idx;
     out->error = err ? 1u : 0u;
-    out->reserved = 0;
     return CSVSIMD_OK;
 }
 

@@ -130,10 +130,10 @@ void csvsimd_comm_destroy(csvsimd_comm* c) {
 }
 
 // One sharded step for this rank, entirely stream-ordered on the device:
-//   speculative pass (entered outside a string) -> ONE all-gather of the 64-byte result records over
-//   xGMI -> stitch kernel (one lane: this rank's entering state, tape index base, totals, in device
-//   memory) -> re-emit launch that reads the entering state from device memory and returns at once
-//   unless it is 1 -> the final record and the stitch travel to the host; ONE synchronisation at the
+//   speculative pass (entering state: known on rank 0, the kernel's own guess elsewhere) -> ONE all-gather of the
+//   64-byte result records over xGMI -> stitch kernel (one lane: this rank's true entering state, tape index base,
+//   totals, "re-emit" flag, in device memory) -> re-emit launch that reads state and flag from device memory and
+//   returns at once unless the flag is set -> the final record and the stitch travel to the host; ONE synchronisation at the
 //   very end.  Nothing in between waits for the host, so the whole step can overlap the next one's
 //   speculative pass or be captured into a hipGraph.
 // Every rank reaches the collective whatever happens locally: arguments are checked and the scratch
@@ -147,7 +147,11 @@ int csvsimd_stage1_index_sharded(csvsimd_ctx* ctx, csvsimd_comm* c, const void* 
     hipStream_t st = (hipStream_t)hip_stream;
     int local = csvsimd_ctx_reserve(ctx, len);  // may allocate: never inside the stream-ordered part
     if (local == CSVSIMD_OK)
-        local = csvsimd_stage1_index_device_async(ctx, dbuf, len, base_off, 0, dtape, tape_cap, c->d_mine, st);
+        // rank 0 knows how the file starts; every other rank lets the kernel choose the entering state its first
+        // tile speaks for (CSVSIMD_ENTER_GUESS) — the stitch tells who chose wrong, and only those re-emit
+        local = csvsimd_stage1_index_device_async(ctx, dbuf, len, base_off,
+                                                  c->rank == 0 ? (file_in_quote_in ? 1u : 0u) : CSVSIMD_ENTER_GUESS,
+                                                  dtape, tape_cap, c->d_mine, st);
     if (local != CSVSIMD_OK &&
         hipMemcpyAsync(c->d_mine, &c->h_rec[1], sizeof(csvsimd_shard_result), hipMemcpyHostToDevice, st) != hipSuccess)
         return CSVSIMD_ERR_HIP;  // cannot even tell the peers: nothing more to be done here

@@ -653,6 +653,7 @@ struct Control {
     u32 err;       // look-back spin bound hit (atomic or)
     u32 hwm;       // descriptor words possibly dirty since the last wrap of the epoch
     u32 probe_ticket, probe_done;  // csvsimd_hbm_probe_device's own pair
+    u32 guess;     // CSVSIMD_ENTER_GUESS launches: 0 = not decided yet, 2 | s = the workgroup of tile 0 chose state s
 };
 static_assert(sizeof(Control) <= CSVSIMD_SCRATCH_CTL_BYTES, "control block must fit its slot");
 
@@ -823,6 +824,9 @@ __device__ __forceinline__ void emit_span(const KernelArgs& args, const RoundMas
 // The end of a launch (wave 0 of every workgroup): count this workgroup done; the workgroup whose add completes the
 // count writes the result record from the last tile's inclusive word and leaves the control block ready for the next
 // launch.
+struct Control;
+__device__ __forceinline__ u32 wait_for_guess(Control* ctl, u32& err);
+constexpr u32 kEnterGuessFwd = CSVSIMD_ENTER_GUESS;
 template <int DIALECT, bool NO_LOOKBACK>
 __device__ __forceinline__ void finish_launch(const KernelArgs& args, u32 epoch, u32 inq_in, u64 wg_tot, u32 err, u32 lane) {
     Control* const ctl = args.ctl;
@@ -838,7 +842,11 @@ __device__ __forceinline__ void finish_launch(const KernelArgs& args, u32 epoch,
     if ((old_hi >> 16) != gridDim.x - 1u) return;
 
     const u64 total = ((((u64)old_hi << 32) | old_lo) & ((1ull << 48) - 1ull)) + wg_tot;
-    u32 state_out = inq_in, e = 0;
+    u32 e = 0;
+    // CSVSIMD_ENTER_GUESS and this workgroup never resolved a tile: the choice of tile 0's workgroup is there by now
+    // (every workgroup has finished); an empty shard has no tile 0 and is "entered outside"
+    if (inq_in == kEnterGuessFwd) inq_in = args.num_tiles ? wait_for_guess(ctl, e) : 0u;
+    u32 state_out = inq_in;
     u64 count = 0;
     if (args.num_tiles > 0 && !NO_LOOKBACK) {
         // published by whichever workgroup resolved the last tile, before it counted itself done
@@ -875,12 +883,14 @@ __device__ __forceinline__ void finish_launch(const KernelArgs& args, u32 epoch,
         r->error = e;
         r->escape_out = esc_out;
         r->written = count < args.tape_cap ? count : args.tape_cap;
-        r->reserved1[0] = 0;
-        r->reserved1[1] = 0;
+        r->in_quote_in_used = inq_in;
+        r->reserved0 = 0;
+        r->reserved1 = 0;
         // ready for the next launch (made visible by the end-of-kernel release)
         ctl->ticket = 0;
         ctl->done_tot = 0;
         ctl->err = 0;
+        ctl->guess = 0;
         ctl->hwm = hwm;
         ctl->epoch = next_epoch;
     }
@@ -952,6 +962,22 @@ __device__ __forceinline__ void wg_barrier() {
 #else
 #define CSVSIMD_LAUNCH_BOUNDS __launch_bounds__(kThreads)
 #endif
+constexpr u32 kEnterGuess = CSVSIMD_ENTER_GUESS;
+constexpr u32 kStitchReemitWord = 9;  // csvsimd_stitch::reemit as a u32 index
+static_assert(offsetof(csvsimd_stitch, reemit) == 4 * kStitchReemitWord && offsetof(csvsimd_stitch, in_quote_in) == 0,
+              "the re-emit launch reads these two words");
+
+// CSVSIMD_ENTER_GUESS: the choice made by the workgroup that counted tile 0 (Control::guess), once it is there
+__device__ __forceinline__ u32 wait_for_guess(Control* ctl, u32& err) {
+    for (u32 spins = 0;; ++spins) {
+        const u32 g = (u32)__builtin_amdgcn_readfirstlane(
+            (int)__hip_atomic_load(&ctl->guess, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (g) return g & 1u;
+        if (spins > kSpinLimit) { err = 1; return 0u; }
+        __builtin_amdgcn_s_sleep(16);
+    }
+}
+
 template <bool EMIT, int DBG = 0, int DIALECT = 0>
 __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
     __shared__ u32 s_tile;
@@ -971,12 +997,14 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
 
     // sharded re-emit: the true entering state sits in device memory (written by the stitch kernel
     // earlier on this stream); a shard that really is entered outside a string has nothing to redo
-    u32 inq_in = args.in_quote_in;
+    u32 inq_in = args.in_quote_in;  // 0 / 1, or kEnterGuess until the choice of tile 0's workgroup is known
     if (args.state_ptr) {
-        const u32 st = (u32)__builtin_amdgcn_readfirstlane(
-            (int)__hip_atomic_load(args.state_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        if (st == 0u) return;
-        inq_in = 1u;
+        // {in_quote_in, ..., reemit}: csvsimd_stitch as the stitch kernel left it earlier on this stream
+        const u32 redo = (u32)__builtin_amdgcn_readfirstlane(
+            (int)__hip_atomic_load(args.state_ptr + kStitchReemitWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (redo == 0u) return;
+        inq_in = (u32)__builtin_amdgcn_readfirstlane(
+                     (int)__hip_atomic_load(args.state_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 1u;
     }
     // requested now, consumed after the first count phase (the load's latency hides behind it)
     const u32 epoch_v = __hip_atomic_load(&args.ctl->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1137,6 +1165,15 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
         // Wave 0 publishes this tile's aggregate and REQUESTS the look-back window of the held tile; then every wave
         // scatters its span of the held tile speculatively (see scatter_span_spec) — the 3-5 us the polls take behind the
         // CU's streaming loads used to be seven idle waves at barrier B — and only then does wave 0 consume the window.
+        if (inq_in == kEnterGuess && have_cur && tile == 0u) {
+            // this workgroup counted the first tile of a shard whose entering state nobody knows: it chooses the state
+            // under which that tile has more entries and makes the choice known before anything of tile 0 is published
+            // (inq_in itself stays what the launch passed: a loop-carried copy costs the default kernel 4 spilled VGPRs;
+            // whoever needs the state reads the control word)
+            if (w == 0 && lane == 0)
+                __hip_atomic_store(&args.ctl->guess, 2u | (agg.b > agg.a ? 1u : 0u), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (w == 0) {
             if (have_cur) {
                 if (!(DBG & 4) && lane == 0) publish_aggregate(args.desc, tile, epoch, agg);
@@ -1158,9 +1195,11 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
             u64 base = 0;
             if (!(DBG & 4)) {
                 u64 pre[4];
+                // CSVSIMD_ENTER_GUESS: the choice was published before tile 0's aggregate, a tile-time ago at least
+                const u32 inq_eff = inq_in == kEnterGuess ? wait_for_guess(args.ctl, err) : inq_in;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 lookback_fetch(s_stage_b[0], held_tile, lane, pre);
-                resolve<true>(args.desc, held_tile, epoch, held_agg, inq_in, lane, pin, base, err, pre);
+                resolve<true>(args.desc, held_tile, epoch, held_agg, inq_eff, lane, pin, base, err, pre);
             }
             if (lane == 0) {
                 s_pin = pin;
@@ -1444,6 +1483,7 @@ __global__ void stitch_kernel(const csvsimd_shard_result* __restrict__ results, 
             o.in_quote_in = state;
             o.count = cnt;
             o.tape_index_base = idx;
+            o.reemit = (results[i].in_quote_in_used & 1u) != state ? 1u : 0u;
         }
         idx += cnt;
         state ^= results[i].quote_parity & 1u;
@@ -1473,7 +1513,7 @@ hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream) {
     a.lo = (u64)(addr & 15);
     a.hi = a.lo + L.len;
     a.base_off = L.base_off;
-    a.in_quote_in = L.in_quote_in ? 1u : 0u;
+    a.in_quote_in = L.in_quote_in <= CSVSIMD_ENTER_GUESS ? L.in_quote_in : 1u;  // 0, 1 or CSVSIMD_ENTER_GUESS
     a.num_tiles = (u32)((a.hi + kTileBytes - 1) / kTileBytes);
     if (L.len == 0) a.num_tiles = 0;
     a.tape = (u64*)L.dtape;

@@ -47,12 +47,13 @@ def result_from_words(h) -> ShardResult:
     r.error = h[4] & 0xFFFFFFFF
     r.escape_out = (h[4] >> 32) & 0xFFFFFFFF
     r.written = h[5]
+    r.in_quote_in_used = h[6] & 0xFFFFFFFF
     return r
 
 
 def words_from_result(r: ShardResult) -> List[int]:
     return [r.count, r.count_enter_outside, r.count_enter_inside, r.quote_parity | (r.in_quote_out << 32),
-            r.error | (r.escape_out << 32), r.written, 0, 0]
+            r.error | (r.escape_out << 32), r.written, r.in_quote_in_used, 0]
 
 
 STITCH_WORDS = 8  # csvsimd_stitch as int64 words (5 used: in_quote_in | in_quote_final << 32, count, base, total,
@@ -66,6 +67,7 @@ def stitch_from_words(h) -> Stitch:
     st.in_quote_final = (h[0] >> 32) & 0xFFFFFFFF
     st.count, st.tape_index_base, st.total_entries = h[1], h[2], h[3]
     st.error = h[4] & 0xFFFFFFFF
+    st.reemit = (h[4] >> 32) & 0xFFFFFFFF
     return st
 
 
@@ -91,7 +93,7 @@ class ShardedStep:
     """Buffers of one rank's sharded step, allocated once: the step itself allocates nothing and never
     waits for the host until its single copy-out at the end.
 
-        launch(0)                      speculative stage-1 pass, record -> d_result       (caller's C-ABI call)
+        launch(first_state)            speculative stage-1 pass, record -> d_result       (caller's C-ABI call)
         all_gather_into_tensor         ONE collective, device to device (RCCL over xGMI)
         stitch_shards_device_async     one-lane kernel: entering state / tape base / totals, on the device
         reemit(d_stitch)               stage-1 launch that reads its entering state from device memory and
@@ -126,10 +128,10 @@ class ShardedStep:
         results = [result_from_words(host[8 * i: 8 * i + 8]) for i in range(self.world)]
         st = stitch_shards(results, self.rank, file_in_quote_in)
         sl.d_stitch.copy_(torch.tensor([st.in_quote_in | (st.in_quote_final << 32), st.count, st.tape_index_base,
-                                        st.total_entries, st.error, 0, 0, 0], dtype=torch.int64))
+                                        st.total_entries, st.error | (st.reemit << 32), 0, 0, 0], dtype=torch.int64))
 
     def enqueue(self, launch: Callable[[int], None], reemit: Callable[[int], None], file_in_quote_in: int = 0,
-                rehearsal: bool = False, slot: int = 0) -> None:
+                rehearsal: bool = False, slot: int = 0, first_state: int = 0) -> None:
         """Everything of a step except waiting for it.  launch(0) must enqueue the speculative pass with its record
         going to self.slots[slot].d_result; reemit(d_stitch_ptr) must enqueue csvsimd_stage1_reemit_device_async
         into the same tape / record."""
@@ -139,7 +141,7 @@ class ShardedStep:
             raise RuntimeError("ShardedStep: slot enqueued again before it was collected")
         sl.err = None
         try:
-            launch(0)
+            launch(first_state)   # 0 = speculate "entered outside"; ENTER_GUESS = the kernel chooses from its first tile
         except Exception as e:  # still join the collective: the peers are about to block in it
             sl.err = e
             sl.d_result.zero_()
@@ -183,25 +185,26 @@ class ShardedStep:
                            for i in range(self.world)]
 
     def run(self, launch: Callable[[int], None], reemit: Callable[[int], None], file_in_quote_in: int = 0,
-            rehearsal: bool = False) -> Tuple[Stitch, ShardResult, List[ShardResult]]:
+            rehearsal: bool = False, first_state: int = 0) -> Tuple[Stitch, ShardResult, List[ShardResult]]:
         """One whole step in slot 0: enqueue, then collect."""
-        self.enqueue(launch, reemit, file_in_quote_in, rehearsal, 0)
+        self.enqueue(launch, reemit, file_in_quote_in, rehearsal, 0, first_state)
         return self.collect(0)
 
 
 def index_sharded(launch: Callable[[int], None], d_result: torch.Tensor, group=None,
-                  file_in_quote_in: int = 0) -> Tuple[Stitch, ShardResult, bool]:
+                  file_in_quote_in: int = 0, first_state: int = 0) -> Tuple[Stitch, ShardResult, bool]:
     """One sharded stage-1 step with the stitch on the HOST (kept for callers without a device-side
     re-emit, and as the arithmetic the gloo tests compare the device stitch with):
-    launch(0) -> ONE all-gather of the result records -> copy to the host -> csvsimd_stitch_shards ->
-    launch(1) only if this rank turns out to start inside a quoted string.
+    launch(first_state) -> ONE all-gather of the result records -> copy to the host -> csvsimd_stitch_shards ->
+    launch(true state) only if the first pass ran with another entering state than the true one
+    (first_state: 0 = speculate "outside", ENTER_GUESS = let the kernel choose from the shard's first tile).
     Returns (stitch, final result of this rank, re_emitted).  Every rank joins the collective even if its
     own launch raises."""
     rank = dist.get_rank(group)
     world = dist.get_world_size(group)
     err = None
     try:
-        launch(0)
+        launch(first_state)
     except Exception as e:
         err = e
         d_result.zero_()
@@ -216,8 +219,8 @@ def index_sharded(launch: Callable[[int], None], d_result: torch.Tensor, group=N
         if r.error:
             raise RuntimeError(f"stage 1 reported an internal error on rank {i}")
     st = stitch_shards(results, rank, file_in_quote_in)
-    if st.in_quote_in:
-        launch(1)
+    if st.reemit:
+        launch(st.in_quote_in)
         final = result_from_words(d_result.cpu().tolist())
         if final.error:
             raise RuntimeError("stage 1 reported an internal error on the re-emit pass")

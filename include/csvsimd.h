@@ -72,8 +72,22 @@ typedef struct csvsimd_shard_result {
     uint32_t error;               /* 0, or CSVSIMD_ERR_INTERNAL's in-kernel flag              */
     uint32_t escape_out;          /* escape dialects only: the byte after the shard is escaped */
     uint64_t written;             /* min(count, tape_cap): entries actually stored            */
-    uint64_t reserved1[2];
+    uint32_t in_quote_in_used;    /* the entering state this pass ran with: the one passed, or — with
+                                     CSVSIMD_ENTER_GUESS — the one the kernel chose itself       */
+    uint32_t reserved0;
+    uint64_t reserved1;
 } csvsimd_shard_result;
+
+/* in_quote_in of the device entry points: 0 = the shard starts outside a quoted string, 1 = inside one,
+ * CSVSIMD_ENTER_GUESS = unknown (a shard cut out of the middle of a file, README.md:24 "splitting work without first
+ * knowing record breaks"): the kernel indexes the shard under the entering state for which its FIRST tile (256 KiB)
+ * has more entries — read with the wrong quote parity, text outside strings looks quoted and nearly every separator
+ * disappears — and reports the choice in in_quote_in_used.  `count`, `in_quote_out` and the tape are those of that
+ * state; the two hypothesis counts and quote_parity are state independent as always.  A wrong guess is found by the
+ * stitch (csvsimd_stitch.reemit) and costs the re-emit launch, exactly like a wrong in_quote_in = 0 speculation. */
+#define CSVSIMD_ENTER_OUTSIDE 0u
+#define CSVSIMD_ENTER_INSIDE 1u
+#define CSVSIMD_ENTER_GUESS 2u
 
 /* ---- stage 1, device-resident (the timed path) ---------------------------------------------
  * Replaces the hot loop of reader::read (src/reader.rs:229-290) = SimdInput::structure
@@ -144,29 +158,32 @@ int csvsimd_stage1_index_dialect(csvsimd_ctx* ctx, const csvsimd_dialect* dialec
 /* ---- multi-GPU stitch (host arithmetic; the exchange itself is one all-gather of these
  * descriptors over RCCL, done by the caller's communicator) -----------------------------------
  * New relative to the reference (single-threaded; README.md:24 lists it as a TODO).  Given the
- * per-shard results of a speculative pass (in_quote_in = 0) in rank order, computes for shard
- * `rank` its true entering state and the global tape index of its first entry (sentinel
- * included), plus the whole-file totals. */
+ * per-shard results of a first pass in rank order — each run with in_quote_in = 0 (speculation), 1, or
+ * CSVSIMD_ENTER_GUESS (the kernel's own choice, reported in in_quote_in_used) — computes for shard
+ * `rank` its true entering state, whether that differs from the state its pass ran with (reemit), and the
+ * global tape index of its first entry (sentinel included), plus the whole-file totals. */
 typedef struct csvsimd_stitch {
-    uint32_t in_quote_in;      /* entering state of this shard (first field: the re-emit launch reads it) */
+    uint32_t in_quote_in;      /* TRUE entering state of this shard (the re-emit launch reads it) */
     uint32_t in_quote_final;   /* state after the last shard                            */
     uint64_t count;            /* this shard's entry count under its true entering state */
     uint64_t tape_index_base;  /* global index of this shard's first entry (>= 1)       */
     uint64_t total_entries;    /* whole file, sentinel included                         */
     uint32_t error;            /* 1 if any shard's record carried its error flag        */
-    uint32_t reserved;
+    uint32_t reemit;           /* 1 if this shard's pass ran with another entering state than the true one
+                                  (results[rank].in_quote_in_used != in_quote_in): its tape must be re-emitted */
 } csvsimd_stitch;
 int csvsimd_stitch_shards(const csvsimd_shard_result* results, uint32_t n_shards, uint32_t rank,
                           uint32_t file_in_quote_in, csvsimd_stitch* out);
 /* The same arithmetic as a one-lane kernel on hip_stream: d_results = n_shards records in DEVICE memory
  * (the all-gather's receive buffer), d_stitch = DEVICE csvsimd_stitch (8-byte aligned).  With
  * csvsimd_stage1_reemit_device_async below the sharded step never waits for the host:
- *     speculative csvsimd_stage1_index_device_async(in_quote_in = 0)  ->  all-gather of the records
+ *     first csvsimd_stage1_index_device_async (rank 0: the file's entering state; other ranks:
+ *     CSVSIMD_ENTER_GUESS, or 0 to speculate)  ->  all-gather of the records
  *     ->  csvsimd_stitch_shards_device_async  ->  csvsimd_stage1_reemit_device_async
  * csvsimd_stage1_reemit_device_async is csvsimd_stage1_index_device_async whose in_quote_in is read on the
- * device from d_stitch->in_quote_in when the kernel starts: if it is 0 the launch returns at once and
- * leaves tape and d_result exactly as the speculative pass wrote them (which is then final); if it is 1
- * the shard is indexed again, for real, as "entered inside a quoted string" (README.md:24 of the
+ * device from d_stitch when the kernel starts: if d_stitch->reemit is 0 the launch returns at once and
+ * leaves tape and d_result exactly as the first pass wrote them (which is then final); if it is 1
+ * the shard is indexed again, for real, with d_stitch->in_quote_in (README.md:24 of the
  * reference: "requires toggling interpretation if/when start in quoted text"). */
 int csvsimd_stitch_shards_device_async(const void* d_results, uint32_t n_shards, uint32_t rank,
                                        uint32_t file_in_quote_in, void* d_stitch, void* hip_stream);
@@ -177,9 +194,9 @@ int csvsimd_stage1_reemit_device_async(csvsimd_ctx* ctx, const void* dbuf, uint6
 /* Native form of the same step for hosts without torch.distributed: one communicator per rank
  * (one process per GPU).  Rank 0 obtains an id (ncclGetUniqueId) and hands its 128 bytes to the
  * other ranks by whatever channel the application has; every rank then creates its communicator
- * (ncclCommInitRank).  csvsimd_stage1_index_sharded = speculative pass (entered outside a string)
- * -> ONE ncclAllGather of the 64-byte result records over xGMI -> stitch on the device -> re-emit
- * launch that does nothing unless this shard starts inside a quoted string -> the final record and the
+ * (ncclCommInitRank).  csvsimd_stage1_index_sharded = first pass (rank 0: file_in_quote_in; other ranks:
+ * CSVSIMD_ENTER_GUESS) -> ONE ncclAllGather of the 64-byte result records over xGMI -> stitch on the device -> re-emit
+ * launch that does nothing unless this rank's pass ran with the wrong entering state -> the final record and the
  * stitch are copied to the host; one synchronisation at the very end.  The tape stays sharded (entries
  * of this rank's bytes, absolute offsets).  Every rank reaches the collective even if its own launch
  * fails (it contributes a record with the error flag set and all ranks return an error).  RCCL is

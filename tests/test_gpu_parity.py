@@ -203,6 +203,58 @@ def test_speculative_scatter_guesses(ctx, torch_cuda, pkg, oracle):
             assert np.array_equal(got, want), (tail, inq)
 
 
+def test_enter_guess_chooses_the_state_of_the_first_tile(ctx, torch_cuda, pkg, oracle):
+    """CSVSIMD_ENTER_GUESS: a shard whose entering state nobody knows is indexed under the state for which its FIRST
+    tile has more entries; the record says which one was used, and count / tape / leaving state are the oracle's for
+    THAT state — whether the guess is the truth (shards cut out of a quoted CSV anywhere) or not (adversarial)."""
+    T = pkg.tile_bytes()
+    rng = np.random.default_rng(808)
+    # a quoted CSV: 10 % of the 30-byte fields are quoted and hold a comma and a line break
+    fields = []
+    for i in range(3 * T // 31 + 50):
+        if rng.random() < 0.1:
+            fields.append(b'"' + b"q" * 9 + b"," + b"q" * 9 + b"\n" + b"q" * 8 + b'"')
+        else:
+            fields.append(b"f" * 30)
+        fields.append(b"\n" if i % 16 == 15 else b",")
+    text = np.frombuffer(b"".join(fields), dtype=np.uint8).copy()
+    _, _ = oracle.scalar_index(text)
+    quotes = np.flatnonzero(text == 0x22)
+    cuts = [0, 1, 31 * 5 + 7, int(quotes[10]) + 3, int(quotes[10]) + 1, int(quotes[11]) + 1, T + 12345,
+            int(quotes[len(quotes) // 2]) + 5, int(quotes[len(quotes) // 2 + 1]) + 5]
+    for cut in cuts:
+        d = text[cut:]
+        truth = int(np.count_nonzero(text[:cut] == 0x22) & 1)
+        got, r = gpu_index(ctx, torch_cuda, d, base_off=cut, in_quote_in=pkg.ENTER_GUESS)
+        want, q = oracle.scalar_index(d, base_off=cut, in_quote_in=r.in_quote_in_used)
+        assert r.in_quote_in_used == truth, cut          # on a real quoted CSV the guess is the truth
+        assert (r.count, r.in_quote_out, r.error) == (want.size, q, 0) and np.array_equal(got, want), cut
+        p, c0, c1 = oracle.shard_descriptor(d)
+        assert (r.quote_parity, r.count_enter_outside, r.count_enter_inside) == (p, c0, c1)
+    # adversarial: first tile = one long quoted field full of commas, truly entered OUTSIDE: the guess says "inside"
+    b = np.full(2 * T + 333, ord("y"), dtype=np.uint8)
+    b[8:T - 32:24] = 0x2C
+    b[6] = 0x22
+    b[T - 2] = 0x22
+    b[T:] = np.frombuffer((b"aaaa,bbbb\n" * (T // 10 + 40))[: T + 333], dtype=np.uint8)
+    got, r = gpu_index(ctx, torch_cuda, b, in_quote_in=pkg.ENTER_GUESS)
+    assert r.in_quote_in_used == 1
+    want, q = oracle.scalar_index(b, in_quote_in=1)
+    assert (r.count, r.in_quote_out) == (want.size, q) and np.array_equal(got, want)
+    # explicit states still mean what they say, and say so
+    for inq in (0, 1):
+        got, r = gpu_index(ctx, torch_cuda, b, in_quote_in=inq)
+        want, q = oracle.scalar_index(b, in_quote_in=inq)
+        assert r.in_quote_in_used == inq and r.count == want.size and np.array_equal(got, want)
+    # an empty shard and a shard smaller than a tile
+    got, r = gpu_index(ctx, torch_cuda, np.zeros(0, dtype=np.uint8), in_quote_in=pkg.ENTER_GUESS)
+    assert (r.count, r.in_quote_in_used, r.in_quote_out) == (0, 0, 0)
+    small = np.frombuffer(b'tail of a quoted field",x,y\n1,2,3\n', dtype=np.uint8).copy()
+    got, r = gpu_index(ctx, torch_cuda, small, in_quote_in=pkg.ENTER_GUESS)
+    want, q = oracle.scalar_index(small, in_quote_in=1)
+    assert r.in_quote_in_used == 1 and np.array_equal(got, want)
+
+
 def test_tape_capacity_and_count_only(ctx, torch_cuda, pkg, oracle):
     rng = np.random.default_rng(8)
     d = random_csvish(rng, 300000, 0.01)
@@ -744,7 +796,8 @@ def test_launch_epochs_wrap_and_shard_sizes_change(pkg, torch_cuda, oracle):
         c.close()
 
 
-def test_device_stitch_and_reemit_three_shards_one_gpu(pkg, torch_cuda, oracle):
+@pytest.mark.parametrize("guess", [False, True])
+def test_device_stitch_and_reemit_three_shards_one_gpu(pkg, torch_cuda, oracle, guess):
     # the N > 1 step as bench.py / csvsimd_stage1_index_sharded drive it, with three shards on ONE GPU and
     # a device-to-device copy standing in for the all-gather: speculative pass -> records side by side in
     # device memory -> stitch kernel -> re-emit launch that reads its entering state from device memory.
@@ -770,7 +823,9 @@ def test_device_stitch_and_reemit_three_shards_one_gpu(pkg, torch_cuda, oracle):
                 for r in range(world):
                     lo, hi = cuts[r], cuts[r + 1]
                     tapes[r].fill_(-1)
-                    ctxs[r].stage1_index_device_async(dbuf.data_ptr() + lo, hi - lo, lo, 0, tapes[r].data_ptr(),
+                    # first pass: speculate "entered outside", or (guess) let ranks > 0 choose from their first tile
+                    first = pkg.ENTER_GUESS if (guess and r > 0) else 0
+                    ctxs[r].stage1_index_device_async(dbuf.data_ptr() + lo, hi - lo, lo, first, tapes[r].data_ptr(),
                                                       tapes[r].numel(), d_fin[r].data_ptr(), s)
                     d_all[8 * r: 8 * r + 8].copy_(d_fin[r])          # "all-gather"
                 spec = [t.clone() for t in tapes]
@@ -787,13 +842,16 @@ def test_device_stitch_and_reemit_three_shards_one_gpu(pkg, torch_cuda, oracle):
                     lo, hi = cuts[r], cuts[r + 1]
                     st = sharded.stitch_from_words(d_st[r].cpu().tolist())
                     host_st = pkg.stitch_shards(recs, r, file_inq)     # device stitch == host stitch
-                    for f in ("in_quote_in", "in_quote_final", "count", "tape_index_base", "total_entries", "error"):
+                    for f in ("in_quote_in", "in_quote_final", "count", "tape_index_base", "total_entries", "error",
+                              "reemit"):
                         assert getattr(st, f) == getattr(host_st, f), (f, r)
+                    assert recs[r].in_quote_in_used in (0, 1) and (guess or recs[r].in_quote_in_used == 0)
+                    assert st.reemit == int(recs[r].in_quote_in_used != state)
                     e, q = oracle.scalar_index(d[lo:hi], base_off=lo, in_quote_in=state)
                     fin = sharded.result_from_words(d_fin[r].cpu().tolist())
                     assert (st.in_quote_in, st.count, st.tape_index_base) == (state, e.size, base)
                     assert (fin.count, fin.in_quote_out, fin.error) == (e.size, q, 0)
-                    if state == 0:   # the re-emit launch must have been a no-op: tape untouched, bit for bit
+                    if not st.reemit:   # the re-emit launch must have been a no-op: tape untouched, bit for bit
                         assert torch.equal(tapes[r], spec[r])
                     # (entries of the speculative pass beyond a shorter re-emitted tape stay where they were)
                     assert bool((tapes[r][max(fin.count, recs[r].count):] == -1).all())

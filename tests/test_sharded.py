@@ -56,13 +56,16 @@ def test_stitch_host_arithmetic(pkg, oracle):
             state, base = q, base + e.size
 
 
-@pytest.mark.parametrize("world,p_quote,skew,device_flow",
-                         [(2, 0.0, 0, False), (2, 0.06, 0, False), (2, 0.06, 777, False), (3, 0.1, 13, False),
-                          (2, 0.06, 777, True), (4, 0.1, 13, True), (2, 0.1, 777, 2), (3, 0.06, 13, 2)])
-def test_gloo_sharded_stitch(pkg, oracle, tmp_path, world, p_quote, skew, device_flow):
+@pytest.mark.parametrize("world,p_quote,skew,device_flow,guess",
+                         [(2, 0.0, 0, False, False), (2, 0.06, 0, False, False), (2, 0.06, 777, False, False),
+                          (3, 0.1, 13, False, False), (2, 0.06, 777, True, False), (4, 0.1, 13, True, False),
+                          (2, 0.1, 777, 2, False), (3, 0.06, 13, 2, False),
+                          # ranks > 0 let the pass choose its entering state (CSVSIMD_ENTER_GUESS)
+                          (3, 0.1, 13, False, True), (4, 0.06, 777, True, True), (3, 0.1, 13, 2, True)])
+def test_gloo_sharded_stitch(pkg, oracle, tmp_path, world, p_quote, skew, device_flow, guess):
     import torch.multiprocessing as mp
     n, seed = 40000, 4242
-    mp.spawn(_dist_worker.worker, args=(world, free_port(), n, seed, p_quote, skew, str(tmp_path), device_flow),
+    mp.spawn(_dist_worker.worker, args=(world, free_port(), n, seed, p_quote, skew, str(tmp_path), device_flow, guess),
              nprocs=world, join=True)
     data = _dist_worker.make_data(n, seed, p_quote)
     want = oracle.scalar_read(data)
