@@ -10,8 +10,9 @@ string and obtains the composable shard descriptor
 — the same two quantities the reference carries between 64-byte blocks (`inside_str`,
 `array_idx`: src/reader.rs:217-218).  ONE all-gather of the 64-byte result record per rank stitches
 them (RCCL has no exclusive scan; the payload is latency-bound, so the 7 x ~153 GB/s xGMI links
-are irrelevant).  Only a rank whose true entering state turns out to be "inside a string"
-re-emits its shard (never on quote-free corpora).  The tape stays sharded in rank order with
+are irrelevant).  Rank 0 knows how the file starts; the other ranks either speculate (first_state 0) or let the kernel
+choose the entering state its first tile speaks for (first_state ENTER_GUESS).  Only a rank whose first pass turns out to
+have used the wrong state re-emits its shard (never on quote-free corpora; with ENTER_GUESS not on quoted CSV either).  The tape stays sharded in rank order with
 absolute offsets: concatenating the shards, after the sentinel 0, is the reference's tape.
 """
 from __future__ import annotations
