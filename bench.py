@@ -4,10 +4,12 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--gib-per-gpu G] [--skew B]
 
 A "step" is one pass of the hot path over one batch of synthetic CSV already resident in HBM:
-each rank indexes its contiguous byte shard of the file (speculative stage-1 launch through the
-C ABI), the ranks exchange their shard descriptors with ONE all-gather over RCCL (N > 1), a one-lane
-kernel stitches quote parity / tape bases ON THE DEVICE, and a second launch re-emits the shard iff
-its true entering state (read from device memory) is "inside a string".  Nothing between the first
+each rank indexes its contiguous byte shard of the file (first stage-1 launch through the C ABI: rank 0
+knows how the file starts, every other rank lets the kernel choose the entering state its first tile
+speaks for, CSVSIMD_ENTER_GUESS), the ranks exchange their shard descriptors with ONE all-gather over
+RCCL (N > 1), a one-lane kernel stitches quote parity / tape bases ON THE DEVICE, and a second launch
+re-emits the shard iff its first pass turns out to have used the wrong entering state (flag read from
+device memory).  Nothing between the first
 launch and the final copy-out waits for the host; the step ends when the tape and its length are
 final on every rank.  Weak scaling: every rank always holds the same number of bytes (default 8 GiB =
 one GPU's shard of BASELINE config 4, "64 GiB synthetic CSV, 64 cols, chunk-sharded 8xMI355X").
