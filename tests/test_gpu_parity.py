@@ -619,6 +619,17 @@ def test_config4_q10_shard_with_carried_state(ctx, torch_cuda, pkg, oracle):
         head = 1 << 20
         assert np.array_equal(t[:head].cpu().numpy().view(np.uint64), want[:head])
         assert np.array_equal(t[-head:].cpu().numpy().view(np.uint64), want[-head:])
+    # the same shard with nobody telling it how it is entered: the kernel's own choice must be the truth (the bytes
+    # before the cut, from the CPU generator), and the tape the one of that state
+    row = cols * (width + 1)
+    r0 = (lo // row) * row
+    truth = int(np.count_nonzero(oracle.synth(r0, lo - r0, cols, width, seed, q) == 0x22)) & 1
+    r = ctx.stage1_index_device(dbuf.data_ptr(), shard, lo, pkg.ENTER_GUESS, dtape.data_ptr(), cap)
+    want, q_out = oracle.scalar_index(host, base_off=lo, in_quote_in=truth)
+    assert (r.in_quote_in_used, r.count, r.in_quote_out, r.error) == (truth, want.size, q_out, 0)
+    out = torch.zeros(2, dtype=torch.int64, device="cuda:0")
+    pkg.tape_checksum_device(dtape.data_ptr(), r.count, 1, out.data_ptr())
+    assert tuple(int(x) & (2**64 - 1) for x in out.cpu().tolist()) == oracle.tape_checksum(want, 1)
 
 
 def test_fuzz_many_shapes(ctx, torch_cuda, pkg, oracle):
