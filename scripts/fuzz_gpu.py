@@ -91,9 +91,14 @@ def main():
         d = make_case(rng)
         n = d.size
         mis = int(rng.integers(0, 128))
-        inq = int(rng.integers(0, 2))
+        inq = int(rng.integers(0, 3))   # 2 = CSVSIMD_ENTER_GUESS: the kernel chooses; the record says what it used
         base = int(rng.integers(0, 1 << 40))
-        want, q = oracle.scalar_index(d, base_off=base, in_quote_in=inq)
+        if inq == 2:
+            _, a0, b0 = oracle.shard_descriptor(d[: pkg.tile_bytes()])
+            used = int(b0 > a0)             # the documented rule: the state under which the first tile has more entries
+        else:
+            used = inq
+        want, q = oracle.scalar_index(d, base_off=base, in_quote_in=used)
         cap_kind = rng.integers(0, 3)
         cap = want.size + 3 if cap_kind == 0 else (n + 1 if cap_kind == 1 else int(rng.integers(0, want.size + 1)))
         dbuf = torch.full((n + 256,), 0x2C, dtype=torch.uint8, device="cuda:0")
@@ -105,7 +110,7 @@ def main():
         got = dtape[:k].cpu().numpy().view(np.uint64)
         p, c0, c1 = oracle.shard_descriptor(d)
         ok = (r.count == want.size and r.in_quote_out == q and r.written == k and np.array_equal(got, want[:k])
-              and bool((dtape[k:] == -1).all()) and r.error == 0
+              and bool((dtape[k:] == -1).all()) and r.error == 0 and r.in_quote_in_used == used
               and (r.quote_parity, r.count_enter_outside, r.count_enter_inside) == (p, c0, c1))
         if not ok:
             bad.append({"case": cases, "n": n, "mis": mis, "inq": inq, "cap": cap, "count": int(r.count),
