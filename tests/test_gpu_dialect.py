@@ -185,6 +185,24 @@ def test_escape_host_path_chains_chunks(ctx, pkg, oracle, monkeypatch):
     assert not np.isin(np.array([4 << 20, 8 << 20], dtype=np.uint64), got).any()
 
 
+def test_enter_guess_in_the_dialect_variants(ctx, pkg, torch_cuda, oracle):
+    # CSVSIMD_ENTER_GUESS is part of the shared kernel body: the dialect instantiations choose their entering state
+    # the same way, and the tape is the scalar definition's for the state the record says was used
+    T = pkg.tile_bytes()
+    for dialect in (pkg.Dialect(";", "'"), pkg.Dialect(",", '"', "\\")):
+        dl, qt = bytes([dialect.delimiter]), bytes([dialect.quote])
+        row = b"aaaa" + dl + qt + b"x" + dl + b"y\nz" + qt + dl + b"bbbb\n"    # one quoted field with a delimiter and an LF
+        text = np.frombuffer(row * (2 * T // len(row) + 3), dtype=np.uint8).copy()
+        for cut in (0, 7, 9, len(row) * 1000 + 8, T + len(row) * 3 + 2):       # cuts 7 / 9 / +8 lie inside the quoted field
+            d = text[cut:]
+            truth = int(np.count_nonzero(text[:cut] == dialect.quote) & 1)
+            got, r = gpu_dialect(ctx, pkg, torch_cuda, d, dialect, base_off=cut, in_quote_in=pkg.ENTER_GUESS)
+            assert r.in_quote_in_used == truth, (dialect.delimiter, cut)
+            want, q, _ = oracle.dialect_index(d, dialect.delimiter, dialect.quote, dialect.escape, base_off=cut,
+                                              in_quote_in=truth, escape_in=0)
+            assert r.count == want.size and r.in_quote_out == q and np.array_equal(got, want)
+
+
 def test_dialect_argument_checks(ctx, pkg, torch_cuda):
     torch = torch_cuda
     dbuf = torch.zeros(256, dtype=torch.uint8, device="cuda:0")
