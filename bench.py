@@ -414,8 +414,9 @@ def ingest_leg(pkg, sb, sample_bytes):
     gib = n / best / 2**30
     return {"value": round(gib, 2), "unit": "GiB/s", "bytes": n, "tape_entries": int(tl), "verified": bool(ok),
             "h2d_probe_GiB_s": round(h2d_gib, 2), "frac_of_h2d_probe": round(gib / h2d_gib, 3),
-            "note": "csvsimd_stage1_index: pageable host buffer -> pinned staging -> H2D -> kernel -> D2H of the "
-                    "tape -> caller's tape (chunks pipelined over three streams); PCIe-inclusive, never part of `value`"}
+            "note": "csvsimd_stage1_index: pageable host buffer -> pinned staging -> H2D -> kernel -> tape to a pinned "
+                    "slot (D2H copy, or written there by the kernel where those copies are slow) -> caller's tape "
+                    "(chunks pipelined over three streams); PCIe-inclusive, never part of `value`"}
 
 
 def consumers_leg(pkg, oracle, device):

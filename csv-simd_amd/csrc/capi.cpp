@@ -10,6 +10,7 @@
 #include <emmintrin.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstddef>
 #include <cstdio>
@@ -193,6 +194,7 @@ struct csvsimd_ctx {
     csvsimd_shard_result* h_res = nullptr;     // pinned, 2 records
     hipEvent_t ev[2] = {nullptr, nullptr};
     std::unique_ptr<CopyPool> copier;         // host-side slices of the staging copies
+    bool tape_zero_copy = false;              // ingest: the kernel writes its tape straight into the pinned slot (below)
 };
 
 extern "C" {
@@ -504,16 +506,35 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
     hipStream_t st = ctx->pipe_stream;
     const uint64_t nchunks = (len + kChunk - 1) / kChunk;
 
+    // How a chunk's tape reaches the host.  Default: a D2H copy on its own stream next to the following chunk's H2D
+    // (49-50 GiB/s end to end on most GPU slots of the two-socket hosts measured).  On some slots those D2H copies crawl
+    // while an H2D is in flight (the call then spends 40 % of its time waiting for them: 41 GiB/s); there the kernel
+    // writes its tape straight into the pinned slot instead (device-visible host memory: the tape crosses PCIe as the
+    // kernel's own stores) — 45-48 GiB/s on those slots, 3-5 % slower than the copies where the copies are healthy.
+    // So: start with copies, switch (for good, for this context) once the waits say the slot is one of the slow ones.
+    bool zero_copy_tape = ctx->tape_zero_copy, adaptive = true, zero_copy_in = false;
+#ifdef CSVSIMD_DEV_PROBES
+    if (const char* e = getenv("CSVSIMD_PROBE_ZEROCOPY_TAPE")) { zero_copy_tape = atoi(e) != 0; adaptive = false; }
+    if (const char* e = getenv("CSVSIMD_PROBE_ZEROCOPY_IN")) zero_copy_in = atoi(e) != 0;  // measured: 36 GiB/s, worse
+#endif
     uint64_t n = 1;  // entries so far, sentinel included
     if (tape && tape_cap >= 1) tape[0] = 0;  // src/reader.rs:216
     uint32_t inq = 0;
 
     // what is still to be unloaded from a slot: `count` entries that belong at tape[at ...]
-    struct Pending { bool valid; uint64_t at, ncopy; } pend[2] = {{false, 0, 0}, {false, 0, 0}};
+    struct Pending { bool valid; uint64_t at, ncopy; bool d2h; } pend[2] = {{false, 0, 0, false}, {false, 0, 0, false}};
+    // where the time of a call goes: the wait for the tape's D2H copies decides how the tape travels (below); the rest
+    // is printed by the probe build (CSVSIMD_PROBE_INGEST_TIMES=1)
+    double t_in = 0, t_out = 0, t_wait_out = 0, t_sync = 0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+#define CSVSIMD_TIMED(acc, stmt) do { const double t0_ = now(); stmt; acc += now() - t0_; } while (0)
     auto unload = [&](int k) -> int {  // waits for the slot's D2H, then copies to the user's tape
         if (!pend[k].valid) return CSVSIMD_OK;
-        HIP_TRY(hipEventSynchronize(ctx->ev[k]));
-        if (pend[k].ncopy) ctx->copier->copy(tape + pend[k].at, ctx->pin_out[k], pend[k].ncopy * 8);
+        hipError_t e_ = hipSuccess;
+        if (pend[k].d2h) CSVSIMD_TIMED(t_wait_out, e_ = hipEventSynchronize(ctx->ev[k]));
+        HIP_TRY(e_);
+        if (pend[k].ncopy) CSVSIMD_TIMED(t_out, ctx->copier->copy(tape + pend[k].at, ctx->pin_out[k], pend[k].ncopy * 8));
         pend[k].valid = false;
         return CSVSIMD_OK;
     };
@@ -522,7 +543,8 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
     auto feed = [&](uint64_t j) -> int {
         const int kj = (int)(j & 1);
         const uint64_t offj = j * kChunk, lenj = std::min<uint64_t>(kChunk, len - offj);
-        ctx->copier->copy(ctx->pin_in[kj], buf + offj, lenj);
+        CSVSIMD_TIMED(t_in, ctx->copier->copy(ctx->pin_in[kj], buf + offj, lenj));
+        if (zero_copy_in) return CSVSIMD_OK;  // the kernel reads the pinned slot itself
         HIP_TRY(hipMemcpyAsync(ctx->d_in[kj], ctx->pin_in[kj], lenj, hipMemcpyHostToDevice, ctx->in_stream));
         HIP_TRY(hipEventRecord(ctx->ev_in[kj], ctx->in_stream));
         return CSVSIMD_OK;
@@ -531,16 +553,31 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
     for (uint64_t i = 0; i < nchunks; ++i) {
         const int k = (int)(i & 1);
         const uint64_t off = i * kChunk, clen = std::min<uint64_t>(kChunk, len - off);
-        HIP_TRY(hipStreamWaitEvent(st, ctx->ev_in[k], 0));
+        const void* in_dev = ctx->d_in[k];
+        if (zero_copy_in) {
+            void* p_ = nullptr;
+            HIP_TRY(hipHostGetDevicePointer(&p_, ctx->pin_in[k], 0));
+            in_dev = p_;
+        } else {
+            HIP_TRY(hipStreamWaitEvent(st, ctx->ev_in[k], 0));
+        }
         // first guess: one entry per 4 bytes; exact retry below if the chunk is denser
         uint64_t cap = 0;
-        if (tape) {
+        void* tape_dev = nullptr;  // where the kernel writes this chunk's tape
+        if (tape && zero_copy_tape) {
+            // straight into the pinned slot the host unloads from (device-visible host memory): the tape crosses PCIe
+            // as the kernel's own stores, not as a D2H copy competing with the next chunk's H2D for the copy engines
+            rc = pipe_ensure_out(ctx, k, std::max<uint64_t>(clen / 4, 4096));
+            if (rc != CSVSIMD_OK) return rc;
+            cap = ctx->pin_out_entries[k];
+            HIP_TRY(hipHostGetDevicePointer(&tape_dev, ctx->pin_out[k], 0));
+        } else if (tape) {
             rc = pipe_ensure_tape(ctx, k, std::max<uint64_t>(clen / 4, 4096));
             if (rc != CSVSIMD_OK) return rc;
             cap = ctx->d_tape_entries[k];
+            tape_dev = ctx->d_tape[k];
         }
-        rc = stage1_async_impl(ctx, dp, ctx->d_in[k], clen, off, inq, tape ? ctx->d_tape[k] : nullptr, cap, ctx->d_res[k],
-                               st);
+        rc = stage1_async_impl(ctx, dp, in_dev, clen, off, inq, tape_dev, cap, ctx->d_res[k], st);
         if (rc != CSVSIMD_OK) return rc;
         HIP_TRY(hipMemcpyAsync(&ctx->h_res[k], ctx->d_res[k], sizeof(csvsimd_shard_result), hipMemcpyDeviceToHost, st));
         // while chunk i is in flight: stage chunk i+1 and start its H2D copy (slot k^1 is free: the
@@ -548,24 +585,42 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
         if (i + 1 < nchunks && (rc = feed(i + 1)) != CSVSIMD_OK) return rc;
         rc = unload(k ^ 1);
         if (rc != CSVSIMD_OK) return rc;
-        HIP_TRY(hipStreamSynchronize(st));
+        if (adaptive && !zero_copy_tape && i >= 6 && t_wait_out > 0.15 * (now() - t_begin)) {
+            zero_copy_tape = true;       // takes effect with the next chunk; pending copies are unloaded as copies
+            ctx->tape_zero_copy = true;  // and the context's later calls start this way
+        }
+        {
+            hipError_t e_ = hipSuccess;
+            CSVSIMD_TIMED(t_sync, e_ = hipStreamSynchronize(st));
+            HIP_TRY(e_);
+        }
         csvsimd_shard_result r = ctx->h_res[k];
         if (r.error) { g_last_error = "stage1 kernel: look-back spin bound hit"; return CSVSIMD_ERR_INTERNAL; }
         if (tape && r.count > cap) {  // denser than guessed: exact capacity, run the chunk again
-            rc = pipe_ensure_tape(ctx, k, r.count);
-            if (rc != CSVSIMD_OK) return rc;
-            rc = stage1_async_impl(ctx, dp, ctx->d_in[k], clen, off, inq, ctx->d_tape[k], ctx->d_tape_entries[k],
-                                   ctx->d_res[k], st);
+            if (zero_copy_tape) {
+                rc = pipe_ensure_out(ctx, k, r.count);
+                if (rc != CSVSIMD_OK) return rc;
+                cap = ctx->pin_out_entries[k];
+                HIP_TRY(hipHostGetDevicePointer(&tape_dev, ctx->pin_out[k], 0));
+            } else {
+                rc = pipe_ensure_tape(ctx, k, r.count);
+                if (rc != CSVSIMD_OK) return rc;
+                cap = ctx->d_tape_entries[k];
+                tape_dev = ctx->d_tape[k];
+            }
+            rc = stage1_async_impl(ctx, dp, in_dev, clen, off, inq, tape_dev, cap, ctx->d_res[k], st);
             if (rc != CSVSIMD_OK) return rc;
             HIP_TRY(hipMemcpyAsync(&ctx->h_res[k], ctx->d_res[k], sizeof(csvsimd_shard_result), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             r = ctx->h_res[k];  // the second pass's own record: its error flag and count are what count
             if (r.error) { g_last_error = "stage1 kernel: look-back spin bound hit"; return CSVSIMD_ERR_INTERNAL; }
-            if (r.count > ctx->d_tape_entries[k]) return CSVSIMD_ERR_INTERNAL;
+            if (r.count > cap) return CSVSIMD_ERR_INTERNAL;
         }
         if (tape && n < tape_cap) {
             const uint64_t ncopy = std::min<uint64_t>(tape_cap - n, r.count);
-            if (ncopy) {
+            if (ncopy && tape_dev != ctx->d_tape[k]) {
+                pend[k] = {true, n, ncopy, false};  // already in the pinned slot: the kernel was waited for
+            } else if (ncopy) {
                 rc = pipe_ensure_out(ctx, k, std::max<uint64_t>(ncopy, 4096));
                 if (rc != CSVSIMD_OK) return rc;
                 // the kernel has finished (its result record was waited for): the tape chunk leaves on
@@ -573,13 +628,22 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
                 HIP_TRY(hipMemcpyAsync(ctx->pin_out[k], ctx->d_tape[k], ncopy * 8, hipMemcpyDeviceToHost,
                                        ctx->out_stream));
                 HIP_TRY(hipEventRecord(ctx->ev[k], ctx->out_stream));
-                pend[k] = {true, n, ncopy};
+                pend[k] = {true, n, ncopy, true};
             }
         }
         n += r.count;
         inq = r.in_quote_out;
         dia.escape_in = (uint8_t)r.escape_out;
     }
+#ifdef CSVSIMD_DEV_PROBES
+    if (getenv("CSVSIMD_PROBE_INGEST_TIMES"))
+        fprintf(stderr, "ingest %.1f MiB: staging copies in %.2f ms, tape copies out %.2f ms, waits for D2H %.2f ms, "
+                        "waits for the kernel (incl. H2D) %.2f ms; tape %s\n",
+                len / 1048576.0, t_in * 1e3, t_out * 1e3, t_wait_out * 1e3, t_sync * 1e3,
+                zero_copy_tape ? "written by the kernel into the pinned slot" : "copied D2H");
+#else
+    (void)t_in; (void)t_out; (void)t_sync;
+#endif
     rc = unload(0);
     if (rc != CSVSIMD_OK) return rc;
     rc = unload(1);
