@@ -335,8 +335,10 @@ __device__ __forceinline__ void lookback_fetch(const uint4* lds, u32 tile, u32 l
 
 template <bool PRE = false>
 __device__ __forceinline__ void resolve(u64* desc, u32 tile, u32 epoch, Desc agg, u32 in_quote_in, u32 lane_in,
-                                        u32& pin_out, u64& base_out, u32& err, const u64* pre = nullptr) {
+                                        u32& pin_out, u64& base_out, u32& err, const u64* pre = nullptr,
+                                        u32* dbg_windows_spins = nullptr) {
     const u32 lane = lane_in;
+    u32 dbg_windows = 0;
     u32 pin = in_quote_in;
     u64 base = 0;
     // acc = composition of the tiles in (hi, tile): function of the state entering tile hi+1
@@ -360,6 +362,7 @@ __device__ __forceinline__ void resolve(u64* desc, u32 tile, u32 epoch, Desc agg
     bool use_pre = PRE;
     for (;;) {
         // lane k holds window positions 4k .. 4k+3 (position 0 = nearest predecessor)
+        ++dbg_windows;
         u64 d[4], x[4];
         u32 linv = 4, linc = 4;  // first invalid / first inclusive among this lane's four
 #pragma unroll
@@ -432,6 +435,7 @@ __device__ __forceinline__ void resolve(u64* desc, u32 tile, u32 epoch, Desc agg
             if (++spins > kSpinLimit) { err = 1; break; }
         }
     }
+    if (dbg_windows_spins) *dbg_windows_spins = (dbg_windows << 16) | (spins & 0xffffu);
     const u32 state_out = pin ^ agg.p;
     const u64 count_out = base + (pin ? agg.b : agg.a);
     if (lane == 0) store_desc(desc + tile, encode_desc(kStatusInc, epoch, (u64)state_out | (count_out << 1)));
@@ -1044,6 +1048,11 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
     bool hold_token = false;
 
     for (u32 iter = 0;; ++iter) {
+#ifdef CSVSIMD_DEV_PROBES
+        u64 trace_top = 0, trace_t = 0, trace_a = 0, trace_landed = 0;
+        u32 trace_ws = 0;
+        if (DBG & 32) trace_top = __builtin_amdgcn_s_memrealtime();
+#endif
         if (w == 0 && lane == 0) {  // (not `t == 0`: threadIdx.x itself would have to stay live through the loop)
             if (my_token && args.token_mode == 2) {
                 // both atomics in flight together (one round trip instead of two); a workgroup that then has to wait
@@ -1068,6 +1077,9 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
         }
         hold_token = my_token != nullptr;
         wg_barrier();  // barrier T
+#ifdef CSVSIMD_DEV_PROBES
+        if (DBG & 32) trace_t = __builtin_amdgcn_s_memrealtime();
+#endif
         CSVSIMD_STAMP(0)
         const u32 tile = (u32)__builtin_amdgcn_readfirstlane((int)s_tile);
         CSVSIMD_TRACE(0, tile)
@@ -1148,6 +1160,9 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
         wg_barrier();     // barrier A
         if (hold_token && w == 0 && lane == 0)
             __hip_atomic_store(my_token, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef CSVSIMD_DEV_PROBES
+        if (DBG & 32) trace_a = __builtin_amdgcn_s_memrealtime();
+#endif
         CSVSIMD_STAMP(2)
         CSVSIMD_TRACE(2, tile)
 
@@ -1198,8 +1213,15 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
                 // CSVSIMD_ENTER_GUESS: the choice was published before tile 0's aggregate, a tile-time ago at least
                 const u32 inq_eff = inq_in == kEnterGuess ? wait_for_guess(args.ctl, err) : inq_in;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef CSVSIMD_DEV_PROBES
+                if (DBG & 32) trace_landed = __builtin_amdgcn_s_memrealtime();
+                lookback_fetch(s_stage_b[0], held_tile, lane, pre);
+                resolve<true>(args.desc, held_tile, epoch, held_agg, inq_eff, lane, pin, base, err, pre,
+                              (DBG & 32) ? &trace_ws : nullptr);
+#else
                 lookback_fetch(s_stage_b[0], held_tile, lane, pre);
                 resolve<true>(args.desc, held_tile, epoch, held_agg, inq_eff, lane, pin, base, err, pre);
+#endif
             }
             if (lane == 0) {
                 s_pin = pin;
@@ -1208,6 +1230,18 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
         }
         CSVSIMD_STAMP(3)  // publish + resolve (wave 0)
         if (have_held) { CSVSIMD_TRACE(3, held_tile) }
+#ifdef CSVSIMD_DEV_PROBES
+        if ((DBG & 32) && w == 0 && lane == 0 && have_held && held_tile < args.num_tiles) {
+            // the iteration that resolved the held tile, in 10-ns ticks: upper half of slot 6 = loop top -> barrier T
+            // (token + ticket) | barrier T -> barrier A (the count phase of the OTHER tile, if any); upper half of slot 7 =
+            // barrier A -> look-back window landed (12 bits) | windows walked (4 bits) | spins (16 bits)
+            u32* const s6 = reinterpret_cast<u32*>(&args.prof[32 + (u64)held_tile * 8 + 6]);
+            u32* const s7 = reinterpret_cast<u32*>(&args.prof[32 + (u64)held_tile * 8 + 7]);
+            const u32 d_top = (u32)(trace_t - trace_top), d_cnt = (u32)(trace_a - trace_t), d_land = (u32)(trace_landed - trace_a);
+            s6[1] = (d_top > 0xffffu ? 0xffffu : d_top) | ((d_cnt > 0xffffu ? 0xffffu : d_cnt) << 16);
+            s7[1] = ((d_land > 0xfffu ? 0xfffu : d_land) << 20) | ((trace_ws >> 16 > 15u ? 15u : trace_ws >> 16) << 16) | (trace_ws & 0xffffu);
+        }
+#endif
         wg_barrier();     // barrier B
         CSVSIMD_STAMP(4)
         if (have_held) { CSVSIMD_TRACE(4, held_tile) }
@@ -1235,8 +1269,11 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
         if (have_held) { CSVSIMD_TRACE(5, held_tile) }
 #ifdef CSVSIMD_DEV_PROBES
         if ((DBG & 32) && w == 0 && lane == 0 && have_cur) {
-            args.prof[32 + (u64)tile * 8 + 6] = (u64)blockIdx.x | ((u64)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xf) << 32);
-            args.prof[32 + (u64)tile * 8 + 7] = (u64)(u32)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));  // HW_ID
+            // lower halves only: the upper halves belong to the iteration that resolves this tile (above)
+            reinterpret_cast<u32*>(&args.prof[32 + (u64)tile * 8 + 6])[0] =
+                blockIdx.x | ((__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xfu) << 16);
+            reinterpret_cast<u32*>(&args.prof[32 + (u64)tile * 8 + 7])[0] =
+                (u32)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));  // HW_ID
         }
 #endif
         // the tile counted in this iteration becomes the held one

@@ -30,9 +30,17 @@ nt = (n + T - 1) // T
 tr = tr[:nt].astype(np.float64)
 t0 = tr[:, 0].min()
 us = (tr[:, :6] - t0) / 100.0          # s_memrealtime ticks at 100 MHz
-blk = (tr[:, 6].astype(np.uint64) & np.uint64(0xffffffff)).astype(np.int64)
-xcc = (tr[:, 6].astype(np.uint64) >> np.uint64(32)).astype(np.int64) & 0xf
-hwid = tr[:, 7].astype(np.uint64).astype(np.int64)
+raw6 = np.fromfile(path, dtype=np.uint64).reshape(-1, 8)[:nt, 6]
+raw7 = np.fromfile(path, dtype=np.uint64).reshape(-1, 8)[:nt, 7]
+blk = (raw6 & np.uint64(0xffff)).astype(np.int64)
+xcc = ((raw6 >> np.uint64(16)) & np.uint64(0xf)).astype(np.int64)
+hwid = (raw7 & np.uint64(0xffffffff)).astype(np.int64)
+# the iteration that resolved each tile (10-ns ticks -> us)
+it_top = ((raw6 >> np.uint64(32)) & np.uint64(0xffff)).astype(np.float64) / 100.0      # loop top -> barrier T (token + ticket)
+it_cnt = ((raw6 >> np.uint64(48)) & np.uint64(0xffff)).astype(np.float64) / 100.0      # barrier T -> barrier A (other tile's count)
+it_land = ((raw7 >> np.uint64(52)) & np.uint64(0xfff)).astype(np.float64) / 100.0      # barrier A -> look-back window landed
+it_win = ((raw7 >> np.uint64(48)) & np.uint64(0xf)).astype(np.int64)                   # windows walked
+it_spin = ((raw7 >> np.uint64(32)) & np.uint64(0xffff)).astype(np.int64)               # back-off spins
 print(f"== {name} {gib} GiB: {ms:.4f} ms (timing build), {nt} tiles, {len(set(blk))} workgroups drew tiles")
 end = us[:, 5].max()
 print(f"launch span by stamps: first ticket 0.0 .. last emit end {end:.1f} us")
@@ -81,10 +89,18 @@ for i in last:
     k = seq.index(int(i))
     prev = seq[k - 1] if k > 0 else None
     extra = f"{us[prev, 3]:8.1f} {us[prev, 5]:8.1f}" if prev is not None else ""
-    print(f"   {int(i):6d} {int(blk[i]):4d} {int(pos[i]):3d} | " + " ".join(f"{x:8.1f}" for x in us[i, :6]) + " | " + extra)
+    print(f"   {int(i):6d} {int(blk[i]):4d} {int(pos[i]):3d} | " + " ".join(f"{x:8.1f}" for x in us[i, :6]) + " | " + extra
+          + f" | resolving iteration: top->T {it_top[i]:.1f} T->A {it_cnt[i]:.1f} A->landed {it_land[i]:.1f} windows {it_win[i]} spins {it_spin[i]}")
 cend = us[:, 1].max()
 late = us[:, 5] > cend
 print(f"after the last count phase ended ({cend:.1f} us): {int(late.sum())} tiles ({late.sum() * T / 2**20:.0f} MiB of input) still to emit, "
       f"done at {us[:, 5].max():.1f} us")
 b = np.histogram(us[late, 5], bins=np.arange(cend, end + 5, 5))[0]
 print("tiles finishing per 5-us bucket after that:", b.tolist())
+print("resolving iteration, medians by position (us): pos  top->T  T->A  A->landed  windows  spins")
+for p_ in range(int(pos.max()) + 1):
+    m = pos == p_
+    if m.sum() == 0:
+        continue
+    print(f"   {p_:3d} {np.median(it_top[m]):7.2f} {np.median(it_cnt[m]):6.2f} {np.median(it_land[m]):8.2f} "
+          f"{np.median(it_win[m]):8.1f} {np.median(it_spin[m]):6.1f}   (max windows {it_win[m].max()}, max spins {it_spin[m].max()})")
