@@ -246,6 +246,11 @@ def test_enter_guess_chooses_the_state_of_the_first_tile(ctx, torch_cuda, pkg, o
         got, r = gpu_index(ctx, torch_cuda, b, in_quote_in=inq)
         want, q = oracle.scalar_index(b, in_quote_in=inq)
         assert r.in_quote_in_used == inq and r.count == want.size and np.array_equal(got, want)
+    # count-only launch (no tape): the same choice, the same counts
+    dbuf = torch_cuda.from_numpy(b).cuda()
+    r0 = ctx.stage1_index_device(dbuf.data_ptr(), b.size, 0, pkg.ENTER_GUESS, 0, 0)
+    want, q = oracle.scalar_index(b, in_quote_in=1)
+    assert (r0.in_quote_in_used, r0.count, r0.in_quote_out, r0.written) == (1, want.size, q, 0)
     # an empty shard and a shard smaller than a tile
     got, r = gpu_index(ctx, torch_cuda, np.zeros(0, dtype=np.uint8), in_quote_in=pkg.ENTER_GUESS)
     assert (r.count, r.in_quote_in_used, r.in_quote_out) == (0, 0, 0)
