@@ -40,7 +40,7 @@ def main():
     launches = 0
     while time.time() < t_end:
         for ci, (name, n, dbuf, dtape, cap, dialect, mis) in enumerate(cases):
-            inq = launches & 1
+            inq = launches % 3   # 0, 1, and 2 = CSVSIMD_ENTER_GUESS (the kernel's own choice must be the same every time too)
             if dialect is None:
                 ctx.stage1_index_device_async(dbuf.data_ptr() + mis, n, 123, inq, dtape.data_ptr(), cap, dres.data_ptr())
             else:
@@ -50,7 +50,8 @@ def main():
             dsum.zero_()
             pkg.tape_checksum_device(dtape.data_ptr(), min(r.count, cap), 0, dsum.data_ptr())
             key = (ci, inq)
-            sig = (r.count, r.in_quote_out, r.error, r.count_enter_outside, r.count_enter_inside, tuple(dsum.tolist()))
+            sig = (r.count, r.in_quote_out, r.error, r.count_enter_outside, r.count_enter_inside, r.in_quote_in_used,
+                   tuple(dsum.tolist()))
             if key not in ref:
                 ref[key] = sig
             hist["ok" if sig == ref[key] else f"MISMATCH case {ci} {name} inq {inq}: {sig} != {ref[key]}"] += 1
