@@ -55,8 +55,10 @@ WINDOW_ENTRIES = 1 << 20  # entries compared with the CPU oracle either side of 
 
 
 def build_if_needed():
+    """Rank 0, before the process group's first barrier: the other ranks load the libraries only after it."""
     so = os.path.join(ROOT, "csv-simd_amd", "csrc", "libcsvsimd_hip.so")
-    if not os.path.exists(so):
+    checker = os.path.join(ROOT, "oracle", "liboracle.so")   # the verification legs' CPU oracle
+    if not (os.path.exists(so) and os.path.exists(checker)):
         graft.build()
 
 
