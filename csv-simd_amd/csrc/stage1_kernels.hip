@@ -846,6 +846,10 @@ __device__ __forceinline__ void finish_launch(const KernelArgs& args, u32 epoch,
     if ((old_hi >> 16) != gridDim.x - 1u) return;
 
     const u64 total = ((((u64)old_hi << 32) | old_lo) & ((1ull << 48) - 1ull)) + wg_tot;
+    // the launch ends when this workgroup does: the control words it needs are requested together with the first poll
+    // of the last tile's word (three round trips in flight at once instead of one after the other)
+    const u32 err_seen = __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u32 hwm_seen = __hip_atomic_load(&ctl->hwm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     u32 e = 0;
     // CSVSIMD_ENTER_GUESS and this workgroup never resolved a tile: the choice of tile 0's workgroup is there by now
     // (every workgroup has finished); an empty shard has no tile 0 and is "entered outside"
@@ -863,13 +867,13 @@ __device__ __forceinline__ void finish_launch(const KernelArgs& args, u32 epoch,
         state_out = (u32)x & 1u;
         count = x >> 1;
     }
-    e |= __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    e |= err_seen;  // every other workgroup raised its flag before it counted itself done
     // escape dialect: is the byte after the shard escaped? (chains into the next shard's escape_in)
     u32 esc_out = 0;
     if (DIALECT == 2)
         esc_out = escape_run_parity(args.abase, args.lo, args.hi, args.hi, args.escape, args.escape_in, lane);
     const u32 next_epoch = (epoch + 1u) & kEpochMask;
-    u32 hwm = ctl->hwm > args.num_tiles ? ctl->hwm : args.num_tiles;
+    u32 hwm = hwm_seen > args.num_tiles ? hwm_seen : args.num_tiles;
     if (next_epoch == 0u) {
         // the epoch wraps: words tagged in earlier rounds of the counter must not be mistaken for
         // the next round's, so everything used since the last wrap is cleared (once per 1024 launches)
