@@ -1298,7 +1298,9 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
         //    top: -0.5 ... -2 % (a shorter hand-off does not help: the steady state is bound by HBM, not by this chain);
         //  * resolving and emitting a tile that is among the last gridDim.x of the shard in the iteration that counted
         //    it (un-lagged, right behind the held one) so that the launch drains in two back-to-back resolves: 0 ... -0.5 %
-        //    (the un-lagged look-back waits for the predecessors that are still counting), and 2 VGPR spills.
+        //    (the un-lagged look-back waits for the predecessors that are still counting), and 2 VGPR spills;
+        //  * no token for a workgroup's FIRST tile (the two workgroups of a CU count their first tiles at once instead
+        //    of the second one sitting out the first one's count phase): 0 ... -2 %, worst on the shortest launches.
         if (!have_cur) break;
     }
 #ifdef CSVSIMD_DEV_PROBES
