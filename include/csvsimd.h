@@ -64,11 +64,11 @@ void csvsimd_ctx_destroy(csvsimd_ctx* ctx);
  * of SURVEY.md §8e; the reference carries the same two quantities between 64-byte blocks as
  * `inside_str` and `array_idx` (src/reader.rs:217-218). */
 typedef struct csvsimd_shard_result {
-    uint64_t count;               /* structural entries for the in_quote_in that was passed  */
+    uint64_t count;               /* structural entries under the entering state of this pass (in_quote_in_used) */
     uint64_t count_enter_outside; /* ... had the shard been entered outside a quoted string   */
     uint64_t count_enter_inside;  /* ... had it been entered inside one                       */
     uint32_t quote_parity;        /* number of '"' bytes in the shard, mod 2                  */
-    uint32_t in_quote_out;        /* in_quote_in ^ quote_parity                               */
+    uint32_t in_quote_out;        /* in_quote_in_used ^ quote_parity                          */
     uint32_t error;               /* 0, or CSVSIMD_ERR_INTERNAL's in-kernel flag              */
     uint32_t escape_out;          /* escape dialects only: the byte after the shard is escaped */
     uint64_t written;             /* min(count, tape_cap): entries actually stored            */
