@@ -56,3 +56,51 @@ def test_settle_count_depends_on_bytes_only(bench):
     assert 10 <= bench.settle_count(8 << 30) <= 20          # ~25 ms of 1.7-ms launches
     assert bench.settle_count(1 << 30) > bench.settle_count(8 << 30)
     assert bench.settle_count(1) == 400 and bench.settle_count(1 << 50) == 1
+
+
+class _StubShard:
+    """What the verification functions read of a ShardBench, on CPU tensors."""
+
+    def __init__(self, torch, data, lo, tape, width=3):
+        self.dbuf = torch.from_numpy(data)
+        self.n, self.lo, self.hi = data.size, lo, lo + data.size
+        self.dtape = torch.from_numpy(tape.astype(np.int64))
+        self.width, self.device = width, torch.device("cpu")
+
+
+def test_torch_restatement_agrees_with_the_oracle_and_can_fail(bench, oracle):
+    """bench.py's independent restatement of the definition (eq / cumsum / nonzero) must agree with the oracle on a
+    correct tape — for both entering states, across its chunk boundaries — and must REJECT a tape with one entry
+    changed, dropped or added."""
+    import torch
+    from conftest import random_csvish
+    rng = np.random.default_rng(77)
+    for inq in (0, 1):
+        d = random_csvish(rng, 300_000, 0.05)
+        lo = 12345
+        want, q = oracle.scalar_index(d, base_off=lo, in_quote_in=inq)
+        ok, n, state = bench.torch_reference_compare(_StubShard(torch, d, lo, want), inq, want.size)
+        assert (ok, n, state) == (True, want.size, q)
+        bad = want.copy()
+        bad[want.size // 2] += 1
+        assert bench.torch_reference_compare(_StubShard(torch, d, lo, bad), inq, bad.size)[0] is False
+        assert bench.torch_reference_compare(_StubShard(torch, d, lo, want[:-1]), inq, want.size - 1)[0] is False
+        extra = np.append(want, want[-1] + 1)
+        assert bench.torch_reference_compare(_StubShard(torch, d, lo, extra), inq, extra.size)[0] is False
+        # the wrong entering state is not the same tape
+        assert bench.torch_reference_compare(_StubShard(torch, d, lo, want), inq ^ 1, want.size)[0] is False
+
+
+def test_closed_form_check_can_fail(bench):
+    import torch
+    width, rows = 3, 1000
+    data = np.frombuffer((b"abc," * 7 + b"abc\n") * rows, dtype=np.uint8).copy()
+    pitch = width + 1
+    lo = 8 * pitch * 5                                        # a shard that starts at a row boundary of a bigger file
+    tape = np.arange(lo // pitch, (lo + data.size) // pitch, dtype=np.int64) * pitch + width
+    sb = _StubShard(torch, data, lo, tape, width)
+    assert bench.closed_form_compare(sb, tape.size) is True
+    assert bench.closed_form_compare(sb, tape.size - 1) is False
+    tape2 = tape.copy()
+    tape2[17] += 4
+    assert bench.closed_form_compare(_StubShard(torch, data, lo, tape2, width), tape2.size) is False
