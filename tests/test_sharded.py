@@ -45,6 +45,7 @@ def test_stitch_host_arithmetic(pkg, oracle):
             p, c0, c1 = oracle.shard_descriptor(d[bounds[i]: bounds[i + 1]])
             r = pkg.ShardResult()
             r.quote_parity, r.count_enter_outside, r.count_enter_inside = p, c0, c1
+            r.in_quote_in_used = int(rng.integers(0, 2))   # whatever state each first pass happened to run with
             results.append(r)
         full, inq = oracle.scalar_index(d)
         state, base = 0, 1
@@ -53,6 +54,7 @@ def test_stitch_host_arithmetic(pkg, oracle):
             e, q = oracle.scalar_index(d[bounds[i]: bounds[i + 1]], in_quote_in=state)
             assert (st.in_quote_in, st.count, st.tape_index_base) == (state, e.size, base)
             assert st.total_entries == full.size + 1 and st.in_quote_final == inq
+            assert st.reemit == int(results[i].in_quote_in_used != state)   # re-emit iff the pass used the wrong state
             state, base = q, base + e.size
 
 
