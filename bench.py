@@ -115,6 +115,12 @@ class ShardBench:
     def stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    def release(self):
+        """Gives the device memory back (the legs of a run recycle HBM one after the other)."""
+        torch.cuda.synchronize(self.device)
+        self.dbuf = self.dtape = self.dtapes = None
+        torch.cuda.empty_cache()
+
     def launch(self, in_quote_in, d_result=None):
         """Enqueue stage 1 over this rank's shard (asynchronous; result record -> d_result)."""
         d_result = self.d_result if d_result is None else d_result
@@ -360,14 +366,33 @@ def load_traffic(workload, launch_bytes):
     return None
 
 
-def cpu_baseline(oracle, sb, sample_bytes):
-    """ref_sse_1t on a bounded sample of the SAME bytes (copied back from HBM)."""
+def host_sample(sb, sample_bytes):
+    """The first `sample_bytes` of this rank's shard, copied back from HBM into a 64-byte-aligned host array:
+    the SAME bytes the GPU scans, for the CPU baselines and the ingest leg."""
+    import __graft_entry__ as g
     n = min(sb.n, sample_bytes)
-    host = oracle.aligned_copy(sb.dbuf[:n].cpu().numpy())
+    return g.load_oracle().aligned_copy(sb.dbuf[:n].cpu().numpy())
+
+
+def cpu_threads():
+    """Threads the multi-threaded CPU variant uses: the cores this process may run on, at most 16 per GPU of the
+    job (a GPU box of this pool gives a container 16 of the host's hardware threads per GPU; neither
+    os.cpu_count() nor the affinity mask shows that share, both report the whole host)."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return max(1, min(avail, 16))
+
+
+def cpu_baseline(oracle, host, budget_s=10.0):
+    """ref_sse_1t on a bounded sample of the SAME bytes (copied back from HBM): the oracle's faithful SSE
+    restatement of reference reader::read (src/reader.rs:229-290), growing Vec, ONE thread like the reference."""
+    n = host.size
     oracle.sse_read_growing_timed(host[: 1 << 24])  # warm the code path / page in
     times, entries = [], 0
     t_total = 0.0
-    while len(times) < 3 or (t_total < 10.0 and len(times) < 64):   # ~10 s of CPU work
+    while len(times) < 3 or (t_total < budget_s and len(times) < 64):   # ~10 s of CPU work
         entries, dt = oracle.sse_read_growing_timed(host)
         times.append(dt)
         t_total += dt
@@ -379,14 +404,70 @@ def cpu_baseline(oracle, sb, sample_bytes):
             "entries": entries, "host_cpus": os.cpu_count()}
 
 
-def ingest_leg(pkg, sb, sample_bytes):
+def cpu_baseline_variants(oracle, host, width, budget_scale=1.0):
+    """The other three CPU variants of BASELINE.md §2 on the same sample, in the same run (VERDICT r2 missing #4):
+    ref_sse_mt (chunked over `cores` threads with a quote-parity / count stitch, -march=native), ref_sse_1t_native
+    (same loop, -march=native, pre-reserved output) and scalar_1t (the byte loop).  liboracle_native.so is built here,
+    for THIS host, from oracle/oracle.c (test infrastructure: the checker's own source with other compiler flags)."""
+    import ctypes as C
+    import subprocess
+    odir = os.path.join(ROOT, "oracle")
+    n = host.size
+    tape = np.zeros(n // (width + 1) + 4096, dtype=np.uint64)
+    cnt = C.c_uint64()
+    u64p = C.POINTER(C.c_uint64)
+    out = {}
+
+    def best_of(fn, budget_s, min_reps=2, max_reps=32):
+        times, t_total = [], 0.0
+        while len(times) < min_reps or (t_total < budget_s and len(times) < max_reps):
+            t0 = time.perf_counter()
+            rc = fn()
+            dt = time.perf_counter() - t0
+            assert rc == 0
+            times.append(dt)
+            t_total += dt
+        return min(times), len(times), t_total
+
+    try:
+        subprocess.run(["make", "-s", "-C", odir, "liboracle_native.so"], check=True, capture_output=True, timeout=120)
+        nat = C.CDLL(os.path.join(odir, "liboracle_native.so"))
+        nat.oracle_sse_read.restype = C.c_int
+        nat.oracle_sse_read.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, u64p]
+        nat.oracle_sse_read_mt.restype = C.c_int
+        nat.oracle_sse_read_mt.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, u64p]
+        threads = cpu_threads()
+        b, k, tt = best_of(lambda: nat.oracle_sse_read_mt(host.ctypes.data, n, threads, tape.ctypes.data, tape.size,
+                                                          C.byref(cnt)), 4.0 * budget_scale)
+        entries_mt = int(cnt.value)
+        out["cpu_baseline_mt"] = {
+            "value": round(n / b / 2**30, 3), "unit": "GiB/s", "cores": threads, "kind": "port",
+            "variant": f"ref_sse_mt (the same SSE block loop on {threads} contiguous chunks, quote-parity / count "
+                       "stitch, -march=native; NOT a reference behaviour: the reference is single-threaded)",
+            "sample": f"first {n / 2**30:.2f} GiB of rank 0's shard, best of {k} passes ({tt:.1f} s)",
+            "entries": entries_mt, "host_cpus": os.cpu_count()}
+        b, k, tt = best_of(lambda: nat.oracle_sse_read(host.ctypes.data, n, tape.ctypes.data, tape.size, C.byref(cnt)), 4.0 * budget_scale)
+        out["ref_sse_1t_native"] = {"value": round(n / b / 2**30, 3), "unit": "GiB/s", "cores": 1, "kind": "port",
+                                    "variant": "ref_sse_1t_native (-march=native, output pre-reserved)",
+                                    "sample": f"the same {n / 2**30:.2f} GiB, best of {k}", "entries": int(cnt.value)}
+    except Exception as e:   # no compiler on the host: the portable variants below still run
+        out["native_build_error"] = repr(e)[:200]
+    base = oracle.lib()
+    m = min(n, 256 << 20)   # the byte loop runs at < 1 GiB/s: a quarter GiB is seconds
+    b, k, tt = best_of(lambda: base.oracle_scalar_read(host.ctypes.data, m, tape.ctypes.data, tape.size, C.byref(cnt)), 2.0 * budget_scale)
+    out["scalar_1t"] = {"value": round(m / b / 2**30, 3), "unit": "GiB/s", "cores": 1, "kind": "port",
+                        "variant": "scalar_1t (byte-at-a-time definition)",
+                        "sample": f"first {m / 2**30:.2f} GiB, best of {k}", "entries": int(cnt.value)}
+    return out
+
+
+def ingest_leg(pkg, device, host, width, closed_form):
     """The host-buffer drop-in for reader::read (csvsimd_stage1_index: pageable host bytes in, host tape
     out) on a bounded sample of the same corpus, next to what this box's PCIe link moves host -> device
     (one pinned hipMemcpy).  PCIe-inclusive by construction; reported beside `value`, never in it."""
-    n = min(sb.n, sample_bytes)
-    host = sb.dbuf[:n].cpu().numpy()
-    tape = np.empty(n // (sb.width + 1) + 64, dtype=np.uint64)
-    ctx = pkg.Context(sb.device.index)
+    n = host.size
+    tape = np.empty(n // (width + 1) + 64, dtype=np.uint64)
+    ctx = pkg.Context(device.index)
     rc, tl, _ = ctx.read_into(host[: 64 << 20], tape)      # allocates the pipeline, pages everything in
     best, ok = None, rc == 0
     for _ in range(3):
@@ -395,14 +476,14 @@ def ingest_leg(pkg, sb, sample_bytes):
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
         ok = ok and rc == 0
-    pitch = sb.width + 1
-    if not sb.q and sb.lo == 0:
-        want = np.arange(n // pitch, dtype=np.uint64) * pitch + sb.width
+    pitch = width + 1
+    if closed_form:
+        want = np.arange(n // pitch, dtype=np.uint64) * pitch + width
         ok = ok and tl == want.size + 1 and tape[0] == 0 and bool(np.array_equal(tape[1:tl], want))
     ctx.close()
-    # probed link rate: pinned host -> device, the same number of bytes, best of 3
+    # probed link rate: pinned host -> device, the same number of bytes, best of 4
     pin = torch.empty(min(n, 1 << 30), dtype=torch.uint8).pin_memory()
-    dst = torch.empty_like(pin, device=sb.device)
+    dst = torch.empty_like(pin, device=device)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     h2d = None
     for _ in range(4):
@@ -416,9 +497,9 @@ def ingest_leg(pkg, sb, sample_bytes):
     gib = n / best / 2**30
     return {"value": round(gib, 2), "unit": "GiB/s", "bytes": n, "tape_entries": int(tl), "verified": bool(ok),
             "h2d_probe_GiB_s": round(h2d_gib, 2), "frac_of_h2d_probe": round(gib / h2d_gib, 3),
-            "note": "csvsimd_stage1_index: pageable host buffer -> pinned staging -> H2D -> kernel -> tape to a pinned "
-                    "slot (D2H copy, or written there by the kernel where those copies are slow) -> caller's tape "
-                    "(chunks pipelined over three streams); PCIe-inclusive, never part of `value`"}
+            "note": "csvsimd_stage1_index: pageable host buffer -> pinned staging -> H2D -> kernel (chunks chained on the "
+                    "device: no host round trip between them) -> tape to a pinned slot -> caller's tape; PCIe-inclusive, "
+                    "never part of `value`"}
 
 
 def consumers_leg(pkg, oracle, device):
@@ -497,6 +578,29 @@ def consumers_leg(pkg, oracle, device):
     res["verified"] = bool(ok)
     ctx.close()
     return res
+
+
+def dense_ceiling(sb):
+    """What bare streams reach with the dense corpus's write share (1.6 B of tape per byte read), next to an
+    INDEPENDENT yardstick: a plain copy — hipMemcpyDtoD and the textbook one-16-byte-element-per-thread
+    kernel, the shape behind the guide's "6.29 TB/s float4 copy" — over the same buffers.  A copy moves 2 bytes per byte
+    read; if it sustains clearly more read + write TB/s than the probe's mixes, the probe is not the ceiling."""
+    ctx, n, s_ = sb.ctx, sb.n, sb.stream()
+    src, dst = sb.dbuf.data_ptr(), sb.dtape.data_ptr()
+    pm = ctx.hbm_probe_device(src, n, dst, 25, s_, 1, 5)
+    pm2 = ctx.hbm_probe_device(src, n, dst, 25, s_, 1, 5, blocks_per_cu=2)
+    ncopy = min(n, sb.cap * 8) // 16 * 16
+    copies = {}
+    for mode, name in ((0, "hipMemcpyDtoD"), (1, "kernel_16B_per_thread"), (2, "kernel_16B_per_thread_nontemporal")):
+        ms = ctx.copy_probe_device(src, dst, ncopy, mode, s_, 2, 10)
+        copies[name + "_read_plus_write_GBps"] = round(2 * ncopy / (ms * 1e-3) / 1e9, 1)
+    return {"hbm_read_frac_16_waves_per_cu": round(n / (pm * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "hbm_read_frac_8_waves_per_cu": round(n / (pm2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "read_plus_write_GBps_16_waves_per_cu": round((n + n * 25 // 16) / (pm * 1e-3) / 1e9, 1),
+            "read_plus_write_GBps_8_waves_per_cu": round((n + n * 25 // 16) / (pm2 * 1e-3) / 1e9, 1),
+            "plain_copy_yardstick": copies, "copy_bytes": ncopy,
+            "note": "bare nt stream writing 25/16 B per byte read, no work at all, and plain copies of the same buffers "
+                    "(2 B moved per byte read): what this GPU's memory system sustains for write-heavy mixes"}
 
 
 def run_sharded(pkg, sb, device, dist_on, rehearsal, comm, steps, warmup):
@@ -614,6 +718,13 @@ def main():
     ap.add_argument("--workload", default="64x31_noquote",
                     choices=["64x31_noquote", "64x31_q10", "16x32_noquote", "16x32_q10", "1024x4_dense"])
     ap.add_argument("--gib-per-gpu", type=float, default=8.0)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): --gib-per-gpu bytes on every rank; strong: ONE file of --total-gib bytes cut "
+                         "into one shard per rank")
+    ap.add_argument("--total-gib", type=float, default=64.0,
+                    help="size of the one file of the strong-scaling legs (BASELINE config 4: 64 GiB)")
+    ap.add_argument("--no-strong-check", action="store_true",
+                    help="skip the strong-scaling leg of the default (weak) line")
     ap.add_argument("--skew", type=int, default=0,
                     help="move every interior shard cut this many bytes to the right (SURVEY §8d: 777)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -668,7 +779,11 @@ def main():
         print(json.dumps({"consumers": consumers_leg(pkg, oracle or graft.load_oracle(), device)}))
         return
 
-    shard_bytes = int(args.gib_per_gpu * 2**30)
+    strong = args.scaling == "strong"
+    # weak (default): every rank holds --gib-per-gpu bytes at every N.  strong: ONE file of --total-gib bytes cut into
+    # `world` contiguous shards — N = 1 indexes the whole of BASELINE config 4 (64 GiB: 64 + 16 GiB of tape fit one
+    # 288 GB GPU), N = 8 takes 8 GiB each: the same file getting faster, not more bytes.
+    shard_bytes = int(args.total_gib * 2**30) // world if strong else int(args.gib_per_gpu * 2**30)
     sb = ShardBench(pkg, device, args.workload, shard_bytes, rank, world, args.skew)
 
     comm = None
@@ -684,12 +799,19 @@ def main():
 
     verified = None if args.no_verify else verify_everything(oracle, sb, state, dist_on, rank, world)
 
-    # ---- roofline leg: the stage-1 kernel alone, HIP events on its own stream -------------------
-    kern_ms = kernel_time_ms(sb, max(5, min(args.steps, 50)))
+    # ---- roofline leg: the stage-1 kernel alone, HIP events on its own stream, on EVERY rank -------
+    kern_ms_mine = kernel_time_ms(sb, max(5, min(args.steps, 50)))
+    per_rank_ms = [kern_ms_mine]
+    if dist_on:
+        gathered_ms = [None] * world
+        dist.all_gather_object(gathered_ms, float(kern_ms_mine))
+        per_rank_ms = [float(x) for x in gathered_ms]
+    # the slowest rank's kernel prices the job (at N = 1 that is the only one)
+    kern_ms = max(per_rank_ms)
     achieved = sb.n / (kern_ms * 1e-3) / 1e9
     entries = state["count"]
     # what this GPU's HBM actually streams with the same traffic shape and no work at all (the tape
-    # shard doubles as the probe's output buffer: it is rewritten by the next launch anyway)
+    # shard doubles as the probe's output buffer: it is rewritten by the next launch anyway); rank 0's GPU only
     probed = None
     if rank == 0 and sb.cap * 8 >= sb.n // 4:
         s_ = sb.stream()
@@ -699,7 +821,8 @@ def main():
         probed = {"read_only_GBps": round(sb.n / (ms_r * 1e-3) / 1e9, 1),
                   "read_with_quarter_written_GBps": round(sb.n / (ms_rw * 1e-3) / 1e9, 1),
                   "read_with_quarter_written_8_waves_per_cu_GBps": round(sb.n / (ms_rw2 * 1e-3) / 1e9, 1),
-                  "kernel_vs_probe": round(achieved / (sb.n / (ms_rw * 1e-3) / 1e9), 3),
+                  "kernel_vs_probe": round(sb.n / (kern_ms_mine * 1e-3) / 1e9 / (sb.n / (ms_rw * 1e-3) / 1e9), 3),
+                  "gpu": "rank 0's",
                   "note": "bare nt stream of the same buffer with none of the work (csvsimd_hbm_probe_device), at the "
                           "kernel's 16 waves/CU and at the 8 waves/CU where a bare stream peaks; the 64x31 corpus "
                           "writes 8 B of tape per 32 B read"}
@@ -708,26 +831,43 @@ def main():
         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": load_traffic(args.workload, sb.n),
         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
         "kernel": pkg.stage1_kernel_name(True), "kernels_per_launch": 1, "kernel_ms": round(kern_ms, 4),
+        "kernel_ms_per_rank": {"min": round(min(per_rank_ms), 4), "max": round(max(per_rank_ms), 4),
+                               "all": [round(x, 4) for x in per_rank_ms],
+                               "note": "every rank times its own launches (HIP events on its stream); `kernel_ms`, "
+                                       "`achieved` and `frac` are the SLOWEST rank's"},
         "entry_point": "csvsimd_stage1_time_device -> launch_stage1 (the product library; probe builds refused)",
         "algorithmic_bytes_per_launch": sb.n,
         "read_plus_tape_write_GBps": round((sb.n + 8 * entries) / (kern_ms * 1e-3) / 1e9, 1),
         "probed_stream": probed,
     }
 
+    if dist_on:
+        backend = dist.get_backend()
+        collective = (f"one all-gather of the 64-byte shard records per step ({backend}"
+                      + (", ncclAllGather from the C ABI" if comm is not None else ", torch.distributed.all_gather_into_tensor")
+                      + f", {dist.get_world_size()} ranks), stitch kernel + conditional re-emit launch on the device")
+    else:
+        backend = None
+        collective = ("none: a single GPU holds the whole file, so the timed step is ONE stage-1 launch + its record's "
+                      "copy-out — no all-gather, no stitch kernel, no re-emit launch (with a world-1 RCCL communicator "
+                      "the same step costs +8 us: profiles/r02_bench_dist_world1_torch.json)")
     out = {
         "metric": "csv_bytes_scanned_per_s", "value": round(gib_s, 3), "unit": "GiB/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {sb.cols} cols x {sb.width}-byte fields, LF rows, "
-                               f"{sb.n / 2**30:.3f} GiB per GPU (BASELINE config 4's per-GPU shard shape)",
+                               f"{sb.n / 2**30:.3f} GiB per GPU"
+                               + (f" = 1/{world} of ONE {total_bytes / 2**30:.0f} GiB file (BASELINE config 4, strong scaling)"
+                                  if strong else " (BASELINE config 4's per-GPU shard shape)"),
                    "bytes_per_gpu": sb.n, "total_bytes": total_bytes, "tape_entries": int(state["total"]),
                    "skew": args.skew,
                    "steps_in_flight": state["pipeline_depth"],   # 2: step i+1 enqueued before step i's record is read
-                   "first_pass": state["first_pass"],
-                   "parallelism": f"chunk-sharded x{world}, one all-gather of shard descriptors, stitch + "
-                                  "conditional re-emit on the device"
-                                  + (" (native RCCL from the C ABI)" if comm is not None else "")
+                   "first_pass": state["first_pass"] if world > 1 else "one rank: the file's entering state is known",
+                   "rccl_world": dist.get_world_size() if (dist_on and backend == "nccl") else None,
+                   "collective_backend": backend,
+                   "parallelism": f"chunk-sharded x{world}; collective: {collective}"
                                   + (" [REHEARSAL: all ranks on one GPU, gloo]" if rehearsal else "")},
         "rows_indexed_per_s": round(rows * args.steps / dt, 1),
         "gib_per_s_per_gpu": round(gib_s / world, 3),
@@ -735,10 +875,15 @@ def main():
         "roofline": roofline,
     }
 
+    # the first 2 GiB of rank 0's shard, on the host, for the CPU baselines and the ingest leg (taken before the
+    # device buffers are recycled by the legs below)
+    sample = host_sample(sb, 2 << 30) if (rank == 0 and not (args.no_cpu_baseline and args.no_ingest)) else None
+    main_width, main_q, main_lo = sb.width, sb.q, sb.lo
+
     # ---- the quoted corpus, cut mid-row: the stitch is non-trivial and ranks re-emit -------------
     failed = verified is not None and not (verified["tape"] and verified["stitch"])
-    if not args.no_q10_check and args.workload == "64x31_noquote" and not args.no_verify:
-        del sb.dtape, sb.dbuf
+    if not args.no_q10_check and args.workload == "64x31_noquote" and not args.no_verify and not strong:
+        sb.release()
         cuts = mid_row_cuts(oracle, pkg, "64x31_q10", shard_bytes, world)
         sbq = ShardBench(pkg, device, "64x31_q10", shard_bytes, rank, world, cuts=cuts)
         k = max(3, min(args.steps, 5))
@@ -755,11 +900,39 @@ def main():
             ms = kernel_time_ms(sbq, 10)
             out["q10_skew_check"]["kernel_ms"] = round(ms, 4)
             out["q10_skew_check"]["hbm_read_frac"] = round(sbq.n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+        sbq.release()
         del sbq
-        # the default corpus again, for the legs below (cpu baseline, ingest)
-        sb = ShardBench(pkg, device, args.workload, shard_bytes, rank, world, args.skew)
+
+    # ---- strong scaling on the config-4 file, in the same run: 64 GiB cut into `world` shards -------------------
+    # (the default line is weak scaling: 8 GiB per GPU at every N.  This leg indexes the SAME 64 GiB file at every N —
+    # all of it on one GPU at N = 1, 8 GiB each at N = 8 — so the driver's N = 1, 2, 4, 8 runs also hold the
+    # speed-up on one file, verified like the main leg.)
+    if not args.no_strong_check and args.workload == "64x31_noquote" and not strong and not args.no_verify:
+        strong_total = int(args.total_gib * 2**30)
+        if strong_total // world == shard_bytes:
+            out["strong_scaling_check"] = {"total_GiB": args.total_gib, "identical_to_main_leg": True,
+                                           "ms_per_step": out["ms_per_step"], "GiB/s": out["value"],
+                                           "note": f"at N = {world} the {args.total_gib:g} GiB file's shards ARE the "
+                                                   "main leg's shards"}
+        else:
+            sb.release()
+            sbs = ShardBench(pkg, device, args.workload, strong_total // world, rank, world)
+            k = max(3, min(args.steps, 5))
+            dts, sts = run_sharded(pkg, sbs, device, dist_on, rehearsal, comm, k, 1)
+            vs = verify_everything(oracle, sbs, sts, dist_on, rank, world)
+            failed = failed or not (vs["tape"] and vs["stitch"])
+            ms = kernel_time_ms(sbs, 5)
+            out["strong_scaling_check"] = {
+                "workload": f"ONE {sbs.total / 2**30:.0f} GiB file of the 64x31 corpus (BASELINE config 4) cut into "
+                            f"{world} contiguous shard(s) of {sbs.n / 2**30:.2f} GiB",
+                "total_bytes": sbs.total, "bytes_per_gpu": sbs.n, "ms_per_step": round(dts / k * 1e3, 4), "steps": k,
+                "GiB/s": round(sbs.total * k / dts / 2**30, 2), "kernel_ms_this_rank": round(ms, 4),
+                "hbm_read_frac_this_rank": round(sbs.n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "verified": vs}
+            sbs.release()
+            del sbs
 
     if rank == 0 and world == 1:
+        sb.release()
         if not args.no_extra:
             extra = {}
             for name in ("16x32_noquote", "16x32_q10", "1024x4_dense"):
@@ -771,30 +944,24 @@ def main():
                                "hbm_read_frac": round(del_sb.n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                                "read_plus_tape_write_GBps": round((del_sb.n + 8 * r.count) / (ms * 1e-3) / 1e9, 1)}
                 if name == "1024x4_dense":
-                    # what a bare stream reaches with this corpus's write share (1.6 B of tape per byte read)
-                    pm = del_sb.ctx.hbm_probe_device(del_sb.dbuf.data_ptr(), del_sb.n, del_sb.dtape.data_ptr(), 25,
-                                                     del_sb.stream(), 1, 5)
-                    pm2 = del_sb.ctx.hbm_probe_device(del_sb.dbuf.data_ptr(), del_sb.n, del_sb.dtape.data_ptr(), 25,
-                                                      del_sb.stream(), 1, 5, blocks_per_cu=2)
-                    extra[name]["probed_stream"] = {
-                        "hbm_read_frac_16_waves_per_cu": round(del_sb.n / (pm * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                        "hbm_read_frac_8_waves_per_cu": round(del_sb.n / (pm2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                        "note": "bare nt stream writing 25/16 B per byte read, no work at all: the ceiling of this "
-                                "traffic mix on this GPU — a read fraction of 0.30 is out of reach of ANY kernel"}
+                    extra[name]["probed_stream"] = dense_ceiling(del_sb)
                 if not args.no_verify:
                     del_sb.run_pass(0)
                     ok, _, _ = torch_reference_compare(del_sb, 0, r.count)
                     extra[name]["verified"] = bool(ok and oracle_windows_compare(oracle, del_sb, 0, r.count))
                     failed = failed or not extra[name]["verified"]
+                del_sb.release()
                 del del_sb
             out["other_workloads"] = extra
             out["consumers"] = consumers_leg(pkg, oracle, device)
             failed = failed or not out["consumers"]["verified"]
         if not args.no_ingest:
-            out["ingest"] = ingest_leg(pkg, sb, 2 << 30)
+            out["ingest"] = ingest_leg(pkg, device, sample, main_width, closed_form=(not main_q and main_lo == 0))
             failed = failed or not out["ingest"]["verified"]
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(oracle, sb, 2 << 30)
+    # ---- the CPU beside it, same bytes, same run, at EVERY N (rank 0's host cores) -------------------------------
+    if rank == 0 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(oracle, sample)
+        out.update(cpu_baseline_variants(oracle, sample, main_width))
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist_on:

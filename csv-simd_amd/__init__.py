@@ -135,6 +135,8 @@ _PROTOTYPES = {
                                                C.c_void_p]),
     "csvsimd_hbm_probe_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                            C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "csvsimd_copy_probe_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_int,
+                                            C.c_int, C.POINTER(C.c_float)]),
     "csvsimd_tape_record_spans_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint64,
                                                    C.c_uint64, C.c_void_p, C.c_void_p, _u64p, C.c_void_p]),
     "csvsimd_stage1_bound": (C.c_int, [C.c_uint64, _u64p]),
@@ -288,6 +290,14 @@ class Context:
         ms = C.c_float()
         _check(lib().csvsimd_hbm_probe_device(self._h, dbuf, length, dout, write_per16, blocks_per_cu, stream or None,
                                               warmup, iters, C.byref(ms)))
+        return float(ms.value)
+
+    def copy_probe_device(self, dsrc: int, ddst: int, length: int, mode: int = 1, stream: int = 0, warmup: int = 2,
+                          iters: int = 10) -> float:
+        """ms per plain copy of `length` bytes: mode 0 = hipMemcpyDtoDAsync, 1 = 16 B per thread, 2 = the same, non-temporal."""
+        ms = C.c_float()
+        _check(lib().csvsimd_copy_probe_device(self._h, dsrc, ddst, length, mode, stream or None, warmup, iters,
+                                               C.byref(ms)))
         return float(ms.value)
 
     def utf8_validate_device(self, dbuf: int, length: int, stream: int = 0) -> Optional[int]:

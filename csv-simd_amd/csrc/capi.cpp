@@ -1238,4 +1238,24 @@ int csvsimd_hbm_probe_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len, v
     });
 }
 
+int csvsimd_copy_probe_device(csvsimd_ctx* ctx, const void* dsrc, void* ddst, uint64_t len, int mode, void* hip_stream,
+                              int warmup, int iters, float* avg_ms) {
+    return csvsimd_guarded([&]() -> int {
+    if (!ctx || !dsrc || !ddst || !avg_ms || iters <= 0 || iters > 4096 || len < 16) return CSVSIMD_ERR_INVALID_ARG;
+    if (mode < 0 || mode > 2 || ((uintptr_t)dsrc & 15) || ((uintptr_t)ddst & 15)) return CSVSIMD_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)hip_stream;
+    for (int i = 0; i < warmup; ++i) HIP_TRY(csvsimd::launch_copy_probe(dsrc, ddst, len, mode, s));
+    EventBatch eb;
+    HIP_TRY(eb.create(2));
+    HIP_TRY(hipEventRecord(eb.ev[0], s));
+    for (int i = 0; i < iters; ++i) HIP_TRY(csvsimd::launch_copy_probe(dsrc, ddst, len, mode, s));
+    HIP_TRY(hipEventRecord(eb.ev[1], s));
+    HIP_TRY(hipEventSynchronize(eb.ev[1]));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, eb.ev[0], eb.ev[1]));
+    *avg_ms = ms / (float)iters;
+    return CSVSIMD_OK;
+    });
+}
+
 }  // extern "C"

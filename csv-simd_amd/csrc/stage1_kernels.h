@@ -73,6 +73,8 @@ hipError_t launch_checksum(const void* dtape, uint64_t n, uint64_t first_index, 
 hipError_t launch_selftest(uint32_t* d_out, hipStream_t stream);
 hipError_t launch_hbm_probe(const void* din, uint64_t len, void* dout, int write_div, void* scratch_base,
                             uint32_t blocks, hipStream_t stream);
+// plain copy yardstick: mode 0 = hipMemcpyDtoDAsync, 1 = one 16-byte element per thread, 2 = the same, non-temporal
+hipError_t launch_copy_probe(const void* din, void* dout, uint64_t len, int mode, hipStream_t stream);
 // csvsimd_stitch_shards on the device (one wave), so the sharded step needs no host round trip
 hipError_t launch_stitch(const void* d_results, uint32_t n_shards, uint32_t rank, uint32_t file_in_quote_in,
                          void* d_stitch, hipStream_t stream);

@@ -1451,6 +1451,19 @@ __global__ __launch_bounds__(256) void hbm_probe_kernel(const uint8_t* __restric
 
 #pragma clang diagnostic pop
 
+// Independent yardstick for the probe above: the textbook copy — one 16-byte element per thread, a
+// grid as large as the buffer, no tickets, no tiles — the shape behind the guide's "6.29 TB/s measured (float4 copy)"
+// (MI355X_MICROARCH.md:36).  NT: non-temporal both ways, as the stage-1 kernel's loads and stores are.
+template <bool NT>
+__global__ __launch_bounds__(256) void copy_probe_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out, u64 n16) {
+    const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n16) return;
+    if (NT)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);
+    else
+        out[i] = in[i];
+}
+
 // self-test of the wavefront primitives against plain loops (one wave); out[0] = failure bits
 __global__ void selftest_kernel(u32* out) {
     __shared__ u32 s_v[64];
@@ -1674,6 +1687,19 @@ hipError_t launch_hbm_probe(const void* din, u64 len, void* dout, int write_div,
     else
         hipLaunchKernelGGL(hbm_probe_kernel<0>, dim3(blocks), dim3(256), 0, stream, (const uint8_t*)din, (uint4*)dout,
                            ctl, tiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_copy_probe(const void* din, void* dout, u64 len, int mode, hipStream_t stream) {
+    const u64 n16 = len / 16;
+    if (n16 == 0) return hipSuccess;
+    if (mode == 0) return hipMemcpyDtoDAsync((hipDeviceptr_t)dout, (hipDeviceptr_t)const_cast<void*>(din), n16 * 16, stream);
+    const u64 blocks = (n16 + 255) / 256;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    if (mode == 2)
+        hipLaunchKernelGGL(copy_probe_kernel<true>, dim3((u32)blocks), dim3(256), 0, stream, (const u32x4*)din, (u32x4*)dout, n16);
+    else
+        hipLaunchKernelGGL(copy_probe_kernel<false>, dim3((u32)blocks), dim3(256), 0, stream, (const u32x4*)din, (u32x4*)dout, n16);
     return hipGetLastError();
 }
 

@@ -104,3 +104,18 @@ def test_closed_form_check_can_fail(bench):
     tape2 = tape.copy()
     tape2[17] += 4
     assert bench.closed_form_compare(_StubShard(torch, data, lo, tape2, width), tape2.size) is False
+
+
+def test_cpu_baseline_variants_time_the_same_bytes(bench, pkg, oracle):
+    """The CPU legs of the bench line (rank 0 at every N): every variant of BASELINE.md §2 runs on the same host
+    sample and finds the same entries; the multi-threaded one states the cores it used."""
+    cols, width, seed, q = pkg.WORKLOADS["64x31_noquote"]
+    n = pkg.workload_len("64x31_noquote", 8 << 20)
+    host = oracle.synth(0, n, cols, width, seed, q)
+    base = bench.cpu_baseline(oracle, host, budget_s=0.05)
+    assert base["cores"] == 1 and base["kind"] == "port" and base["entries"] == n // (width + 1) + 1
+    v = bench.cpu_baseline_variants(oracle, host, width, budget_scale=0.01)
+    assert "native_build_error" not in v, v
+    assert v["cpu_baseline_mt"]["cores"] == bench.cpu_threads() >= 1
+    assert v["cpu_baseline_mt"]["entries"] == v["ref_sse_1t_native"]["entries"] == v["scalar_1t"]["entries"] == base["entries"]
+    assert all(v[k]["value"] > 0 for k in ("cpu_baseline_mt", "ref_sse_1t_native", "scalar_1t"))
