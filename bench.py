@@ -502,12 +502,24 @@ def ingest_leg(pkg, device, host, width, closed_form):
                     "never part of `value`"}
 
 
+def consumer_traffic(key):
+    """HBM bytes per launch of a consumer kernel from the committed PMC profile (separate --pmc passes over
+    `bench.py --only-consumers`, scripts/collect_profiles_consumers.sh), or None."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(p) as f:
+            return json.load(f).get("consumers", {}).get(key)
+    except Exception:
+        return None
+
+
 def consumers_leg(pkg, oracle, device):
     """§8f rank 3 — the reference's stated use of the tape ("frequency counts, and function search",
-    design_notes_1.md:1-4) on a device-resident tape of the 16x32 corpus (1 GiB, 2.03 M records, one column):
-    wall time of the synchronous entry points, best of 3.  Algorithmic bytes per record = its two tape entries
-    (16 B) + its field text; HBM moves whole 64/128-byte sectors of a row-major file, so a single column of a
-    528-byte row cannot come near the streaming roofline — reported, not hidden."""
+    design_notes_1.md:1-4) on a device-resident tape of the 16x32 corpus (1 GiB, 2.03 M records).  ONE pass turns the
+    row-major file + tape into columns (csvsimd_chunk_to_columns_device: every byte of the file and of the tape read
+    once, all 16 columns written); frequency count and search then run on a column with contiguous 16-byte loads.
+    Wall time of the calls incl. their synchronisation, best of 3; algorithmic bytes next to the PMC traffic of the
+    committed profile.  The per-column path of round 2 (a column of the ROW-MAJOR file per call) is timed beside it."""
     name = "16x32_noquote"
     cols, width, seed, q = pkg.WORKLOADS[name]
     n = pkg.workload_len(name, 1 << 30)
@@ -533,11 +545,62 @@ def consumers_leg(pkg, oracle, device):
             t = dt if t is None else min(t, dt)
         return t, out
 
-    alg = nrec * (16 + width)
-    res = {"workload": f"{name} 1 GiB: {nrec} records, column {field} ({width}-byte fields)",
-           "algorithmic_bytes": alg, "note": "bytes per record = 2 tape entries + field text; sector-granular HBM traffic "
-                                             "of one column of a row-major file is several times that"}
-    # spans + gather of the column
+    res = {"workload": f"{name} 1 GiB: {nrec} records x {cols} columns ({width}-byte fields)"}
+    stride = 32
+    # ---- the whole file -> 16 columns, one pass ---------------------------------------------------------------------
+    ccols = torch.empty((cols, nrec, stride), dtype=torch.uint8, device=device)
+    clens = torch.empty((cols, nrec), dtype=torch.int32, device=device)
+    t, _ = best(lambda: pkg.chunk_to_columns_device(ctx, dbytes.data_ptr(), n, args[1], index_len, cols, "LF", whole, None,
+                                                    ccols.data_ptr(), stride, clens.data_ptr()), reps=5)
+    table = dbytes[: rows * cols * (width + 1)].view(rows, cols, width + 1)[1:, :, :width]
+    ok = bool((clens == width).all()) and torch.equal(ccols, table.permute(1, 0, 2).contiguous())
+    del table
+    alg_read = (n - cols * (width + 1)) + 8 * (index_len - cols)          # the data rows' bytes + their tape entries
+    alg_write = cols * nrec * (stride + 4)
+    traffic = consumer_traffic("to_columns_kernel")
+    res["to_columns"] = {"ms": round(t * 1e3, 3), "columns": cols, "stride": stride,
+                         "algorithmic_bytes": {"read": alg_read, "written": alg_write},
+                         "read_plus_write_GBps": round((alg_read + alg_write) / t / 1e9, 1),
+                         "hbm_traffic_bytes_profiled": traffic,
+                         "traffic_over_algorithmic": round(traffic / (alg_read + alg_write), 3) if traffic else None,
+                         "note": "row-major file + tape read once (rows staged through LDS), every column written with "
+                                 "1-KiB wave stores; wall time of the call + synchronisation"}
+    # ---- frequency count of one column (all values distinct: the table's worst case) -------------------------------
+    slots = 1 << 22
+    scratch = torch.empty(pkg.columnar_frequency_scratch_bytes(slots), dtype=torch.uint8, device=device)
+    ent = torch.empty((nrec + 8, 2), dtype=torch.int64, device=device)
+    col_ptr, len_ptr = ccols[field].data_ptr(), clens[field].data_ptr()
+    t, st = best(lambda: pkg.columnar_frequency_device(ctx, col_ptr, len_ptr, nrec, stride, 0, scratch.data_ptr(), slots,
+                                                       ent.data_ptr(), ent.shape[0]))
+    ok = ok and st.n_records == nrec and st.truncated == 0 and int(ent[: st.n_distinct, 1].sum()) == nrec
+    # the CPU definition on a bounded sample: first 50 k records
+    host = dbytes[: 50001 * cols * (width + 1)].cpu().numpy().tobytes()
+    hidx = dindex[: 50001 * cols + 1].cpu().numpy().view(np.uint64)
+    sample = (0, cols, 50001 * cols, 50000)
+    want = oracle.column_frequency(host, hidx, cols, False, [sample], field)
+    st_s = pkg.columnar_frequency_device(ctx, col_ptr, len_ptr, 50000, stride, 0, scratch.data_ptr(), slots, ent.data_ptr(),
+                                         ent.shape[0])
+    got = {oracle.seek_field(host, hidx, cols, False, f_, field): c for f_, c in ent[: st_s.n_distinct].cpu().tolist()}
+    ok = ok and got == dict(want)
+    alg_f = nrec * (stride + 4) + nrec * 16
+    res["frequency_count"] = {"ms": round(t * 1e3, 3), "distinct": int(st.n_distinct),
+                              "algorithmic_bytes": alg_f, "GBps_algorithmic": round(alg_f / t / 1e9, 1),
+                              "hbm_traffic_bytes_profiled": consumer_traffic("colfreq"),
+                              "note": "on the column: memset of the table, insert (one returning atomic per new value; slots "
+                                      "point at a representative record and compare bytes: exact, no verification pass), "
+                                      "compact; algorithmic bytes = the column + its lengths read, 16 B per distinct value "
+                                      "written"}
+    # ---- search -----------------------------------------------------------------------------------------------------
+    needle = host[int(hidx[1000 * cols + field]) + 4: int(hidx[1000 * cols + field]) + 10]
+    bm = torch.zeros((nrec + 63) // 64 + 1, dtype=torch.int64, device=device)
+    t, hits = best(lambda: pkg.columnar_search_device(ctx, col_ptr, len_ptr, nrec, stride, needle, pkg.SEARCH_CONTAINS,
+                                                      bm.data_ptr()))
+    hits_s = pkg.columnar_search_device(ctx, col_ptr, len_ptr, 50000, stride, needle, pkg.SEARCH_CONTAINS, bm.data_ptr())
+    ok = ok and hits >= 1 and hits_s == len(oracle.column_search(host, hidx, cols, False, sample, field, needle, 2))
+    alg_s = nrec * (stride + 4)
+    res["search_contains"] = {"ms": round(t * 1e3, 3), "matches": int(hits), "algorithmic_bytes": alg_s,
+                              "GBps_algorithmic": round(alg_s / t / 1e9, 1)}
+    # ---- round 2's per-column path on the row-major file, for comparison --------------------------------------------
     b = torch.empty(nrec, dtype=torch.int64, device=device)
     e = torch.empty(nrec, dtype=torch.int64, device=device)
     dst = torch.empty(nrec * 32, dtype=torch.uint8, device=device)
@@ -545,36 +608,21 @@ def consumers_leg(pkg, oracle, device):
     def spans_gather():
         pkg.chunk_field_spans_device(args[1], index_len, cols, "LF", whole, field, b.data_ptr(), e.data_ptr())
         pkg.gather_fields_device(args[0], n, b.data_ptr(), e.data_ptr(), nrec, dst.data_ptr(), 32)
-    t, _ = best(spans_gather)
-    ok = bool((e - b == width).all()) and bytes(dst[:32].cpu().numpy()) == bytes(dbytes[int(b[0]): int(e[0])].cpu().numpy())
-    res["spans_plus_gather"] = {"ms": round(t * 1e3, 3), "GBps_algorithmic": round((alg + nrec * 48) / t / 1e9, 1)}
-    # frequency count (all values distinct: the table's worst case)
-    slots = 1 << 22
-    scratch = torch.empty(pkg.column_frequency_scratch_bytes(slots), dtype=torch.uint8, device=device)
-    ent = torch.empty((nrec + 8, 4), dtype=torch.int64, device=device)
-    t, st = best(lambda: pkg.column_frequency_device(ctx, *args, [whole], field, scratch.data_ptr(), slots, ent.data_ptr(),
-                                                     ent.shape[0]))
-    ok = ok and st.n_records == nrec and st.collisions == 0 and int(ent[: st.n_distinct, 3].sum()) == nrec
-    # the CPU definition on a bounded sample: first 50 k records
-    host = dbytes[: 50001 * cols * (width + 1)].cpu().numpy().tobytes()
-    hidx = dindex[: 50001 * cols + 1].cpu().numpy().view(np.uint64)
-    sample = (0, cols, 50001 * cols, 50000)
-    want = oracle.column_frequency(host, hidx, cols, False, [sample], field)
-    st_s = pkg.column_frequency_device(ctx, args[0], args[1], 50001 * cols + 1, cols, "LF", [sample], field,
-                                       scratch.data_ptr(), slots, ent.data_ptr(), ent.shape[0])
-    got = {host[b_: e_]: c for _, b_, e_, c in ent[: st_s.n_distinct].cpu().tolist()}
-    ok = ok and got == dict(want)
-    res["frequency_count"] = {"ms": round(t * 1e3, 3), "distinct": int(st.n_distinct),
-                              "GBps_algorithmic": round(2 * alg / t / 1e9, 1),
-                              "note": "insert pass + byte-for-byte verification pass (exact counts)"}
-    # search
-    needle = host[int(hidx[1000 * cols + field]) + 4: int(hidx[1000 * cols + field]) + 10]
-    bm = torch.zeros((nrec + 63) // 64 + 1, dtype=torch.int64, device=device)
-    t, hits = best(lambda: pkg.column_search_device(ctx, args[0], n, *args[1:], whole, field, needle, pkg.SEARCH_CONTAINS, bm.data_ptr()))
-    hits_s = pkg.column_search_device(ctx, args[0], n, args[1], 50001 * cols + 1, cols, "LF", sample, field, needle,
-                                      pkg.SEARCH_CONTAINS, bm.data_ptr())
-    ok = ok and hits >= 1 and hits_s == len(oracle.column_search(host, hidx, cols, False, sample, field, needle, 2))
-    res["search_contains"] = {"ms": round(t * 1e3, 3), "matches": int(hits), "GBps_algorithmic": round(alg / t / 1e9, 1)}
+    t_g, _ = best(spans_gather)
+    ok = ok and torch.equal(dst.view(nrec, 32), ccols[field])
+    slots_o = 1 << 22
+    scratch_o = torch.empty(pkg.column_frequency_scratch_bytes(slots_o), dtype=torch.uint8, device=device)
+    ent_o = torch.empty((nrec + 8, 4), dtype=torch.int64, device=device)
+    t_f, st_o = best(lambda: pkg.column_frequency_device(ctx, *args, [whole], field, scratch_o.data_ptr(), slots_o,
+                                                         ent_o.data_ptr(), ent_o.shape[0]))
+    ok = ok and st_o.n_distinct == st.n_distinct
+    t_s, hits_o = best(lambda: pkg.column_search_device(ctx, args[0], n, *args[1:], whole, field, needle, pkg.SEARCH_CONTAINS,
+                                                        bm.data_ptr()))
+    ok = ok and hits_o == hits
+    res["per_column_on_row_major_file"] = {"spans_plus_gather_ms": round(t_g * 1e3, 3), "frequency_count_ms": round(t_f * 1e3, 3),
+                                           "search_contains_ms": round(t_s * 1e3, 3),
+                                           "note": "one column per call straight from the row-major file (a 32-byte field of a "
+                                                   "528-byte row costs 1-2 sectors + a slice of tape per record)"}
     res["verified"] = bool(ok)
     ctx.close()
     return res

@@ -105,7 +105,13 @@ class FreqStatus(C.Structure):
                 ("overflow", C.c_uint64)]
 
 
+class ColFreqStatus(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("n_distinct", C.c_uint64), ("truncated", C.c_uint64),
+                ("overflow", C.c_uint64)]
+
+
 SEARCH_EQUALS, SEARCH_STARTS_WITH, SEARCH_CONTAINS = 0, 1, 2
+ABI_VERSION = 3   # what this binding was written against: checked when the library is loaded
 
 # every symbol include/csvsimd.h declares: (restype, argtypes)
 _u64p = C.POINTER(C.c_uint64)
@@ -184,6 +190,15 @@ _PROTOTYPES = {
     "csvsimd_column_search_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int,
                                                C.POINTER(_Chunk), C.c_uint32, C.c_char_p, C.c_uint32, C.c_int,
                                                C.c_void_p, _u64p, C.c_void_p]),
+    "csvsimd_chunk_to_columns_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32,
+                                                  C.c_int, C.POINTER(_Chunk), C.POINTER(C.c_uint32), C.c_uint32,
+                                                  C.c_void_p, C.c_uint32, C.c_void_p, _u64p, C.c_void_p]),
+    "csvsimd_columnar_frequency_scratch_bytes": (C.c_uint64, [C.c_uint64]),
+    "csvsimd_columnar_frequency_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
+                                                    C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                                    C.POINTER(ColFreqStatus), C.c_void_p]),
+    "csvsimd_columnar_search_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_char_p,
+                                                 C.c_uint32, C.c_int, C.c_void_p, _u64p, C.c_void_p]),
     "csvsimd_bitmap_select_scratch_bytes": (C.c_uint64, [C.c_uint64]),
     "csvsimd_bitmap_select_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
                                                _u64p, C.c_void_p]),
@@ -209,6 +224,10 @@ def lib() -> C.CDLL:
         for name, (res, args) in _PROTOTYPES.items():
             fn = getattr(handle, name)  # AttributeError = the ABI lost a symbol
             fn.restype, fn.argtypes = res, args
+        got = handle.csvsimd_abi_version()
+        if got != ABI_VERSION:   # entry points changed their argument lists between versions: never call across them
+            raise OSError(f"{LIB_PATH} reports C ABI version {got}, this binding is written against {ABI_VERSION}: rebuild "
+                          "(__graft_entry__.build())")
         _lib = handle
     return _lib
 
@@ -272,8 +291,9 @@ class Context:
 
     def stage1_reemit_device_async(self, dbuf: int, length: int, base_off: int, d_stitch: int, dtape: int,
                                    tape_cap: int, d_result: int, stream: int = 0) -> None:
-        """Second launch of a sharded step: indexes the shard again as "entered inside a quoted string" iff the
-        DEVICE word d_stitch->in_quote_in is 1 when the kernel starts; otherwise it returns at once."""
+        """Second launch of a sharded step: indexes the shard again, under the entering state d_stitch->in_quote_in, iff
+        the DEVICE word d_stitch->reemit is 1 when the kernel starts (the first pass ran with another state than the
+        true one — a wrong speculation or a wrong ENTER_GUESS, either way round); otherwise it returns at once."""
         _check(lib().csvsimd_stage1_reemit_device_async(self._h, dbuf, length, base_off, d_stitch, dtape or None,
                                                         tape_cap, d_result, stream or None))
 
@@ -593,6 +613,52 @@ def column_search_device(ctx: "Context", dbytes: int, bytes_len: int, dindex: in
                                               NEWLINE_CRLF if new_line == "CRLF" else NEWLINE_LF, C.byref(ch),
                                               field_idx, needle, len(needle), mode, d_bitmap or None, C.byref(n),
                                               stream or None))
+    return n.value
+
+
+def chunk_to_columns_device(ctx: "Context", dbytes: int, bytes_len: int, dindex: int, index_len: int, field_cnt: int,
+                            new_line: str, chunk, fields, d_cols: int, stride: int, d_lens: int = 0,
+                            stream: int = 0) -> int:
+    """Row-major CSV -> columns in one pass over the chunk's bytes and tape: field fields[c] of the chunk's i-th record
+    lands in d_cols[(c * n + i) * stride ...) (truncated, zero padded), its length in d_lens[c * n + i] (uint32).
+    fields = list of field ids, or None for all columns.  Returns n = the chunk's record count.  Asynchronous."""
+    n = C.c_uint64()
+    ch = _chunk(chunk)
+    if fields is None:
+        arr, nf = None, 0
+    else:
+        nf = len(fields)
+        arr = (C.c_uint32 * max(nf, 1))(*fields)
+    _check(lib().csvsimd_chunk_to_columns_device(ctx._h, dbytes, bytes_len, dindex, index_len, field_cnt,
+                                                 NEWLINE_CRLF if new_line == "CRLF" else NEWLINE_LF, C.byref(ch), arr, nf,
+                                                 d_cols or None, stride, d_lens or None, C.byref(n), stream or None))
+    return n.value
+
+
+def columnar_frequency_scratch_bytes(table_slots: int) -> int:
+    return lib().csvsimd_columnar_frequency_scratch_bytes(table_slots)
+
+
+def columnar_frequency_device(ctx: "Context", d_col: int, d_len: int, n_records: int, stride: int, first_record: int,
+                              d_scratch: int, table_slots: int, d_entries: int, entries_cap: int, stream: int = 0,
+                              allow_capacity: bool = False) -> ColFreqStatus:
+    """Exact frequency count of one column of a columnar copy; entries (first_record, count as 2 x uint64) land in
+    d_entries, status.n_distinct of them."""
+    st = ColFreqStatus()
+    rc = lib().csvsimd_columnar_frequency_device(ctx._h, d_col or None, d_len or None, n_records, stride, first_record,
+                                                 d_scratch, table_slots, d_entries or None, entries_cap, C.byref(st),
+                                                 stream or None)
+    if not (rc == ERR_TAPE_CAPACITY and allow_capacity):
+        _check(rc)
+    return st
+
+
+def columnar_search_device(ctx: "Context", d_col: int, d_len: int, n_records: int, stride: int, needle: bytes, mode: int,
+                           d_bitmap: int, stream: int = 0) -> int:
+    """column_search_device on a column of a columnar copy; returns the match count."""
+    n = C.c_uint64()
+    _check(lib().csvsimd_columnar_search_device(ctx._h, d_col or None, d_len or None, n_records, stride, needle,
+                                                len(needle), mode, d_bitmap or None, C.byref(n), stream or None))
     return n.value
 
 

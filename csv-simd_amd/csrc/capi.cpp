@@ -176,7 +176,8 @@ struct csvsimd_ctx {
     uint32_t max_blocks = 0;
     int n_cus = 0;
     csvsimd_shard_result* d_result = nullptr;  // for the synchronous entry points
-    void* d_small = nullptr;                   // 1 KiB: search needle + match counter (consumer entry points)
+    void* d_small = nullptr;                   // 8 KiB: [0, 16) match / truncation counters, [64, 328) search needle,
+                                               // [1024, 5120) field list of csvsimd_chunk_to_columns_device
     // host-buffer path (csvsimd_stage1_index): two-slot pipeline, allocated on first use
     static constexpr uint64_t kChunk = 32ull << 20;  // bytes per slot
     bool pipe_ready = false;                   // every resource below exists
@@ -224,7 +225,7 @@ int csvsimd_device_count(void) {
     return n;
 }
 
-uint32_t csvsimd_abi_version(void) { return 2; }
+uint32_t csvsimd_abi_version(void) { return 3; }
 uint32_t csvsimd_tile_bytes(void) { return CSVSIMD_TILE_BYTES; }
 
 int csvsimd_ctx_create(int device, csvsimd_ctx** out) {
@@ -247,7 +248,7 @@ int csvsimd_ctx_create(int device, csvsimd_ctx** out) {
     const int per_cu = csvsimd::stage1_max_blocks_per_cu();
     ctx->max_blocks = (uint32_t)(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256) * (uint32_t)per_cu;
     HIP_TRY(hipMalloc((void**)&ctx->d_result, sizeof(csvsimd_shard_result)));
-    HIP_TRY(hipMalloc(&ctx->d_small, 1024));
+    HIP_TRY(hipMalloc(&ctx->d_small, 8192));
     *out = ctx.release();
     const int rc = csvsimd_ctx_reserve(*out, 1ull << 30);
     if (rc != CSVSIMD_OK) {
@@ -1030,6 +1031,95 @@ int csvsimd_bitmap_select_device(const void* d_bitmap, uint64_t n_rows, uint64_t
     HIP_TRY(hipMemcpyAsync(n_out, d_total, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return *n_out > out_cap ? CSVSIMD_ERR_TAPE_CAPACITY : CSVSIMD_OK;
+}
+
+/* ---- columnar consumers (columnar_kernels.hip) ------------------------------------------------------------------ */
+
+int csvsimd_chunk_to_columns_device(csvsimd_ctx* ctx, const void* dbytes, uint64_t bytes_len, const void* dindex,
+                                    uint64_t index_len, uint32_t field_cnt, int new_line, const csvsimd_chunk* chunk,
+                                    const uint32_t* fields, uint32_t n_fields, void* d_cols, uint32_t stride, void* d_lens,
+                                    uint64_t* n_records, void* hip_stream) {
+    return csvsimd_guarded([&]() -> int {
+    if (!ctx || !dbytes || !dindex || !n_records) return CSVSIMD_ERR_INVALID_ARG;
+    uint64_t row_size = 0, record_cnt = 0, n = 0;
+    int rc = tape_shape(index_len, field_cnt, new_line, &row_size, &record_cnt);
+    if (rc == CSVSIMD_OK) rc = chunk_rows(chunk, index_len, row_size, &n);
+    if (rc != CSVSIMD_OK) return rc;
+    if (!fields && n_fields == 0) n_fields = field_cnt;  // all columns
+    if (n_fields == 0 || n_fields > 1024 || stride == 0 || (stride & 15u) || stride > 4096) return CSVSIMD_ERR_INVALID_ARG;
+    if (n && (!d_cols || ((uintptr_t)d_cols & 15) || ((uintptr_t)d_lens & 3))) return CSVSIMD_ERR_INVALID_ARG;
+    if (n >= 0xffffffffull) return CSVSIMD_ERR_INVALID_ARG;  // record ids of a chunk are 32-bit (Tape.record_cnt, src/tape.rs:76)
+    if (fields)
+        for (uint32_t i = 0; i < n_fields; ++i)
+            if (fields[i] >= field_cnt) return CSVSIMD_ERR_INVALID_ARG;
+    if (!fields && n_fields > field_cnt) return CSVSIMD_ERR_INVALID_ARG;
+    *n_records = n;
+    if (n == 0) return CSVSIMD_OK;
+    hipStream_t s = (hipStream_t)hip_stream;
+    void* d_fields = nullptr;
+    if (fields) {
+        d_fields = (char*)ctx->d_small + 1024;
+        HIP_TRY(hipMemcpyAsync(d_fields, fields, n_fields * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    }
+    // rows staged per workgroup step: what fits the window on average, with a fifth of it to spare for longer rows
+    const uint64_t avg_row = std::max<uint64_t>(1, bytes_len / std::max<uint64_t>(1, record_cnt));
+    const uint64_t r = std::max<uint64_t>(1, (uint64_t)csvsimd::to_columns_window_bytes() * 4 / 5 / avg_row);
+    HIP_TRY(csvsimd::launch_to_columns(dbytes, bytes_len, dindex, chunk->start, row_size, n, d_fields, n_fields, d_cols,
+                                       stride, d_lens, (uint32_t)std::min<uint64_t>(r, 4096), ctx->n_cus, s));
+    return CSVSIMD_OK;
+    });
+}
+
+uint64_t csvsimd_columnar_frequency_scratch_bytes(uint64_t table_slots) { return table_slots * 16 + 64; }
+
+int csvsimd_columnar_frequency_device(csvsimd_ctx* ctx, const void* d_col, const void* d_len, uint64_t n_records,
+                                      uint32_t stride, uint64_t first_record, void* d_scratch, uint64_t table_slots,
+                                      void* d_entries, uint64_t entries_cap, csvsimd_colfreq_status* status,
+                                      void* hip_stream) {
+    return csvsimd_guarded([&]() -> int {
+    if (!ctx || !d_scratch || !status || (n_records && !d_col) || (entries_cap && !d_entries)) return CSVSIMD_ERR_INVALID_ARG;
+    if (table_slots < 64 || (table_slots & (table_slots - 1)) || ((uintptr_t)d_scratch & 15) || ((uintptr_t)d_entries & 7))
+        return CSVSIMD_ERR_INVALID_ARG;
+    if (stride == 0 || (stride & 15u) || stride > 4096 || ((uintptr_t)d_col & 15) || ((uintptr_t)d_len & 3) ||
+        n_records >= 0xffffffffull)
+        return CSVSIMD_ERR_INVALID_ARG;
+    static_assert(sizeof(csvsimd_colfreq_status) == 32 && sizeof(csvsimd_colfreq_entry) == 16, "layouts shared with the kernels");
+    hipStream_t s = (hipStream_t)hip_stream;
+    void* d_status = (char*)d_scratch + table_slots * 16;
+    HIP_TRY(hipMemsetAsync(d_scratch, 0, table_slots * 16 + 64, s));
+    HIP_TRY(csvsimd::launch_colfreq_insert(d_col, d_len, n_records, stride, d_scratch, table_slots, d_status, ctx->n_cus, s));
+    HIP_TRY(csvsimd::launch_colfreq_compact(d_scratch, table_slots, first_record, d_entries, entries_cap, d_status, s));
+    HIP_TRY(hipMemcpyAsync(status, d_status, sizeof(*status), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (status->overflow) return CSVSIMD_ERR_TAPE_CAPACITY;   // the table is full: call again with more slots
+    if (status->truncated) return CSVSIMD_ERR_TAPE_CAPACITY;  // values longer than the stride: counts would merge them
+    if (status->n_distinct > entries_cap) return CSVSIMD_ERR_TAPE_CAPACITY;
+    return CSVSIMD_OK;
+    });
+}
+
+int csvsimd_columnar_search_device(csvsimd_ctx* ctx, const void* d_col, const void* d_len, uint64_t n_records,
+                                   uint32_t stride, const void* needle, uint32_t needle_len, int mode, void* d_bitmap,
+                                   uint64_t* n_matches, void* hip_stream) {
+    if (!ctx || !n_matches || (n_records && (!d_col || !d_bitmap)) || (needle_len && !needle) || needle_len > 256)
+        return CSVSIMD_ERR_INVALID_ARG;
+    if (mode != CSVSIMD_SEARCH_EQUALS && mode != CSVSIMD_SEARCH_STARTS_WITH && mode != CSVSIMD_SEARCH_CONTAINS)
+        return CSVSIMD_ERR_INVALID_ARG;
+    if (stride == 0 || (stride & 15u) || stride > 4096 || ((uintptr_t)d_col & 15) || ((uintptr_t)d_len & 3) ||
+        ((uintptr_t)d_bitmap & 7))
+        return CSVSIMD_ERR_INVALID_ARG;
+    *n_matches = 0;
+    if (n_records == 0) return CSVSIMD_OK;
+    hipStream_t s = (hipStream_t)hip_stream;
+    uint64_t h[2] = {0, 0};  // matches, records longer than the stride
+    HIP_TRY(hipMemsetAsync(ctx->d_small, 0, 16, s));
+    if (needle_len) HIP_TRY(hipMemcpyAsync((char*)ctx->d_small + 64, needle, needle_len, hipMemcpyHostToDevice, s));
+    HIP_TRY(csvsimd::launch_colsearch(d_col, d_len, n_records, stride, (char*)ctx->d_small + 64, needle_len, mode, d_bitmap,
+                                      ctx->d_small, (char*)ctx->d_small + 8, s));
+    HIP_TRY(hipMemcpyAsync(h, ctx->d_small, 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *n_matches = h[0];
+    return h[1] ? CSVSIMD_ERR_TAPE_CAPACITY : CSVSIMD_OK;  // truncated records: the match is only known for their first `stride` bytes
 }
 
 int csvsimd_trim_spans_device(const void* dbytes, void* d_begin, void* d_end, uint64_t n_records, uint32_t flags,

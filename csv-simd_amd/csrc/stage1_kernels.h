@@ -97,6 +97,18 @@ hipError_t launch_search(const void* dbytes, uint64_t bytes_len, const void* din
                          hipStream_t stream);
 hipError_t launch_bitmap_select(const void* d_bitmap, uint64_t n_rows, uint64_t first_row, void* d_block_scratch,
                                 void* d_out, uint64_t out_cap, void* d_total, hipStream_t stream);
+// columnar_kernels.hip: row-major CSV + tape -> columns in one pass; frequency count and search on a column
+hipError_t launch_to_columns(const void* dbytes, uint64_t bytes_len, const void* dindex, uint64_t first_key, uint64_t jump,
+                             uint64_t n_rows, const void* d_fields, uint32_t n_fields, void* d_cols, uint32_t stride,
+                             void* d_lens, uint32_t rows_per_block, int n_cus, hipStream_t stream);
+uint32_t to_columns_window_bytes();
+hipError_t launch_colfreq_insert(const void* d_col, const void* d_len, uint64_t n_rows, uint32_t stride, void* d_table,
+                                 uint64_t slots, void* d_status, int n_cus, hipStream_t stream);
+hipError_t launch_colfreq_compact(const void* d_table, uint64_t slots, uint64_t first_record, void* d_out, uint64_t out_cap,
+                                  void* d_status, hipStream_t stream);
+hipError_t launch_colsearch(const void* d_col, const void* d_len, uint64_t n_rows, uint32_t stride, const void* d_needle,
+                            uint32_t needle_len, int mode, void* d_bitmap, void* d_count, void* d_truncated,
+                            hipStream_t stream);
 // text_kernels.hip
 hipError_t launch_utf8_validate(const void* dbuf, uint64_t len, void* d_result, int n_cus, hipStream_t stream);
 hipError_t launch_trim_spans(const void* dbytes, void* d_begin, void* d_end, uint64_t n, uint32_t flags,

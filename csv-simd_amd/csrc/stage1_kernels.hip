@@ -657,7 +657,9 @@ struct Control {
     u32 err;       // look-back spin bound hit (atomic or)
     u32 hwm;       // descriptor words possibly dirty since the last wrap of the epoch
     u32 probe_ticket, probe_done;  // csvsimd_hbm_probe_device's own pair
-    u32 guess;     // CSVSIMD_ENTER_GUESS launches: 0 = not decided yet, 2 | s = the workgroup of tile 0 chose state s
+    u32 guess;     // CSVSIMD_ENTER_GUESS launches: 0 = not decided yet, 2 | s = state s was chosen (by the workgroup whose
+                   // aggregate was the last of the shard's first kGuessTiles to arrive)
+    u32 guess_cnt; // ... how many of those aggregates have arrived
 };
 static_assert(sizeof(Control) <= CSVSIMD_SCRATCH_CTL_BYTES, "control block must fit its slot");
 
@@ -672,8 +674,9 @@ struct KernelArgs {
     u64* desc;      // num_tiles words of this context's scratch (epoch-tagged, never zeroed per launch)
     Control* ctl;
     csvsimd_shard_result* result;
-    // optional (sharded re-emit): device word holding the TRUE entering state of this shard.  When
-    // set, the launch does nothing at all unless *state_ptr == 1, and then runs with in_quote_in = 1.
+    // optional (sharded re-emit): the device csvsimd_stitch of this shard.  When set, the launch does nothing at all
+    // unless its `reemit` word (index 9) is 1, and then runs with the stitch's in_quote_in (word 0) — 0 or 1: a wrong
+    // CSVSIMD_ENTER_GUESS can err either way.
     const u32* state_ptr;
     // dialect variants only (DIALECT != 0)
     u32 delim, quote, escape;  // bytes; quote / escape 0 = feature off
@@ -899,6 +902,7 @@ __device__ __forceinline__ void finish_launch(const KernelArgs& args, u32 epoch,
         ctl->done_tot = 0;
         ctl->err = 0;
         ctl->guess = 0;
+        ctl->guess_cnt = 0;
         ctl->hwm = hwm;
         ctl->epoch = next_epoch;
     }
@@ -975,7 +979,45 @@ constexpr u32 kStitchReemitWord = 9;  // csvsimd_stitch::reemit as a u32 index
 static_assert(offsetof(csvsimd_stitch, reemit) == 4 * kStitchReemitWord && offsetof(csvsimd_stitch, in_quote_in) == 0,
               "the re-emit launch reads these two words");
 
-// CSVSIMD_ENTER_GUESS: the choice made by the workgroup that counted tile 0 (Control::guess), once it is there
+// CSVSIMD_ENTER_GUESS: a shard cut out of the middle of a file, entering state unknown.  The shard's first kGuessTiles
+// tiles (2 MiB) vote: each of their workgroups counts itself in after publishing its aggregate (P, A, B); the one whose
+// count completes the set reads the aggregates back, composes them IN ORDER — the counts of tiles 1.. depend on the
+// parity of the tiles before them — and chooses the entering state under which those tiles together hold more entries:
+// read with the wrong quote parity, text outside strings looks quoted and nearly every separator disappears.  (Round 2
+// let tile 0 decide alone: one long quoted field at the start of a shard was enough to fool it; now it takes 2 MiB of
+// them.)  The voters' count phases run concurrently at the start of the launch and wait for nothing, so the choice
+// is there before any workgroup needs it (wave 0 of a workgroup that resolves a tile: wait_for_guess); no tile
+// becomes inclusive before the choice exists, so the words read back here are still aggregates.
+constexpr u32 kGuessTiles = 8;
+__device__ __forceinline__ void guess_vote(u64* desc, Control* ctl, u32 num_tiles, u32 epoch, u32 lane, u32& err) {
+    const u32 voters = num_tiles < kGuessTiles ? num_tiles : kGuessTiles;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's aggregate has left before it is counted in
+    u32 old = 0;
+    if (lane == 0) old = atomicAdd(&ctl->guess_cnt, 1u);
+    old = (u32)__builtin_amdgcn_readfirstlane((int)old);
+    if (old != voters - 1u) return;
+    // one word after the other, in a loop that stays a loop: this runs once per launch, in ONE workgroup, at a point
+    // where wave 0 holds two tiles' masks — a wave-parallel composition here cost the default kernel 4 spilled VGPRs
+    Desc F = {0, 0, 0};
+#pragma unroll 1
+    for (u32 k = 0; k < voters; ++k) {
+        u64 x = 0;
+        for (u32 spins = 0; decode_desc(load_desc(desc + k), epoch, x) != kStatusAgg; ++spins) {
+            // (a word still in flight between two XCDs: look again)
+            if (spins > kSpinLimit) { err = 1; x = 0; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        Desc d;
+        d.p = (u32)x & 1u;
+        d.a = (u32)(x >> 1) & (kHalfMask >> 1);
+        d.b = (u32)(x >> kAggShiftB) & kHalfMask;
+        F = compose(F, d);
+    }
+    if (lane == 0)
+        __hip_atomic_store(&ctl->guess, 2u | (F.b > F.a ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// CSVSIMD_ENTER_GUESS: the choice of the shard's first tiles (Control::guess), once it is there
 __device__ __forceinline__ u32 wait_for_guess(Control* ctl, u32& err) {
     for (u32 spins = 0;; ++spins) {
         const u32 g = (u32)__builtin_amdgcn_readfirstlane(
@@ -1184,20 +1226,14 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
         // Wave 0 publishes this tile's aggregate and REQUESTS the look-back window of the held tile; then every wave
         // scatters its span of the held tile speculatively (see scatter_span_spec) — the 3-5 us the polls take behind the
         // CU's streaming loads used to be seven idle waves at barrier B — and only then does wave 0 consume the window.
-        if (inq_in == kEnterGuess && have_cur && tile == 0u) {
-            // this workgroup counted the first tile of a shard whose entering state nobody knows: it chooses the state
-            // under which that tile has more entries and makes the choice known before anything of tile 0 is published
-            // (inq_in itself stays what the launch passed: a loop-carried copy costs the default kernel 4 spilled VGPRs;
-            // whoever needs the state reads the control word)
-            if (w == 0 && lane == 0)
-                __hip_atomic_store(&args.ctl->guess, 2u | (agg.b > agg.a ? 1u : 0u), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-        }
         if (w == 0) {
             if (have_cur) {
                 if (!(DBG & 4) && lane == 0) publish_aggregate(args.desc, tile, epoch, agg);
                 wg_tot += (u64)(u32)__builtin_amdgcn_readfirstlane((int)(agg.a + agg.b));
             }
+            // a shard whose entering state nobody knows: the first kGuessTiles tiles vote (see guess_vote)
+            if (inq_in == kEnterGuess && have_cur && tile < kGuessTiles && !(DBG & 4))
+                guess_vote(args.desc, args.ctl, args.num_tiles, epoch, lane, err);
             // into wave 0's second stage image: idle until the next count phase
             if (have_held && !(DBG & 4)) lookback_issue(args.desc, held_tile, lane, s_stage_b[0]);
         }

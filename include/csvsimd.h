@@ -47,7 +47,8 @@ extern "C" {
 const char* csvsimd_strerror(int code);
 const char* csvsimd_last_error(void); /* thread-local text of the last HIP failure */
 int csvsimd_device_count(void);       /* number of HIP devices visible, 0 if none */
-uint32_t csvsimd_abi_version(void); /* 2: csvsimd_stitch grew an error field; device-side stitch / re-emit */
+uint32_t csvsimd_abi_version(void); /* 3: + columnar consumers, copy yardstick (2: csvsimd_stitch grew an error field;
+                                       device-side stitch / re-emit).  Bindings should check it when they load the library */
 /* bytes one workgroup indexes per look-back step (informational: tests probe sizes around it) */
 uint32_t csvsimd_tile_bytes(void);
 
@@ -80,9 +81,9 @@ typedef struct csvsimd_shard_result {
 
 /* in_quote_in of the device entry points: 0 = the shard starts outside a quoted string, 1 = inside one,
  * CSVSIMD_ENTER_GUESS = unknown (a shard cut out of the middle of a file, README.md:24 "splitting work without first
- * knowing record breaks"): the kernel indexes the shard under the entering state for which its FIRST tile (256 KiB)
- * has more entries — read with the wrong quote parity, text outside strings looks quoted and nearly every separator
- * disappears — and reports the choice in in_quote_in_used.  `count`, `in_quote_out` and the tape are those of that
+ * knowing record breaks"): the kernel indexes the shard under the entering state for which its first EIGHT tiles
+ * (2 MiB; their quote parities and counts composed in order) hold more entries — read with the wrong quote parity, text
+ * outside strings looks quoted and nearly every separator disappears — and reports the choice in in_quote_in_used.  `count`, `in_quote_out` and the tape are those of that
  * state; the two hypothesis counts and quote_parity are state independent as always.  A wrong guess is found by the
  * stitch (csvsimd_stitch.reemit) and costs the re-emit launch, exactly like a wrong in_quote_in = 0 speculation. */
 #define CSVSIMD_ENTER_OUTSIDE 0u
@@ -335,6 +336,49 @@ int csvsimd_column_search_device(csvsimd_ctx* ctx, const void* dbytes, uint64_t 
 uint64_t csvsimd_bitmap_select_scratch_bytes(uint64_t n_rows);
 int csvsimd_bitmap_select_device(const void* d_bitmap, uint64_t n_rows, uint64_t first_record, void* d_scratch,
                                  void* d_out, uint64_t out_cap, uint64_t* n_out, void* hip_stream);
+
+/* ---- row-major CSV -> columns in ONE pass, and the two consumers on a column ------------------------------------
+ * The per-column entry points above re-read the row-major file once per column (a 32-byte field of a 528-byte row
+ * costs one or two 64-byte sectors plus a slice of tape per record).  csvsimd_chunk_to_columns_device reads a chunk's
+ * bytes and its slice of the tape ONCE (whole rows staged through LDS) and writes every requested column:
+ *     field fields[c] of the chunk's i-th record -> d_cols[(c * n + i) * stride ...), truncated to stride, zero padded,
+ *     its untruncated length -> d_lens[c * n + i] (uint32; d_lens may be NULL),      n = *n_records = chunk->record_cnt.
+ * Field text is RecordSource::seek_field's (src/record_source.rs:106-140), quotes included.  fields = HOST array of
+ * n_fields <= 1024 field ids; fields == NULL: the first n_fields columns (n_fields 0 = all field_cnt of them).  stride: a
+ * multiple of 16, <= 4096; d_cols 16-byte aligned.  Asynchronous on hip_stream (nothing is waited for).  Frequency
+ * count and search then run on a column with contiguous 16-byte loads (below), and any columnar engine can take the
+ * buffers as they are. */
+int csvsimd_chunk_to_columns_device(csvsimd_ctx* ctx, const void* dbytes, uint64_t bytes_len, const void* dindex,
+                                    uint64_t index_len, uint32_t field_cnt, int new_line, const csvsimd_chunk* chunk,
+                                    const uint32_t* fields, uint32_t n_fields, void* d_cols, uint32_t stride, void* d_lens,
+                                    uint64_t* n_records, void* hip_stream);
+/* Frequency count of one column of such a copy (d_col = n_records x stride bytes, d_len = its lengths or NULL for
+ * fixed-width keys): one entry per DISTINCT value (length + bytes) with the number of records that hold it and the FIRST
+ * record that does (first_record + its position in the column; the value's text is that row of the column).  EXACT by
+ * construction: a table slot points at a representative record and is a value's only if the bytes are equal, so a hash
+ * collision costs a probe, never a wrong count — no verification pass, no retry.  design_notes_1.md:1-4; definition
+ * checked against collections.Counter over seek_field.
+ *   d_scratch : csvsimd_columnar_frequency_scratch_bytes(table_slots) bytes, 16-byte aligned; table_slots a power of two
+ *               >= 64, ~2x the number of distinct values (CSVSIMD_ERR_TAPE_CAPACITY if it fills: status->overflow)
+ *   d_entries : entries_cap csvsimd_colfreq_entry, unordered; status->n_distinct are valid
+ * CSVSIMD_ERR_TAPE_CAPACITY also if status->truncated records are longer than the stride (their counts would merge
+ * values that differ past it: transpose with a larger stride).  Synchronous on hip_stream. */
+typedef struct csvsimd_colfreq_entry {
+    uint64_t first_record, count;
+} csvsimd_colfreq_entry;
+typedef struct csvsimd_colfreq_status {
+    uint64_t n_records, n_distinct, truncated, overflow;
+} csvsimd_colfreq_status;
+uint64_t csvsimd_columnar_frequency_scratch_bytes(uint64_t table_slots);
+int csvsimd_columnar_frequency_device(csvsimd_ctx* ctx, const void* d_col, const void* d_len, uint64_t n_records,
+                                      uint32_t stride, uint64_t first_record, void* d_scratch, uint64_t table_slots,
+                                      void* d_entries, uint64_t entries_cap, csvsimd_colfreq_status* status,
+                                      void* hip_stream);
+/* csvsimd_column_search_device on a column of the columnar copy: bit i of d_bitmap = record i matches; same modes and
+ * definitions.  CSVSIMD_ERR_TAPE_CAPACITY (bitmap and *n_matches still written) if some record is longer than the stride. */
+int csvsimd_columnar_search_device(csvsimd_ctx* ctx, const void* d_col, const void* d_len, uint64_t n_records,
+                                   uint32_t stride, const void* needle, uint32_t needle_len, int mode, void* d_bitmap,
+                                   uint64_t* n_matches, void* hip_stream);
 
 /* Trims every span [d_begin[i], d_end[i]) in place: CSVSIMD_TRIM_SPACE drops leading / trailing
  * 0x20 bytes — the reference's class 4, whose legend says `todo: trim " xx "`

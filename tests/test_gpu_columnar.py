@@ -1,0 +1,221 @@
+"""Row-major CSV -> columns in one pass (csvsimd_chunk_to_columns_device) and the two consumers on a column, against
+the scalar definitions in oracle/: every cell is seek_field's text (src/record_source.rs:106-140) truncated / zero padded,
+the frequency count is collections.Counter, the search is == / startswith / `in` (reference design_notes_1.md:1-4,
+src/tape.rs:12-19, 95-140).  Never checked against the product's own per-column consumers."""
+import numpy as np
+import pytest
+
+from test_gpu_consumers import DeviceTape, make_csv
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def transpose(ctx, pkg, torch, dt, chunk, fields, stride, with_lens=True):
+    n = chunk[3]
+    nf = dt.field_cnt if fields is None else len(fields)
+    cols = torch.full((nf, n, stride), 0xEE, dtype=torch.uint8, device="cuda:0")
+    lens = torch.full((nf, n), -1, dtype=torch.int32, device="cuda:0") if with_lens else None
+    dbytes, dindex, index_len, field_cnt, new_line = dt.args()
+    got_n = pkg.chunk_to_columns_device(ctx, dbytes, len(dt.data), dindex, index_len, field_cnt, new_line, chunk, fields,
+                                        cols.data_ptr(), stride, lens.data_ptr() if with_lens else 0)
+    torch.cuda.synchronize()
+    assert got_n == n
+    return cols, lens
+
+
+def check_cells(oracle, dt, chunk, fields, stride, cols, lens):
+    flist = list(range(dt.field_cnt)) if fields is None else list(fields)
+    h = cols.cpu().numpy()
+    hl = lens.cpu().numpy() if lens is not None else None
+    for i, rec in enumerate(oracle.chunk_record_ids(chunk, dt.field_cnt, dt.crlf)):
+        for c, f in enumerate(flist):
+            text = oracle.seek_field(dt.data, dt.index, dt.field_cnt, dt.crlf, rec, f)
+            want = text[:stride] + b"\0" * (stride - min(len(text), stride))
+            assert h[c, i].tobytes() == want, (rec, f, text)
+            if hl is not None:
+                assert int(hl[c, i]) == len(text)
+
+
+@pytest.mark.parametrize("line_end", [b"\n", b"\r\n"])
+def test_every_cell_is_seek_field(ctx, pkg, oracle, torch_cuda, line_end):
+    torch = torch_cuda
+    rng = np.random.default_rng(31)
+    dt = DeviceTape(ctx, pkg, torch, make_csv(rng, 1500, line_end))
+    for n_chunks in (1, 3, 7):
+        for ch in dt.tape.chunks(n_chunks):
+            for fields, stride in ((None, 32), ([3, 1], 16), ([2, 2, 0], 48), ([1], 16)):
+                cols, lens = transpose(ctx, pkg, torch, dt, ch, fields, stride)
+                check_cells(oracle, dt, ch, fields, stride, cols, lens)
+    # without the length array, and the first n_fields columns by count
+    ch = dt.tape.chunks(1)[0]
+    cols, _ = transpose(ctx, pkg, torch, dt, ch, None, 64, with_lens=False)
+    check_cells(oracle, dt, ch, None, 64, cols, None)
+
+
+def test_rows_that_do_not_fit_the_window_take_the_global_path(ctx, pkg, oracle, torch_cuda):
+    """Rows longer than the 32-KiB window, and more columns than the 4096 staged tape entries: same cells."""
+    torch = torch_cuda
+    rng = np.random.default_rng(5)
+    rows = [b"a,b,c"]
+    for r in range(40):
+        big = bytes(rng.integers(97, 123, size=int(rng.integers(30000, 70000)), dtype=np.uint8)) if r % 3 == 0 else b"s%d" % r
+        rows.append(b"%d,%s,x%d" % (r, big, r))
+    dt = DeviceTape(ctx, pkg, torch, b"\n".join(rows) + b"\n")
+    for ch in dt.tape.chunks(2):
+        cols, lens = transpose(ctx, pkg, torch, dt, ch, None, 64)
+        check_cells(oracle, dt, ch, None, 64, cols, lens)
+    wide = [b",".join(b"h%d" % c for c in range(5000))]
+    for r in range(6):
+        wide.append(b",".join(b"%d" % ((r * 7919 + c) % 1000) for c in range(5000)))
+    dt = DeviceTape(ctx, pkg, torch, b"\n".join(wide) + b"\n")
+    ch = dt.tape.chunks(1)[0]
+    fields = [0, 1, 4095, 4096, 4097, 4999]
+    cols, lens = transpose(ctx, pkg, torch, dt, ch, fields, 16)
+    check_cells(oracle, dt, ch, fields, 16, cols, lens)
+
+
+def test_any_alignment_of_the_byte_buffer(ctx, pkg, oracle, torch_cuda):
+    torch = torch_cuda
+    rng = np.random.default_rng(77)
+    data = make_csv(rng, 300, b"\n")
+    base = DeviceTape(ctx, pkg, torch, data)
+    for off in (1, 5, 15):
+        shifted = torch.zeros(len(data) + 32, dtype=torch.uint8, device="cuda:0")
+        shifted[off: off + len(data)] = base.dbytes
+        ch = base.tape.chunks(1)[0]
+        n = ch[3]
+        cols = torch.zeros((base.field_cnt, n, 32), dtype=torch.uint8, device="cuda:0")
+        lens = torch.zeros((base.field_cnt, n), dtype=torch.int32, device="cuda:0")
+        pkg.chunk_to_columns_device(ctx, shifted.data_ptr() + off, len(data), base.dindex.data_ptr(), base.index.size,
+                                    base.field_cnt, base.new_line, ch, None, cols.data_ptr(), 32, lens.data_ptr())
+        torch.cuda.synchronize()
+        check_cells(oracle, base, ch, None, 32, cols, lens)
+
+
+def test_columnar_frequency_is_counter(ctx, pkg, oracle, torch_cuda):
+    torch = torch_cuda
+    rng = np.random.default_rng(2025)
+    dt = DeviceTape(ctx, pkg, torch, make_csv(rng, 6000, b"\n"))
+    ch = dt.tape.chunks(1)[0]
+    n = ch[3]
+    stride = 48   # every field of make_csv is <= 40 bytes
+    cols, lens = transpose(ctx, pkg, torch, dt, ch, None, stride)
+    first_record = ch[1] // dt.tape.record_jump_size - 1
+    for f, slots in ((1, 64), (2, 16384), (3, 256), (0, 16384)):
+        want = oracle.column_frequency(dt.data, dt.index, dt.field_cnt, dt.crlf, [ch], f)
+        scratch = torch.empty(pkg.columnar_frequency_scratch_bytes(slots), dtype=torch.uint8, device="cuda:0")
+        ent = torch.zeros((len(want) + 3, 2), dtype=torch.int64, device="cuda:0")
+        st = pkg.columnar_frequency_device(ctx, cols[f].data_ptr(), lens[f].data_ptr(), n, stride, first_record,
+                                           scratch.data_ptr(), slots, ent.data_ptr(), ent.shape[0])
+        assert (st.n_records, st.n_distinct, st.truncated, st.overflow) == (n, len(want), 0, 0)
+        got = {}
+        for first, cnt in ent[: st.n_distinct].cpu().tolist():
+            text = oracle.seek_field(dt.data, dt.index, dt.field_cnt, dt.crlf, first, f)
+            assert text not in got
+            got[text] = cnt
+            # the entry names the FIRST record holding the value
+            assert all(oracle.seek_field(dt.data, dt.index, dt.field_cnt, dt.crlf, r, f) != text for r in range(first))
+        assert got == dict(want)
+    # capacity protocol: a table smaller than the number of distinct values fills up, loudly
+    scratch = torch.empty(pkg.columnar_frequency_scratch_bytes(1024), dtype=torch.uint8, device="cuda:0")
+    ent = torch.zeros((8, 2), dtype=torch.int64, device="cuda:0")
+    with pytest.raises(pkg.StructureError) as e:
+        pkg.columnar_frequency_device(ctx, cols[2].data_ptr(), lens[2].data_ptr(), n, stride, 0, scratch.data_ptr(), 1024,
+                                      ent.data_ptr(), 8)
+    assert e.value.code == pkg.ERR_TAPE_CAPACITY
+    # too few output entries: the status says how many are needed
+    scratch = torch.empty(pkg.columnar_frequency_scratch_bytes(16384), dtype=torch.uint8, device="cuda:0")
+    st = pkg.columnar_frequency_device(ctx, cols[1].data_ptr(), lens[1].data_ptr(), n, stride, 0, scratch.data_ptr(), 16384,
+                                       ent.data_ptr(), 2, allow_capacity=True)
+    assert st.n_distinct == len(oracle.column_frequency(dt.data, dt.index, dt.field_cnt, dt.crlf, [ch], 1)) > 2
+    # a stride shorter than some values: the count would merge values that differ past it -> refused, and counted
+    short, slens = transpose(ctx, pkg, torch, dt, ch, [2], 16)
+    st = pkg.columnar_frequency_device(ctx, short[0].data_ptr(), slens[0].data_ptr(), n, 16, 0, scratch.data_ptr(), 16384,
+                                       ent.data_ptr(), 8, allow_capacity=True)
+    assert st.truncated == int((slens[0] > 16).sum())  and st.truncated > 0
+
+
+def test_columnar_frequency_same_hash_tag_never_merges(ctx, pkg, torch_cuda):
+    """Fixed-width keys without a length array; many records, few values, and values that differ in one late byte."""
+    torch = torch_cuda
+    rng = np.random.default_rng(9)
+    n, stride = 200_000, 32
+    vocab = rng.integers(0, 256, size=(300, stride), dtype=np.uint8)
+    vocab[150:] = vocab[:150]
+    vocab[150:, 31] ^= 1                      # pairs that differ in the last byte only
+    pick = rng.integers(0, 300, size=n)
+    col = torch.from_numpy(vocab[pick]).cuda()
+    scratch = torch.empty(pkg.columnar_frequency_scratch_bytes(1024), dtype=torch.uint8, device="cuda:0")
+    ent = torch.zeros((400, 2), dtype=torch.int64, device="cuda:0")
+    st = pkg.columnar_frequency_device(ctx, col.data_ptr(), 0, n, stride, 1000, scratch.data_ptr(), 1024, ent.data_ptr(), 400)
+    want = np.bincount(pick, minlength=300)
+    first = {v: int(np.flatnonzero(pick == v)[0]) for v in range(300)}
+    assert st.n_distinct == int((want > 0).sum()) and st.n_records == n
+    got = {int(f) - 1000: int(c) for f, c in ent[: st.n_distinct].cpu().tolist()}
+    assert got == {first[v]: int(want[v]) for v in range(300) if want[v]}
+
+
+def test_columnar_search(ctx, pkg, oracle, torch_cuda):
+    torch = torch_cuda
+    rng = np.random.default_rng(404)
+    dt = DeviceTape(ctx, pkg, torch, make_csv(rng, 5000, b"\r\n"))
+    stride = 48
+    for ch in dt.tape.chunks(3):
+        n = ch[3]
+        cols, lens = transpose(ctx, pkg, torch, dt, ch, None, stride)
+        first_record = ch[1] // dt.tape.record_jump_size - 1
+        for f, needle, mode in ((1, b"Oslo", pkg.SEARCH_EQUALS), (1, b"Os", pkg.SEARCH_STARTS_WITH),
+                                (3, b"needle", pkg.SEARCH_CONTAINS), (1, b"", pkg.SEARCH_EQUALS),
+                                (1, b"", pkg.SEARCH_CONTAINS), (2, b"qz", pkg.SEARCH_CONTAINS),
+                                (1, b'"Washington, D.C."', pkg.SEARCH_EQUALS), (3, b"yy", pkg.SEARCH_CONTAINS),
+                                (1, b"ashington, D.C", pkg.SEARCH_CONTAINS), (1, b'"Washington', pkg.SEARCH_STARTS_WITH),
+                                (3, b"hayy", pkg.SEARCH_CONTAINS), (3, b"xneedleyy", pkg.SEARCH_CONTAINS),
+                                (2, b"abcdefghijklmnopqrstuvwxyzabcdefghijklmnopqrstuvwxyz", pkg.SEARCH_CONTAINS)):
+            want = oracle.column_search(dt.data, dt.index, dt.field_cnt, dt.crlf, ch, f, needle, mode)
+            bm = torch.zeros((n + 63) // 64 + 1, dtype=torch.int64, device="cuda:0")
+            got_n = pkg.columnar_search_device(ctx, cols[f].data_ptr(), lens[f].data_ptr(), n, stride, needle, mode,
+                                               bm.data_ptr())
+            assert got_n == len(want), (needle, mode)
+            scratch = torch.empty(pkg.bitmap_select_scratch_bytes(n), dtype=torch.uint8, device="cuda:0")
+            ids = torch.full((got_n + 2,), -1, dtype=torch.int64, device="cuda:0")
+            k = pkg.bitmap_select_device(bm.data_ptr(), n, first_record, scratch.data_ptr(), ids.data_ptr(), got_n + 2)
+            assert k == got_n and ids[:k].cpu().tolist() == want
+    # a stride shorter than some records: refused (the bitmap only speaks for the first `stride` bytes)
+    ch = dt.tape.chunks(1)[0]
+    short, slens = transpose(ctx, pkg, torch, dt, ch, [2], 16)
+    bm = torch.zeros((ch[3] + 63) // 64 + 1, dtype=torch.int64, device="cuda:0")
+    with pytest.raises(pkg.StructureError) as e:
+        pkg.columnar_search_device(ctx, short[0].data_ptr(), slens[0].data_ptr(), ch[3], 16, b"a", pkg.SEARCH_CONTAINS,
+                                   bm.data_ptr())
+    assert e.value.code == pkg.ERR_TAPE_CAPACITY
+
+
+def test_synthetic_corpus_all_columns_at_once(ctx, pkg, torch_cuda):
+    """127 k records of the 16x32 corpus, all 16 columns in one pass: every cell against plain slicing of the
+    fixed-pitch rows (the corpus' closed form), lengths all 32."""
+    torch = torch_cuda
+    cols_, width, seed, q = pkg.WORKLOADS["16x32_noquote"]
+    n = pkg.workload_len("16x32_noquote", 64 << 20)
+    dbytes = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    pkg.synth_fill_device(dbytes.data_ptr(), 0, n, cols_, width, seed, q)
+    entries = n // (width + 1)
+    dindex = torch.zeros(entries + 2, dtype=torch.int64, device="cuda:0")
+    r = ctx.stage1_index_device(dbytes.data_ptr(), n, 0, 0, dindex.data_ptr() + 8, entries + 1)
+    rows = r.count // cols_
+    nrec = rows - 1
+    whole = (0, cols_, rows * cols_, nrec)
+    out = torch.zeros((cols_, nrec, 32), dtype=torch.uint8, device="cuda:0")
+    lens = torch.zeros((cols_, nrec), dtype=torch.int32, device="cuda:0")
+    got = pkg.chunk_to_columns_device(ctx, dbytes.data_ptr(), n, dindex.data_ptr(), r.count + 1, cols_, "LF", whole, None,
+                                      out.data_ptr(), 32, lens.data_ptr())
+    torch.cuda.synchronize()
+    assert got == nrec and bool((lens == width).all())
+    table = dbytes.view(rows, cols_, width + 1)[1:, :, :width]           # row-major: record, column, byte
+    assert torch.equal(out, table.permute(1, 0, 2).contiguous())

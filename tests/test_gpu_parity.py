@@ -203,10 +203,11 @@ def test_speculative_scatter_guesses(ctx, torch_cuda, pkg, oracle):
             assert np.array_equal(got, want), (tail, inq)
 
 
-def test_enter_guess_chooses_the_state_of_the_first_tile(ctx, torch_cuda, pkg, oracle):
-    """CSVSIMD_ENTER_GUESS: a shard whose entering state nobody knows is indexed under the state for which its FIRST
-    tile has more entries; the record says which one was used, and count / tape / leaving state are the oracle's for
-    THAT state — whether the guess is the truth (shards cut out of a quoted CSV anywhere) or not (adversarial)."""
+def test_enter_guess_chooses_the_state_of_the_first_tiles(ctx, torch_cuda, pkg, oracle):
+    """CSVSIMD_ENTER_GUESS: a shard whose entering state nobody knows is indexed under the state for which its first
+    EIGHT tiles (2 MiB), composed in order, hold more entries; the record says which one was used, and count / tape /
+    leaving state are the oracle's for THAT state — whether the guess is the truth (shards cut out of a quoted CSV
+    anywhere; a first tile that lies, outvoted by the tiles behind it) or not (2 MiB of lying tiles)."""
     T = pkg.tile_bytes()
     rng = np.random.default_rng(808)
     # a quoted CSV: 10 % of the 30-byte fields are quoted and hold a comma and a line break
@@ -231,12 +232,37 @@ def test_enter_guess_chooses_the_state_of_the_first_tile(ctx, torch_cuda, pkg, o
         assert (r.count, r.in_quote_out, r.error) == (want.size, q, 0) and np.array_equal(got, want), cut
         p, c0, c1 = oracle.shard_descriptor(d)
         assert (r.quote_parity, r.count_enter_outside, r.count_enter_inside) == (p, c0, c1)
-    # adversarial: first tile = one long quoted field full of commas, truly entered OUTSIDE: the guess says "inside"
-    b = np.full(2 * T + 333, ord("y"), dtype=np.uint8)
-    b[8:T - 32:24] = 0x2C
-    b[6] = 0x22
-    b[T - 2] = 0x22
-    b[T:] = np.frombuffer((b"aaaa,bbbb\n" * (T // 10 + 40))[: T + 333], dtype=np.uint8)
+
+    def lying_tiles(k, truly_inside):
+        """k tiles that are ONE long quoted field full of commas (a comma every 24 bytes), then plain rows.
+        truly_inside False: the field opens at byte 6 -> entered OUTSIDE, yet those tiles have ~0 entries "outside" and
+        thousands "inside".  True: the shard starts in the middle of that field (entered INSIDE): the tiles have no
+        entries "inside" and thousands "outside"."""
+        body = np.full(k * T, ord("y"), dtype=np.uint8)
+        body[8:k * T - 32:24] = 0x2C
+        if not truly_inside:
+            body[6] = 0x22
+        body[k * T - 2] = 0x22
+        rows = np.frombuffer((b"aaaa,bbbb\n" * ((9 * T) // 10 + 40))[: 9 * T + 333], dtype=np.uint8)
+        return np.concatenate([body, rows])
+
+    # tile 0 lies, the tiles behind it tell the truth: round 2's one-tile vote chose wrong here, eight tiles do not
+    for truly_inside in (False, True):
+        for k in (1, 3):
+            b = lying_tiles(k, truly_inside)
+            got, r = gpu_index(ctx, torch_cuda, b, in_quote_in=pkg.ENTER_GUESS)
+            assert r.in_quote_in_used == int(truly_inside), (k, truly_inside)
+            want, q = oracle.scalar_index(b, in_quote_in=int(truly_inside))
+            assert (r.count, r.in_quote_out) == (want.size, q) and np.array_equal(got, want), (k, truly_inside)
+    # the same with only two tiles behind the lying one (a shard of three tiles: all three vote)
+    b = lying_tiles(1, False)[: 2 * T + 333]
+    got, r = gpu_index(ctx, torch_cuda, b, in_quote_in=pkg.ENTER_GUESS)
+    assert r.in_quote_in_used == 0
+    want, q = oracle.scalar_index(b, in_quote_in=0)
+    assert (r.count, r.in_quote_out) == (want.size, q) and np.array_equal(got, want)
+    # adversarial for good: ALL eight voting tiles lie (2 MiB inside one quoted field, truly entered outside): the guess
+    # says "inside", says so in the record, and everything is the oracle's for THAT state — the stitch then re-emits
+    b = lying_tiles(8, False)
     got, r = gpu_index(ctx, torch_cuda, b, in_quote_in=pkg.ENTER_GUESS)
     assert r.in_quote_in_used == 1
     want, q = oracle.scalar_index(b, in_quote_in=1)
@@ -258,6 +284,12 @@ def test_enter_guess_chooses_the_state_of_the_first_tile(ctx, torch_cuda, pkg, o
     got, r = gpu_index(ctx, torch_cuda, small, in_quote_in=pkg.ENTER_GUESS)
     want, q = oracle.scalar_index(small, in_quote_in=1)
     assert r.in_quote_in_used == 1 and np.array_equal(got, want)
+    # back-to-back launches: the vote counter is reset by every launch (the second shard has other tiles)
+    for _ in range(3):
+        for truly_inside in (False, True):
+            b = lying_tiles(1, truly_inside)
+            got, r = gpu_index(ctx, torch_cuda, b, in_quote_in=pkg.ENTER_GUESS)
+            assert r.in_quote_in_used == int(truly_inside)
 
 
 def test_tape_capacity_and_count_only(ctx, torch_cuda, pkg, oracle):
