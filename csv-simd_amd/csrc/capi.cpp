@@ -81,50 +81,93 @@ static void copy_streaming(char* dst, const char* src, size_t n) {
     if (n - body) memcpy(dst + body, src + body, n - body);
 }
 
-// Host-side copies of the ingest pipeline (user buffer -> pinned staging, pinned tape -> user tape).
-// One thread moves ~10-20 GB/s, less than the PCIe link it feeds, so the copies are sliced over a few
+// 32-bit chunk-relative tape offsets (as the narrow kernel left them in the pinned slot) -> the caller's tape: u64, absolute.
+// Streaming stores like copy_streaming: the destination is 8-byte aligned, head and tail entries go one by one.
+static void expand_streaming(uint64_t* dst, const uint32_t* src, size_t n, uint64_t base) {
+    size_t i = 0;
+    for (; i < n && ((uintptr_t)(dst + i) & 15u); ++i) dst[i] = base + src[i];
+    const __m128i vb = _mm_set1_epi64x((long long)base), zero = _mm_setzero_si128();
+    for (; i + 4 <= n; i += 4) {
+        const __m128i v = _mm_loadu_si128((const __m128i*)(src + i));
+        _mm_stream_si128((__m128i*)(dst + i), _mm_add_epi64(_mm_unpacklo_epi32(v, zero), vb));
+        _mm_stream_si128((__m128i*)(dst + i + 2), _mm_add_epi64(_mm_unpackhi_epi32(v, zero), vb));
+    }
+    _mm_sfence();
+    for (; i < n; ++i) dst[i] = base + src[i];
+}
+
+// Host-side copies of the ingest pipeline (user buffer -> pinned staging, pinned 32-bit tape -> user tape).
+// One thread moves ~10-30 GB/s, less than the PCIe link it feeds, so the copies are sliced over a few
 // persistent workers (measured on the MI355X host: 22 -> 39 GiB/s host buffer to tape).
 class CopyPool {
 public:
     explicit CopyPool(int workers) {
-        for (int i = 0; i < workers; ++i) threads_.emplace_back([this] { run(); });
-    }
-    ~CopyPool() {
-        {
-            std::lock_guard<std::mutex> g(m_);
-            stop_ = true;
+        jobs_.reserve(64);  // copy() must not allocate once jobs are published
+        try {
+            for (int i = 0; i < workers; ++i) threads_.emplace_back([this] { run(); });
+        } catch (...) {
+            // thread creation failed half way: the workers that did start wait on members of this object, and a
+            // vector of joinable threads must not be destroyed — stop and join them before the exception leaves
+            shutdown();
+            throw;
         }
-        cv_work_.notify_all();
-        for (auto& t : threads_) t.join();
     }
+    ~CopyPool() { shutdown(); }
     // synchronous: returns when all n bytes are in place
-    void copy(void* dst, const void* src, size_t n) {
-        constexpr size_t kMinSlice = 2u << 20;
-        const size_t parts = std::min<size_t>(threads_.size() + 1, std::max<size_t>(1, n / kMinSlice));
-        if (parts <= 1) {
-            copy_streaming((char*)dst, (const char*)src, n);
-            return;
-        }
-        const size_t slice = ((n / parts) + 4095) & ~(size_t)4095;
-        {
-            std::lock_guard<std::mutex> g(m_);
-            for (size_t off = slice; off < n; off += slice) {
-                jobs_.push_back({(char*)dst + off, (const char*)src + off, std::min(slice, n - off)});
-                ++pending_;
-            }
-        }
-        cv_work_.notify_all();
-        copy_streaming((char*)dst, (const char*)src, std::min(slice, n));  // the calling thread takes the first slice
-        std::unique_lock<std::mutex> g(m_);
-        cv_done_.wait(g, [this] { return pending_ == 0; });
+    void copy(void* dst, const void* src, size_t n) { run_sliced(Job{(char*)dst, (const char*)src, n, 0, false}, 1); }
+    // synchronous: dst[i] = base + src[i] for i < n
+    void expand(uint64_t* dst, const uint32_t* src, size_t n, uint64_t base) {
+        run_sliced(Job{(char*)dst, (const char*)src, n, base, true}, 4);
     }
 
 private:
     struct Job {
         char* dst;
         const char* src;
-        size_t n;
+        size_t n;  // bytes (copy) or entries (expand)
+        uint64_t base;
+        bool widen;
     };
+    static void execute(const Job& j) {
+        if (j.widen) expand_streaming((uint64_t*)j.dst, (const uint32_t*)j.src, j.n, j.base);
+        else copy_streaming(j.dst, j.src, j.n);
+    }
+    // unit = source bytes per item of n
+    void run_sliced(Job whole, size_t unit) {
+        constexpr size_t kMinSlice = 2u << 20;  // source bytes
+        const size_t bytes = whole.n * unit;
+        const size_t parts = std::min<size_t>(threads_.size() + 1, std::max<size_t>(1, bytes / kMinSlice));
+        if (parts <= 1) {
+            execute(whole);
+            return;
+        }
+        const size_t slice = (((whole.n / parts) + 4095) & ~(size_t)4095);  // items; a multiple of 4096 keeps every slice aligned
+        const size_t dst_unit = whole.widen ? 8 : 1, src_unit = whole.widen ? 4 : 1;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            if (jobs_.capacity() < parts) jobs_.reserve(parts);  // before anything is published: a throw here harms nobody
+            for (size_t off = slice; off < whole.n; off += slice) {
+                jobs_.push_back(Job{whole.dst + off * dst_unit, whole.src + off * src_unit, std::min(slice, whole.n - off),
+                                    whole.base, whole.widen});
+                ++pending_;
+            }
+        }
+        cv_work_.notify_all();
+        Job first = whole;
+        first.n = std::min(slice, whole.n);
+        execute(first);  // the calling thread takes the first slice
+        std::unique_lock<std::mutex> g(m_);
+        cv_done_.wait(g, [this] { return pending_ == 0; });
+    }
+    void shutdown() {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+        }
+        cv_work_.notify_all();
+        for (auto& t : threads_)
+            if (t.joinable()) t.join();
+    }
     void run() {
         for (;;) {
             Job j;
@@ -135,7 +178,7 @@ private:
                 j = jobs_.back();
                 jobs_.pop_back();
             }
-            copy_streaming(j.dst, j.src, j.n);
+            execute(j);
             {
                 std::lock_guard<std::mutex> g(m_);
                 if (--pending_ == 0) cv_done_.notify_all();
@@ -183,19 +226,17 @@ struct csvsimd_ctx {
     bool pipe_ready = false;                   // every resource below exists
     hipStream_t pipe_stream = nullptr;         // kernels + result records
     hipStream_t in_stream = nullptr;           // H2D of input chunks (runs one chunk ahead of the kernels)
-    hipStream_t out_stream = nullptr;          // D2H of finished tape chunks
     hipEvent_t ev_in[2] = {nullptr, nullptr};  // chunk has landed in d_in[k]
     void* pin_in[2] = {nullptr, nullptr};     // pinned staging of the input chunk
     void* d_in[2] = {nullptr, nullptr};
     uint64_t* d_tape[2] = {nullptr, nullptr};  // device tape of a chunk (grown on demand)
     uint64_t d_tape_entries[2] = {0, 0};
-    uint64_t* pin_out[2] = {nullptr, nullptr};  // pinned staging of a chunk's tape
+    uint32_t* pin_out[2] = {nullptr, nullptr};  // pinned slot of a chunk's tape on its way back: 32-bit chunk-relative offsets
     uint64_t pin_out_entries[2] = {0, 0};
     csvsimd_shard_result* d_res[2] = {nullptr, nullptr};
     csvsimd_shard_result* h_res = nullptr;     // pinned, 2 records
-    hipEvent_t ev[2] = {nullptr, nullptr};
+    hipEvent_t ev_rec[2] = {nullptr, nullptr}; // result record of the slot's chunk has landed in h_res[k] (and its tape in pin_out[k])
     std::unique_ptr<CopyPool> copier;         // host-side slices of the staging copies
-    bool tape_zero_copy = false;              // ingest: the kernel writes its tape straight into the pinned slot (below)
 };
 
 extern "C" {
@@ -272,11 +313,10 @@ void csvsimd_ctx_destroy(csvsimd_ctx* ctx) {
         if (ctx->d_in[k]) (void)hipFree(ctx->d_in[k]);
         if (ctx->d_tape[k]) (void)hipFree(ctx->d_tape[k]);
         if (ctx->d_res[k]) (void)hipFree(ctx->d_res[k]);
-        if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
         if (ctx->ev_in[k]) (void)hipEventDestroy(ctx->ev_in[k]);
+        if (ctx->ev_rec[k]) (void)hipEventDestroy(ctx->ev_rec[k]);
     }
     if (ctx->in_stream) (void)hipStreamDestroy(ctx->in_stream);
-    if (ctx->out_stream) (void)hipStreamDestroy(ctx->out_stream);
     if (ctx->h_res) (void)hipHostFree(ctx->h_res);
     if (ctx->pipe_stream) (void)hipStreamDestroy(ctx->pipe_stream);
     delete ctx;
@@ -287,13 +327,10 @@ int csvsimd_ctx_reserve(csvsimd_ctx* ctx, uint64_t max_len) {
     const uint64_t need = csvsimd::Stage1Launch::scratch_bytes_for(max_len);
     if (need <= ctx->scratch_bytes) return CSVSIMD_OK;
     HIP_TRY(hipSetDevice(ctx->device));
-    // launches of one context are ordered with respect to each other (include/csvsimd.h), so waiting for
-    // the stream of the latest one covers every launch that may still use the old block — no device-wide
-    // synchronisation, other contexts keep running
-    if (ctx->launched && hipStreamSynchronize(ctx->last_stream) != hipSuccess) {
-        (void)hipGetLastError();  // the caller may have destroyed that stream already: wait for everything instead
-        HIP_TRY(hipDeviceSynchronize());
-    }
+    // every launch that may still use the old block has to finish first.  The stream of the latest launch is remembered,
+    // but the caller may have destroyed it since (a dangling handle is not a guaranteed error), so this rare path
+    // (a context is asked for a larger shard than ever before) waits for the whole device
+    if (ctx->launched) HIP_TRY(hipDeviceSynchronize());
     if (ctx->scratch) HIP_TRY(hipFree(ctx->scratch));
     ctx->scratch = nullptr;
     ctx->scratch_bytes = 0;
@@ -318,7 +355,8 @@ static int dialect_check(const csvsimd_dialect* d) {
 
 static int stage1_async_impl(csvsimd_ctx* ctx, const csvsimd_dialect* dialect, const void* dbuf, uint64_t len,
                              uint64_t base_off, uint32_t in_quote_in, void* dtape, uint64_t tape_cap, void* d_result,
-                             void* hip_stream, const uint32_t* d_state = nullptr) {
+                             void* hip_stream, const uint32_t* d_state = nullptr,
+                             const csvsimd_shard_result* d_chain = nullptr) {
     if (!ctx || !d_result || (len && !dbuf) || (!dtape && tape_cap)) return CSVSIMD_ERR_INVALID_ARG;
     // a shard's entry count must fit the 39-bit field of a look-back word (288 GB of HBM is 2^38.1 bytes)
     if (len >= (1ull << 39)) return CSVSIMD_ERR_INVALID_ARG;
@@ -339,6 +377,7 @@ static int stage1_async_impl(csvsimd_ctx* ctx, const csvsimd_dialect* dialect, c
     L.bind_scratch(ctx->scratch);
     L.max_blocks = ctx->max_blocks;
     L.d_state = d_state;
+    L.d_chain = d_chain;
     if (dialect) {
         L.delimiter = dialect->delimiter;
         L.quote = dialect->quote;
@@ -414,51 +453,47 @@ int csvsimd_stage1_bound(uint64_t len, uint64_t* max_entries) {
 }
 
 // Host-buffer drop-in for reader::read (ingest).  The file is streamed through
-// the GPU in 32-MiB chunks over a two-slot pipeline on three private streams (H2D, kernels, D2H):
-// while the kernel of chunk i runs, chunk i+1 is staged (sliced over a few host threads) and already
-// copied to the device, and the tape of chunk i-1 (exactly its entries) travels back and is unloaded.
-// The two loop-carried values of the reference (inside_str, array_idx: src/reader.rs:217-218) are
-// carried between chunks on the host.  This path is PCIe bound by construction; the HBM-resident
-// entry points are the timed ones.
+// the GPU in chunks over a two-slot pipeline on two private streams (H2D; kernels): while the kernels of chunk i
+// run, chunk i+1 is staged (sliced over a few host threads) and already on its way to the device, and the tape of
+// chunk i-1 is expanded from its pinned slot into the caller's tape.  This path is PCIe bound by construction; the
+// HBM-resident entry points are the timed ones.
 static int pipe_setup(csvsimd_ctx* ctx) {
     if (ctx->pipe_ready) return CSVSIMD_OK;
     // a previous attempt may have failed half way (out of memory): only create what is still missing
     if (!ctx->copier) ctx->copier.reset(new CopyPool(ingest_workers()));
     if (!ctx->pipe_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->pipe_stream, hipStreamNonBlocking));
     if (!ctx->in_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->in_stream, hipStreamNonBlocking));
-    if (!ctx->out_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->out_stream, hipStreamNonBlocking));
     if (!ctx->h_res)
         HIP_TRY(hipHostMalloc((void**)&ctx->h_res, 2 * sizeof(csvsimd_shard_result), hipHostMallocDefault));
     for (int k = 0; k < 2; ++k) {
         if (!ctx->pin_in[k]) HIP_TRY(hipHostMalloc(&ctx->pin_in[k], csvsimd_ctx::kChunk, hipHostMallocDefault));
         if (!ctx->d_in[k]) HIP_TRY(hipMalloc(&ctx->d_in[k], csvsimd_ctx::kChunk));
         if (!ctx->d_res[k]) HIP_TRY(hipMalloc((void**)&ctx->d_res[k], sizeof(csvsimd_shard_result)));
-        if (!ctx->ev[k]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev[k], hipEventDisableTiming));
         if (!ctx->ev_in[k]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_in[k], hipEventDisableTiming));
+        if (!ctx->ev_rec[k]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_rec[k], hipEventDisableTiming));
     }
     ctx->pipe_ready = true;
     return CSVSIMD_OK;
 }
+// a slot's device tape and its pinned way back, both for `entries` entries; everything that touches them runs on
+// pipe_stream (the stage-1 launch writes the device tape, the narrow kernel reads it and writes the pinned slot)
 static int pipe_ensure_tape(csvsimd_ctx* ctx, int k, uint64_t entries) {
-    if (ctx->d_tape_entries[k] >= entries) return CSVSIMD_OK;
-    // the slot's device tape is written by kernels on pipe_stream and read by copies on out_stream
+    if (ctx->d_tape_entries[k] >= entries && ctx->pin_out_entries[k] >= entries) return CSVSIMD_OK;
     HIP_TRY(hipStreamSynchronize(ctx->pipe_stream));
-    HIP_TRY(hipStreamSynchronize(ctx->out_stream));
-    if (ctx->d_tape[k]) HIP_TRY(hipFree(ctx->d_tape[k]));
-    ctx->d_tape[k] = nullptr;
-    ctx->d_tape_entries[k] = 0;
-    HIP_TRY(hipMalloc((void**)&ctx->d_tape[k], entries * 8));
-    ctx->d_tape_entries[k] = entries;
-    return CSVSIMD_OK;
-}
-static int pipe_ensure_out(csvsimd_ctx* ctx, int k, uint64_t entries) {
-    if (ctx->pin_out_entries[k] >= entries) return CSVSIMD_OK;
-    HIP_TRY(hipStreamSynchronize(ctx->out_stream));  // only D2H copies on out_stream touch the pinned slot
-    if (ctx->pin_out[k]) HIP_TRY(hipHostFree(ctx->pin_out[k]));
-    ctx->pin_out[k] = nullptr;
-    ctx->pin_out_entries[k] = 0;
-    HIP_TRY(hipHostMalloc((void**)&ctx->pin_out[k], entries * 8, hipHostMallocDefault));
-    ctx->pin_out_entries[k] = entries;
+    if (ctx->d_tape_entries[k] < entries) {
+        if (ctx->d_tape[k]) HIP_TRY(hipFree(ctx->d_tape[k]));
+        ctx->d_tape[k] = nullptr;
+        ctx->d_tape_entries[k] = 0;
+        HIP_TRY(hipMalloc((void**)&ctx->d_tape[k], entries * 8));
+        ctx->d_tape_entries[k] = entries;
+    }
+    if (ctx->pin_out_entries[k] < entries) {
+        if (ctx->pin_out[k]) HIP_TRY(hipHostFree(ctx->pin_out[k]));
+        ctx->pin_out[k] = nullptr;
+        ctx->pin_out_entries[k] = 0;
+        HIP_TRY(hipHostMalloc((void**)&ctx->pin_out[k], entries * 4 + 16, hipHostMallocDefault));
+        ctx->pin_out_entries[k] = entries;
+    }
     return CSVSIMD_OK;
 }
 
@@ -469,12 +504,11 @@ static int stage1_index_host_impl(csvsimd_ctx* ctx, const csvsimd_dialect* diale
                                   uint64_t* tape, uint64_t tape_cap, uint64_t* tape_len, uint32_t* in_quote_out) {
     const int rc = stage1_index_host_body(ctx, dialect, buf, len, tape, tape_cap, tape_len, in_quote_out);
     if (rc != CSVSIMD_OK && rc != CSVSIMD_ERR_TAPE_CAPACITY && ctx && ctx->pipe_ready) {
-        // an error exit in mid-pipeline leaves copies in flight on the pinned slots: drain the three
+        // an error exit in mid-pipeline leaves copies and kernels in flight on the pinned slots: drain the
         // streams so the next call (or the caller freeing `buf` / `tape`) cannot race them
         const std::string keep = g_last_error;
         (void)hipStreamSynchronize(ctx->in_stream);
         (void)hipStreamSynchronize(ctx->pipe_stream);
-        (void)hipStreamSynchronize(ctx->out_stream);
         (void)hipGetLastError();
         g_last_error = keep;
     }
@@ -485,163 +519,191 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
                                   uint64_t* tape, uint64_t tape_cap, uint64_t* tape_len, uint32_t* in_quote_out) {
     if (!ctx || (len && !buf) || (!tape && tape_cap) || !tape_len) return CSVSIMD_ERR_INVALID_ARG;
     if (dialect_check(dialect) != CSVSIMD_OK) return CSVSIMD_ERR_INVALID_ARG;
-    csvsimd_dialect dia;  // per-chunk copy: escape_in is carried from chunk to chunk like the quote state
-    if (dialect) dia = *dialect;
-    const csvsimd_dialect* dp = dialect ? &dia : nullptr;
     HIP_TRY(hipSetDevice(ctx->device));
     int rc = pipe_setup(ctx);
     if (rc != CSVSIMD_OK) return rc;
-    // chunk size: the slots hold up to 32 MiB; a mid-size file is cut into ~4 chunks (>= 4 MiB, a multiple
-    // of 1 MiB) so that staging, H2D, kernel and D2H of neighbouring chunks overlap inside it as well.
-    // Every chunk costs ~100 us of host-side launches and waits, so smaller is not better: measured
-    // (scripts/probe_latency.py) 32 MiB file 25 -> 32 GiB/s with 8-MiB chunks, but a 256 MiB file
-    // 45 -> 22 GiB/s with 4-MiB chunks.
-    uint64_t kChunk = csvsimd_ctx::kChunk;
+    // Chunk plan.  The slots hold up to 32 MiB.  A large file ramps up (4, 8, 16 MiB, then 32) and down (..., 16, 8):
+    // the pipeline's fill — staging + H2D of the first chunk, during which nothing else runs — and its drain — kernel,
+    // D2H and unload of the last chunk's tape — then cost a 4- / 8-MiB chunk's time instead of a 32-MiB chunk's
+    // (~0.8 + 0.3 ms of a 40 ms call on 2 GiB).  A mid-size file is cut into ~4 chunks (>= 4 MiB, a multiple of 1 MiB)
+    // so that staging, H2D, kernel and D2H of neighbouring chunks overlap inside it as well.  Every chunk costs ~100 us
+    // of host-side launches and waits, so smaller is not better: measured (scripts/probe_latency.py) 32 MiB file
+    // 25 -> 32 GiB/s with 8-MiB chunks, but a 256 MiB file 45 -> 22 GiB/s with 4-MiB chunks.
+    constexpr uint64_t kMiB = 1ull << 20, kMax = csvsimd_ctx::kChunk;
+    std::vector<uint64_t> cuts;  // chunk i = [cuts[i], cuts[i + 1])
+    cuts.push_back(0);
+    uint64_t uniform = 0;
     if (const char* e = getenv("CSVSIMD_INGEST_CHUNK_MIB")) {
         const uint64_t v = (uint64_t)atoi(e) << 20;
-        if (v >= (1ull << 20) && v <= csvsimd_ctx::kChunk) kChunk = v;
-    } else if (len < 4 * csvsimd_ctx::kChunk) {
-        const uint64_t target = ((len / 4 + (1ull << 20) - 1) >> 20) << 20;
-        kChunk = std::min<uint64_t>(csvsimd_ctx::kChunk, std::max<uint64_t>(4ull << 20, target));
+        if (v >= kMiB && v <= kMax) uniform = v;
     }
+    if (!uniform && len < 4 * kMax) {
+        const uint64_t target = ((len / 4 + kMiB - 1) >> 20) << 20;
+        uniform = std::min<uint64_t>(kMax, std::max<uint64_t>(4 * kMiB, target));
+    }
+    for (uint64_t off = 0, i = 0; off < len; ++i) {
+        const uint64_t rem = len - off;
+        uint64_t sz;
+        if (uniform) {
+            sz = std::min(uniform, rem);
+        } else {
+            const uint64_t up = i < 3 ? (4 * kMiB) << i : kMax;                       // 4, 8, 16, 32, 32, ...
+            if (rem > kMax + 24 * kMiB) sz = std::min(up, kMax);
+            else if (rem > 24 * kMiB) sz = std::min(up, rem - 24 * kMiB);              // ... <= 32, then 16, 8
+            else if (rem > 8 * kMiB) sz = std::min(up, rem - 8 * kMiB);
+            else sz = rem;
+        }
+        off += sz;
+        cuts.push_back(off);
+    }
+    const uint64_t nchunks = cuts.size() - 1;
     hipStream_t st = ctx->pipe_stream;
-    const uint64_t nchunks = (len + kChunk - 1) / kChunk;
 
-    // How a chunk's tape reaches the host.  Default: a D2H copy on its own stream next to the following chunk's H2D
-    // (49-50 GiB/s end to end on most GPU slots of the two-socket hosts measured).  On some slots those D2H copies crawl
-    // while an H2D is in flight (the call then spends 40 % of its time waiting for them: 41 GiB/s); there the kernel
-    // writes its tape straight into the pinned slot instead (device-visible host memory: the tape crosses PCIe as the
-    // kernel's own stores) — 45-48 GiB/s on those slots, 3-5 % slower than the copies where the copies are healthy.
-    // So: start with copies, switch (for good, for this context) once the waits say the slot is one of the slow ones.
-    bool zero_copy_tape = ctx->tape_zero_copy, adaptive = true, zero_copy_in = false;
+    // How a chunk's tape reaches the host: a small kernel right behind the stage-1 launch packs the chunk's entries into
+    // 32-bit chunk-relative offsets and writes them straight into the slot's pinned host buffer (narrow_tape_kernel,
+    // text_kernels.hip): half the bytes cross PCIe, as the kernel's own posted writes, and no copy engine is involved.
+    // Measured on the pool's two-socket hosts (scripts/probe_ingest3.py, 2 GiB): with the tape copied back by D2H
+    // copies the H2D copies of the following chunks are served one after the other with them (49 ms = 39 ms of H2D +
+    // 10 ms of D2H; the count-only call: 39 ms); with the stage-1 kernel writing its u64 tape into the pinned slot
+    // itself, 42 ms; (the round-2 pipeline chose between those two by watching its waits).
+    bool zero_copy_in = false;
 #ifdef CSVSIMD_DEV_PROBES
-    if (const char* e = getenv("CSVSIMD_PROBE_ZEROCOPY_TAPE")) { zero_copy_tape = atoi(e) != 0; adaptive = false; }
     if (const char* e = getenv("CSVSIMD_PROBE_ZEROCOPY_IN")) zero_copy_in = atoi(e) != 0;  // measured: 36 GiB/s, worse
 #endif
     uint64_t n = 1;  // entries so far, sentinel included
     if (tape && tape_cap >= 1) tape[0] = 0;  // src/reader.rs:216
-    uint32_t inq = 0;
 
-    // what is still to be unloaded from a slot: `count` entries that belong at tape[at ...]
-    struct Pending { bool valid; uint64_t at, ncopy; bool d2h; } pend[2] = {{false, 0, 0, false}, {false, 0, 0, false}};
-    // where the time of a call goes: the wait for the tape's D2H copies decides how the tape travels (below); the rest
-    // is printed by the probe build (CSVSIMD_PROBE_INGEST_TIMES=1)
-    double t_in = 0, t_out = 0, t_wait_out = 0, t_sync = 0;
+    // The loop-carried values of the reference (inside_str, array_idx: src/reader.rs:217-218) between chunks: the
+    // entering state travels ON THE DEVICE — the launch of chunk i + 1 reads in_quote_out (and escape_out) from chunk i's
+    // result record when it starts (KernelArgs::chain) — so chunk i + 1 is enqueued before the host has seen chunk i's
+    // record, and nothing on the GPU ever waits for the host.  The host reads the records one chunk late, only to learn
+    // how many entries came back and where they belong in the caller's tape.
+    struct Slot {
+        bool busy = false;   // a chunk's kernels are enqueued and its record not yet consumed
+        uint64_t chunk = 0, cap = 0;
+        bool pend = false;   // entries waiting in pin_out[k] for the caller's tape
+        uint64_t at = 0, ncopy = 0, base = 0;
+    } slot[2];
+    uint32_t host_inq = 0, host_esc = dialect ? dialect->escape_in : 0;  // the state after the last chunk whose record was read
+    double t_in = 0, t_out = 0, t_sync = 0;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t_begin = now();
 #define CSVSIMD_TIMED(acc, stmt) do { const double t0_ = now(); stmt; acc += now() - t0_; } while (0)
-    auto unload = [&](int k) -> int {  // waits for the slot's D2H, then copies to the user's tape
-        if (!pend[k].valid) return CSVSIMD_OK;
-        hipError_t e_ = hipSuccess;
-        if (pend[k].d2h) CSVSIMD_TIMED(t_wait_out, e_ = hipEventSynchronize(ctx->ev[k]));
-        HIP_TRY(e_);
-        if (pend[k].ncopy) CSVSIMD_TIMED(t_out, ctx->copier->copy(tape + pend[k].at, ctx->pin_out[k], pend[k].ncopy * 8));
-        pend[k].valid = false;
+
+    auto unload = [&](int k) -> int {  // the slot's 32-bit offsets -> the caller's tape (the record was waited for)
+        if (!slot[k].pend) return CSVSIMD_OK;
+        if (slot[k].ncopy)
+            CSVSIMD_TIMED(t_out, ctx->copier->expand(tape + slot[k].at, ctx->pin_out[k], slot[k].ncopy, slot[k].base));
+        slot[k].pend = false;
         return CSVSIMD_OK;
     };
-
     // stages chunk j into its slot and starts its H2D copy on the input stream
     auto feed = [&](uint64_t j) -> int {
         const int kj = (int)(j & 1);
-        const uint64_t offj = j * kChunk, lenj = std::min<uint64_t>(kChunk, len - offj);
+        const uint64_t offj = cuts[j], lenj = cuts[j + 1] - offj;
         CSVSIMD_TIMED(t_in, ctx->copier->copy(ctx->pin_in[kj], buf + offj, lenj));
         if (zero_copy_in) return CSVSIMD_OK;  // the kernel reads the pinned slot itself
         HIP_TRY(hipMemcpyAsync(ctx->d_in[kj], ctx->pin_in[kj], lenj, hipMemcpyHostToDevice, ctx->in_stream));
         HIP_TRY(hipEventRecord(ctx->ev_in[kj], ctx->in_stream));
         return CSVSIMD_OK;
     };
-    if (nchunks && (rc = feed(0)) != CSVSIMD_OK) return rc;
-    for (uint64_t i = 0; i < nchunks; ++i) {
-        const int k = (int)(i & 1);
-        const uint64_t off = i * kChunk, clen = std::min<uint64_t>(kChunk, len - off);
+    // enqueues the kernels of the chunk in slot k (stage 1, the narrow kernel) and the copy-out of its record
+    auto launch = [&](int k, bool chained) -> int {
+        const uint64_t i = slot[k].chunk, off = cuts[i], clen = cuts[i + 1] - off;
         const void* in_dev = ctx->d_in[k];
         if (zero_copy_in) {
-            void* p_ = nullptr;
-            HIP_TRY(hipHostGetDevicePointer(&p_, ctx->pin_in[k], 0));
-            in_dev = p_;
-        } else {
-            HIP_TRY(hipStreamWaitEvent(st, ctx->ev_in[k], 0));
+            void* q = nullptr;
+            HIP_TRY(hipHostGetDevicePointer(&q, ctx->pin_in[k], 0));
+            in_dev = q;
         }
-        // first guess: one entry per 4 bytes; exact retry below if the chunk is denser
-        uint64_t cap = 0;
-        void* tape_dev = nullptr;  // where the kernel writes this chunk's tape
-        if (tape && zero_copy_tape) {
-            // straight into the pinned slot the host unloads from (device-visible host memory): the tape crosses PCIe
-            // as the kernel's own stores, not as a D2H copy competing with the next chunk's H2D for the copy engines
-            rc = pipe_ensure_out(ctx, k, std::max<uint64_t>(clen / 4, 4096));
-            if (rc != CSVSIMD_OK) return rc;
-            cap = ctx->pin_out_entries[k];
-            HIP_TRY(hipHostGetDevicePointer(&tape_dev, ctx->pin_out[k], 0));
-        } else if (tape) {
-            rc = pipe_ensure_tape(ctx, k, std::max<uint64_t>(clen / 4, 4096));
-            if (rc != CSVSIMD_OK) return rc;
-            cap = ctx->d_tape_entries[k];
-            tape_dev = ctx->d_tape[k];
+        csvsimd_dialect dia;
+        if (dialect) { dia = *dialect; dia.escape_in = (uint8_t)host_esc; }
+        int rc_ = stage1_async_impl(ctx, dialect ? &dia : nullptr, in_dev, clen, off, host_inq,
+                                    tape ? ctx->d_tape[k] : nullptr, slot[k].cap, ctx->d_res[k], st, nullptr,
+                                    chained ? ctx->d_res[k ^ 1] : nullptr);
+        if (rc_ != CSVSIMD_OK) return rc_;
+        if (tape) {
+            void* out_dev = nullptr;
+            HIP_TRY(hipHostGetDevicePointer(&out_dev, ctx->pin_out[k], 0));
+            HIP_TRY(csvsimd::launch_narrow_tape(ctx->d_tape[k], ctx->d_res[k], slot[k].cap, off, out_dev, ctx->n_cus, st));
         }
-        rc = stage1_async_impl(ctx, dp, in_dev, clen, off, inq, tape_dev, cap, ctx->d_res[k], st);
-        if (rc != CSVSIMD_OK) return rc;
         HIP_TRY(hipMemcpyAsync(&ctx->h_res[k], ctx->d_res[k], sizeof(csvsimd_shard_result), hipMemcpyDeviceToHost, st));
-        // while chunk i is in flight: stage chunk i+1 and start its H2D copy (slot k^1 is free: the
-        // kernel of chunk i-1 has been waited for), unload the tape of chunk i-1
-        if (i + 1 < nchunks && (rc = feed(i + 1)) != CSVSIMD_OK) return rc;
-        rc = unload(k ^ 1);
-        if (rc != CSVSIMD_OK) return rc;
-        if (adaptive && !zero_copy_tape && i >= 6 && t_wait_out > 0.15 * (now() - t_begin)) {
-            zero_copy_tape = true;       // takes effect with the next chunk; pending copies are unloaded as copies
-            ctx->tape_zero_copy = true;  // and the context's later calls start this way
-        }
+        HIP_TRY(hipEventRecord(ctx->ev_rec[k], st));
+        return CSVSIMD_OK;
+    };
+    // reads the record of the chunk in slot k (one chunk behind the launches) and re-runs the chunk if its tape did not fit
+    auto finish = [&](int k) -> int {
+        if (!slot[k].busy) return CSVSIMD_OK;
         {
             hipError_t e_ = hipSuccess;
-            CSVSIMD_TIMED(t_sync, e_ = hipStreamSynchronize(st));
+            CSVSIMD_TIMED(t_sync, e_ = hipEventSynchronize(ctx->ev_rec[k]));
             HIP_TRY(e_);
         }
         csvsimd_shard_result r = ctx->h_res[k];
         if (r.error) { g_last_error = "stage1 kernel: look-back spin bound hit"; return CSVSIMD_ERR_INTERNAL; }
-        if (tape && r.count > cap) {  // denser than guessed: exact capacity, run the chunk again
-            if (zero_copy_tape) {
-                rc = pipe_ensure_out(ctx, k, r.count);
-                if (rc != CSVSIMD_OK) return rc;
-                cap = ctx->pin_out_entries[k];
-                HIP_TRY(hipHostGetDevicePointer(&tape_dev, ctx->pin_out[k], 0));
-            } else {
-                rc = pipe_ensure_tape(ctx, k, r.count);
-                if (rc != CSVSIMD_OK) return rc;
-                cap = ctx->d_tape_entries[k];
-                tape_dev = ctx->d_tape[k];
-            }
-            rc = stage1_async_impl(ctx, dp, in_dev, clen, off, inq, tape_dev, cap, ctx->d_res[k], st);
-            if (rc != CSVSIMD_OK) return rc;
-            HIP_TRY(hipMemcpyAsync(&ctx->h_res[k], ctx->d_res[k], sizeof(csvsimd_shard_result), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
+        if (tape && r.count > slot[k].cap) {
+            // denser than guessed (first guess: one entry per 4 bytes): exact capacity, run the chunk again.  Its input is
+            // still in the slot (the next chunk for this slot is fed only after this), its entering state is the host's:
+            // everything before it has been read.  The chunk enqueued behind it meanwhile chained from this chunk's first
+            // record, whose in_quote_out / escape_out do not depend on the capacity — and the re-run writes the same.
+            int rc_ = pipe_ensure_tape(ctx, k, r.count);  // waits for pipe_stream
+            if (rc_ != CSVSIMD_OK) return rc_;
+            slot[k].cap = std::min(ctx->d_tape_entries[k], ctx->pin_out_entries[k]);
+            rc_ = launch(k, false);
+            if (rc_ != CSVSIMD_OK) return rc_;
+            HIP_TRY(hipEventSynchronize(ctx->ev_rec[k]));
             r = ctx->h_res[k];  // the second pass's own record: its error flag and count are what count
             if (r.error) { g_last_error = "stage1 kernel: look-back spin bound hit"; return CSVSIMD_ERR_INTERNAL; }
-            if (r.count > cap) return CSVSIMD_ERR_INTERNAL;
+            if (r.count > slot[k].cap) return CSVSIMD_ERR_INTERNAL;
         }
+        slot[k].busy = false;
         if (tape && n < tape_cap) {
-            const uint64_t ncopy = std::min<uint64_t>(tape_cap - n, r.count);
-            if (ncopy && tape_dev != ctx->d_tape[k]) {
-                pend[k] = {true, n, ncopy, false};  // already in the pinned slot: the kernel was waited for
-            } else if (ncopy) {
-                rc = pipe_ensure_out(ctx, k, std::max<uint64_t>(ncopy, 4096));
-                if (rc != CSVSIMD_OK) return rc;
-                // the kernel has finished (its result record was waited for): the tape chunk leaves on
-                // its own stream, next to the H2D of the following chunk (PCIe is full duplex)
-                HIP_TRY(hipMemcpyAsync(ctx->pin_out[k], ctx->d_tape[k], ncopy * 8, hipMemcpyDeviceToHost,
-                                       ctx->out_stream));
-                HIP_TRY(hipEventRecord(ctx->ev[k], ctx->out_stream));
-                pend[k] = {true, n, ncopy, true};
-            }
+            slot[k].ncopy = std::min<uint64_t>(tape_cap - n, r.count);
+            slot[k].at = n;
+            slot[k].base = cuts[slot[k].chunk];
+            slot[k].pend = slot[k].ncopy != 0;
         }
         n += r.count;
-        inq = r.in_quote_out;
-        dia.escape_in = (uint8_t)r.escape_out;
+        host_inq = r.in_quote_out;
+        host_esc = r.escape_out;
+        return CSVSIMD_OK;
+    };
+
+    if (nchunks && (rc = feed(0)) != CSVSIMD_OK) return rc;
+    for (uint64_t i = 0; i < nchunks; ++i) {
+        const int k = (int)(i & 1);
+        const uint64_t clen = cuts[i + 1] - cuts[i];
+        // slot k's previous chunk (i - 2): its record was consumed in the previous iteration; its offsets must have left
+        // the pinned slot before this chunk's narrow kernel may write it
+        rc = unload(k);
+        if (rc != CSVSIMD_OK) return rc;
+        if (!zero_copy_in) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_in[k], 0));
+        slot[k].chunk = i;
+        slot[k].cap = 0;
+        if (tape) {
+            rc = pipe_ensure_tape(ctx, k, std::max<uint64_t>(clen / 4, 4096));  // first guess: one entry per 4 bytes
+            if (rc != CSVSIMD_OK) return rc;
+            slot[k].cap = std::min(ctx->d_tape_entries[k], ctx->pin_out_entries[k]);
+        }
+        rc = launch(k, i > 0);
+        if (rc != CSVSIMD_OK) return rc;
+        slot[k].busy = true;
+        // one chunk behind: the record of chunk i - 1 (the host blocks here until the GPU is one chunk ahead of it — the
+        // GPU itself never waits for the host)
+        rc = finish(k ^ 1);
+        if (rc != CSVSIMD_OK) return rc;
+        // stage chunk i + 1 and start its H2D copy (slot k^1: its kernels have finished, its record is read — its
+        // offsets stay in the pinned slot until the top of the next iteration) ...
+        if (i + 1 < nchunks && (rc = feed(i + 1)) != CSVSIMD_OK) return rc;
+        // ... and expand them into the caller's tape while chunk i is on the GPU
+        rc = unload(k ^ 1);
+        if (rc != CSVSIMD_OK) return rc;
     }
+    if (nchunks && (rc = finish((int)((nchunks - 1) & 1))) != CSVSIMD_OK) return rc;
 #ifdef CSVSIMD_DEV_PROBES
     if (getenv("CSVSIMD_PROBE_INGEST_TIMES"))
-        fprintf(stderr, "ingest %.1f MiB: staging copies in %.2f ms, tape copies out %.2f ms, waits for D2H %.2f ms, "
-                        "waits for the kernel (incl. H2D) %.2f ms; tape %s\n",
-                len / 1048576.0, t_in * 1e3, t_out * 1e3, t_wait_out * 1e3, t_sync * 1e3,
-                zero_copy_tape ? "written by the kernel into the pinned slot" : "copied D2H");
+        fprintf(stderr, "ingest %.1f MiB in %llu chunks: staging copies in %.2f ms, tape expansion out %.2f ms, "
+                        "waits for records (H2D + kernels) %.2f ms\n",
+                len / 1048576.0, (unsigned long long)nchunks, t_in * 1e3, t_out * 1e3, t_sync * 1e3);
 #else
     (void)t_in; (void)t_out; (void)t_sync;
 #endif
@@ -650,7 +712,7 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
     rc = unload(1);
     if (rc != CSVSIMD_OK) return rc;
     *tape_len = n;
-    if (in_quote_out) *in_quote_out = inq;
+    if (in_quote_out) *in_quote_out = host_inq;
     if (tape && n > tape_cap) return CSVSIMD_ERR_TAPE_CAPACITY;
     return CSVSIMD_OK;
 }

@@ -374,13 +374,17 @@ __global__ __launch_bounds__(256) void search_kernel(const Column c, const uint8
 // bitmap -> ascending record ids.  Two small passes keep the order without any global atomics on the output:
 //   pass 1: popcount per 4096-bit block -> block_counts;  (host-free) pass 2: one workgroup scans the block
 //   counts;  pass 3: every block writes its ids from its base.
-__global__ void bitmap_block_count_kernel(const u64* __restrict__ bitmap, u64 n_words, u64* __restrict__ block_counts) {
+// bits at positions >= n_rows in the last word are not rows: a caller's bitmap may hold anything there
+__device__ __forceinline__ u64 bitmap_word(const u64* __restrict__ bitmap, u64 w, u64 n_words, u64 n_rows) {
+    if (w >= n_words) return 0;
+    u64 bits = bitmap[w];
+    if (w == n_words - 1 && (n_rows & 63u)) bits &= (1ull << (n_rows & 63u)) - 1ull;
+    return bits;
+}
+__global__ void bitmap_block_count_kernel(const u64* __restrict__ bitmap, u64 n_words, u64 n_rows, u64* __restrict__ block_counts) {
     const u64 blk = blockIdx.x;
     u32 c = 0;
-    for (u32 k = threadIdx.x; k < 64; k += blockDim.x) {
-        const u64 w = blk * 64 + k;
-        c += w < n_words ? (u32)__builtin_popcountll(bitmap[w]) : 0u;
-    }
+    for (u32 k = threadIdx.x; k < 64; k += blockDim.x) c += (u32)__builtin_popcountll(bitmap_word(bitmap, blk * 64 + k, n_words, n_rows));
     for (int d = 32; d >= 1; d >>= 1) c += (u32)__shfl_xor((int)c, d);
     if (threadIdx.x == 0) block_counts[blk] = c;
 }
@@ -410,13 +414,13 @@ __global__ __launch_bounds__(1024) void bitmap_scan_kernel(u64* __restrict__ blo
         run += v;
     }
 }
-__global__ void bitmap_select_kernel(const u64* __restrict__ bitmap, u64 n_words, const u64* __restrict__ block_base,
+__global__ void bitmap_select_kernel(const u64* __restrict__ bitmap, u64 n_words, u64 n_rows, const u64* __restrict__ block_base,
                                      u64 first_row, u64* __restrict__ out, u64 out_cap) {
     // one wave per 4096-bit block: lane l owns word l of the block
     const u64 blk = blockIdx.x;
     const u32 lane = threadIdx.x;
     const u64 w = blk * 64 + lane;
-    u64 bits = w < n_words ? bitmap[w] : 0;
+    u64 bits = bitmap_word(bitmap, w, n_words, n_rows);
     u32 c = (u32)__builtin_popcountll(bits);
     u32 incl = c;
     for (int d = 1; d < 64; d <<= 1) {
@@ -515,9 +519,9 @@ hipError_t launch_bitmap_select(const void* d_bitmap, u64 n_rows, u64 first_row,
     const u64 n_blocks = (n_words + 63) / 64;
     if (n_blocks > 0x7fffffffull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(bitmap_block_count_kernel, dim3((u32)n_blocks), dim3(64), 0, stream, (const u64*)d_bitmap, n_words,
-                       (u64*)d_block_scratch);
+                       n_rows, (u64*)d_block_scratch);
     hipLaunchKernelGGL(bitmap_scan_kernel, dim3(1), dim3(1024), 0, stream, (u64*)d_block_scratch, n_blocks, (u64*)d_total);
-    hipLaunchKernelGGL(bitmap_select_kernel, dim3((u32)n_blocks), dim3(64), 0, stream, (const u64*)d_bitmap, n_words,
+    hipLaunchKernelGGL(bitmap_select_kernel, dim3((u32)n_blocks), dim3(64), 0, stream, (const u64*)d_bitmap, n_words, n_rows,
                        (const u64*)d_block_scratch, first_row, (u64*)d_out, out_cap);
     return hipGetLastError();
 }

@@ -44,6 +44,8 @@ struct Stage1Launch {
     uint32_t max_blocks;
     // sharded re-emit: device word with the shard's true entering state; the launch is a no-op unless it is 1
     const uint32_t* d_state = nullptr;
+    // chunked ingest: device result record of the previous chunk; entering state (and escape_in) are read from it on the device
+    const csvsimd_shard_result* d_chain = nullptr;
     // optional: recorded immediately around the stage-1 kernel itself (bench roofline leg)
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     int debug_mode = 0;  // development probes (-DCSVSIMD_DEV_PROBES builds only; see stage1_kernel's DBG)
@@ -113,6 +115,9 @@ hipError_t launch_colsearch(const void* d_col, const void* d_len, uint64_t n_row
 hipError_t launch_utf8_validate(const void* dbuf, uint64_t len, void* d_result, int n_cus, hipStream_t stream);
 hipError_t launch_trim_spans(const void* dbytes, void* d_begin, void* d_end, uint64_t n, uint32_t flags,
                              uint32_t quote, hipStream_t stream);
+// ingest: a chunk's tape (u64, device) -> 32-bit chunk-relative offsets in a pinned host slot; count read on the device
+hipError_t launch_narrow_tape(const void* d_tape, const void* d_result, uint64_t cap, uint64_t base, void* d_out, int n_cus,
+                              hipStream_t stream);
 int stage1_max_blocks_per_cu();
 
 }  // namespace csvsimd

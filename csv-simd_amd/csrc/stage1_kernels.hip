@@ -678,6 +678,11 @@ struct KernelArgs {
     // unless its `reemit` word (index 9) is 1, and then runs with the stitch's in_quote_in (word 0) — 0 or 1: a wrong
     // CSVSIMD_ENTER_GUESS can err either way.
     const u32* state_ptr;
+    // optional (chunked ingest): the device result record of the chunk right before this one.  When set, the launch takes
+    // its entering state (and, escape dialects, its escape_in) from that record when it starts — chunk i + 1 is
+    // enqueued behind chunk i without the host ever reading chunk i's record: the two values the reference carries
+    // between 64-byte blocks (inside_str, src/reader.rs:218) carried between launches on the device.
+    const csvsimd_shard_result* chain;
     // dialect variants only (DIALECT != 0)
     u32 delim, quote, escape;  // bytes; quote / escape 0 = feature off
     u32 escape_in;             // the first byte of the shard is escaped
@@ -692,6 +697,17 @@ struct KernelArgs {
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// "the first byte of the shard is escaped": the launch's own argument, or the previous chunk's escape_out (chained
+// launches; re-read where it is needed rather than carried through the tile loop in a register)
+template <int DIALECT>
+__device__ __forceinline__ u32 escape_in_of(const KernelArgs& args) {
+    if (DIALECT != 2) return 0u;
+    if (args.chain)
+        return (u32)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&args.chain->escape_out, __ATOMIC_RELAXED,
+                                                                        __HIP_MEMORY_SCOPE_AGENT)) & 1u;
+    return args.escape_in;
+}
 
 // Window slot of entry k (opt-in build knob, default off).  A lane scatters its stripe's entries to consecutive
 // ranks, so in one ds_write_b16 the 64 lanes hit ranks that are `entries per stripe` apart: on a regular dense file
@@ -874,7 +890,7 @@ __device__ __forceinline__ void finish_launch(const KernelArgs& args, u32 epoch,
     // escape dialect: is the byte after the shard escaped? (chains into the next shard's escape_in)
     u32 esc_out = 0;
     if (DIALECT == 2)
-        esc_out = escape_run_parity(args.abase, args.lo, args.hi, args.hi, args.escape, args.escape_in, lane);
+        esc_out = escape_run_parity(args.abase, args.lo, args.hi, args.hi, args.escape, escape_in_of<DIALECT>(args), lane);
     const u32 next_epoch = (epoch + 1u) & kEpochMask;
     u32 hwm = hwm_seen > args.num_tiles ? hwm_seen : args.num_tiles;
     if (next_epoch == 0u) {
@@ -1056,6 +1072,9 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
         inq_in = (u32)__builtin_amdgcn_readfirstlane(
                      (int)__hip_atomic_load(args.state_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 1u;
     }
+    if (args.chain)  // chained launch: the state the previous chunk left (written by a launch earlier on this stream)
+        inq_in = (u32)__builtin_amdgcn_readfirstlane(
+                     (int)__hip_atomic_load(&args.chain->in_quote_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 1u;
     // requested now, consumed after the first count phase (the load's latency hides behind it)
     const u32 epoch_v = __hip_atomic_load(&args.ctl->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
@@ -1154,7 +1173,7 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
 
             // ---- count phase: masks for the whole span stay in registers ---------------------
             u32 carry = 0, cnt_a = 0, cnt_t = 0;
-            const EdgeKeep ek = edge_keep_of_tile(lane, w, lo_rel, hi_rel, DIALECT == 2 ? args.escape_in : 0u);
+            const EdgeKeep ek = edge_keep_of_tile(lane, w, lo_rel, hi_rel, escape_in_of<DIALECT>(args));
             DialectRegs dr = {0, 0, 0, 0};
             u32 esc_carry = 0;
             if (DIALECT != 0) {
@@ -1169,7 +1188,7 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
                 const u64 span0 = tile0 + (u64)w * kSpanBytes;
                 if (span0 > args.lo || lo_rel == 0u)
                     esc_carry = (u32)__builtin_amdgcn_readfirstlane(
-                        (int)escape_run_parity(args.abase, args.lo, args.hi, span0, args.escape, args.escape_in, lane));
+                        (int)escape_run_parity(args.abase, args.lo, args.hi, span0, args.escape, escape_in_of<DIALECT>(args), lane));
             }
             if (DBG & 1) {
                 uint4 v[kRows];
@@ -1614,6 +1633,7 @@ hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream) {
     a.ctl = reinterpret_cast<Control*>(L.scratch_base);
     a.result = L.d_result;
     a.state_ptr = L.d_state;
+    a.chain = L.d_chain;
     a.delim = L.delimiter;
     a.quote = L.quote;
     a.escape = L.escape;

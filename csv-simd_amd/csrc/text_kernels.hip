@@ -254,4 +254,37 @@ hipError_t launch_trim_spans(const void* dbytes, void* d_begin, void* d_end, u64
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// ingest: the way back of a chunk's tape (csvsimd_stage1_index).  The chunk's entries (u64, absolute) sit in device
+// memory; what crosses PCIe is HALF of that: 32-bit offsets relative to the chunk (a chunk is <= 32 MiB), written by
+// this kernel straight into the pinned host slot (device-visible host memory: posted writes, no copy engine — measured,
+// a D2H copy of the tape is served one after the other with the H2D copies of the following chunks on the pool's
+// hosts, +10 ms on a 38 ms call).  The entry count is read from the chunk's result record ON THE DEVICE, so the kernel
+// is enqueued right behind the stage-1 launch without the host knowing the count; the host expands the offsets into
+// the caller's tape when it has read the record.
+// ---------------------------------------------------------------------------------------------
+typedef uint32_t u32x4t __attribute__((ext_vector_type(4)));
+typedef uint64_t u64x2t __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void narrow_tape_kernel(const u64* __restrict__ tape, const csvsimd_shard_result* __restrict__ res,
+                                                          u64 cap, u64 base, u32* __restrict__ out) {
+    const u64 count = res->count;
+    const u64 n = count < cap ? count : cap;
+    const u64 n4 = n / 4;
+    for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < n4; j += (u64)gridDim.x * blockDim.x) {
+        const u64x2t a = __builtin_nontemporal_load(reinterpret_cast<const u64x2t*>(tape) + 2 * j);
+        const u64x2t b = __builtin_nontemporal_load(reinterpret_cast<const u64x2t*>(tape) + 2 * j + 1);
+        const u32x4t v = {(u32)(a.x - base), (u32)(a.y - base), (u32)(b.x - base), (u32)(b.y - base)};
+        reinterpret_cast<u32x4t*>(out)[j] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) out[4 * n4 + threadIdx.x] = (u32)(tape[4 * n4 + threadIdx.x] - base);
+}
+
+hipError_t launch_narrow_tape(const void* d_tape, const void* d_result, u64 cap, u64 base, void* d_out, int n_cus,
+                              hipStream_t stream) {
+    // 16-byte aligned tape and slot (hipMalloc / hipHostMalloc); a modest grid: the kernel is bound by the PCIe writes
+    hipLaunchKernelGGL(narrow_tape_kernel, dim3((u32)(n_cus > 0 ? n_cus : 256)), dim3(256), 0, stream, (const u64*)d_tape,
+                       (const csvsimd_shard_result*)d_result, cap, base, (u32*)d_out);
+    return hipGetLastError();
+}
+
 }  // namespace csvsimd

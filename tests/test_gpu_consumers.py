@@ -207,3 +207,17 @@ def test_consumers_on_the_synthetic_corpus_at_scale(ctx, pkg, oracle, torch_cuda
     ids = torch.zeros(len(hits), dtype=torch.int64, device="cuda:0")
     assert pkg.bitmap_select_device(bm.data_ptr(), nrec, 0, scratch2.data_ptr(), ids.data_ptr(), len(hits)) == len(hits)
     assert ids.cpu().tolist() == hits
+
+
+def test_bitmap_select_ignores_bits_past_n_rows(pkg, torch_cuda):
+    """include/csvsimd.h: "set bits among the first n_rows".  A caller's bitmap (not one search_kernel wrote) may hold
+    anything past n_rows in its last word: those bits are not records."""
+    torch = torch_cuda
+    for n_rows in (1, 63, 64, 65, 100, 4096 + 7):
+        words = (n_rows + 63) // 64
+        bm = torch.full((words,), -1, dtype=torch.int64, device="cuda:0")       # every bit set, incl. the stray ones
+        scratch = torch.empty(pkg.bitmap_select_scratch_bytes(n_rows), dtype=torch.uint8, device="cuda:0")
+        ids = torch.full((n_rows + 70,), -1, dtype=torch.int64, device="cuda:0")
+        n = pkg.bitmap_select_device(bm.data_ptr(), n_rows, 500, scratch.data_ptr(), ids.data_ptr(), n_rows + 70)
+        assert n == n_rows
+        assert ids[:n].cpu().tolist() == list(range(500, 500 + n_rows)) and bool((ids[n:] == -1).all())

@@ -488,6 +488,34 @@ def test_host_ingest_pipeline_multi_chunk(ctx, pkg, oracle, tmp_path, monkeypatc
     assert np.array_equal(t.index(), oracle.scalar_read(body))
 
 
+def test_host_ingest_chained_chunks_ramped_plan_and_mid_pipeline_retry(ctx, pkg, oracle):
+    """A file large enough for the ramped chunk plan (4, 8, 16, 32 ... 16, 8 MiB).  Chunks are chained ON THE DEVICE
+    (chunk i + 1 reads its entering state from chunk i's record; the host reads records one chunk late), so: quoted
+    stretches that cross every kind of boundary, a chunk in the MIDDLE that is denser than the capacity guess (its
+    re-run happens after the chunk behind it was already enqueued from its first record), an odd number of quotes in
+    that dense chunk (the state it hands on must be right the first time), and the capacity protocol at this size."""
+    rng = np.random.default_rng(90210)
+    n = (168 << 20) + 54321
+    d = random_csvish(rng, n, 0.001)
+    cuts = [4 << 20, 12 << 20, 28 << 20, 60 << 20, 92 << 20]
+    for c in cuts:                                                     # a quote right at, before and after each cut
+        d[c - 2: c + 3] = np.frombuffer(b',"\n",', dtype=np.uint8)[:5]
+    dense0 = 61 << 20                                                  # inside the chunk [60, 92) MiB
+    d[dense0: dense0 + (24 << 20)] = 0x2C                              # 24 MiB of commas: > 1 entry per 4 bytes
+    d[dense0 + 12345] = 0x22                                           # ... with ONE quote in it: parity flips here
+    d[dense0 + (23 << 20)] = 0x22                                      # ... and back, 11 MiB of commas are quoted
+    d[dense0 + (23 << 20) + 5] = 0x22                                  # ... and once more: the chunk leaves INSIDE a string
+    want = oracle.scalar_read(d)
+    got = ctx.read(d)
+    assert got.size == want.size and np.array_equal(got, want)
+    rc, cnt, q = ctx.read_into(d, None)
+    assert rc == 0 and cnt == want.size
+    assert q == int(np.count_nonzero(d == 0x22) & 1)
+    small = np.zeros(100_000, dtype=np.uint64)
+    rc, cnt, _ = ctx.read_into(d, small)
+    assert rc == pkg.ERR_TAPE_CAPACITY and cnt == want.size and np.array_equal(small, want[:100_000])
+
+
 def test_async_entry_point_is_graph_capturable(ctx, torch_cuda, pkg, oracle):
     # include/csvsimd.h promises: no allocation and no synchronisation inside
     # csvsimd_stage1_index_device_async once the scratch is reserved -> it can be captured into a
