@@ -586,6 +586,7 @@ def consumers_leg(pkg, oracle, device):
     res["frequency_count"] = {"ms": round(t * 1e3, 3), "distinct": int(st.n_distinct),
                               "algorithmic_bytes": alg_f, "GBps_algorithmic": round(alg_f / t / 1e9, 1),
                               "hbm_traffic_bytes_profiled": consumer_traffic("colfreq"),
+                              "hbm_traffic_bytes_table_memset": slots * 16,
                               "note": "on the column: memset of the table, insert (one returning atomic per new value; slots "
                                       "point at a representative record and compare bytes: exact, no verification pass), "
                                       "compact; algorithmic bytes = the column + its lengths read, 16 B per distinct value "
@@ -598,8 +599,10 @@ def consumers_leg(pkg, oracle, device):
     hits_s = pkg.columnar_search_device(ctx, col_ptr, len_ptr, 50000, stride, needle, pkg.SEARCH_CONTAINS, bm.data_ptr())
     ok = ok and hits >= 1 and hits_s == len(oracle.column_search(host, hidx, cols, False, sample, field, needle, 2))
     alg_s = nrec * (stride + 4)
+    tr_s = consumer_traffic("colsearch_kernel")
     res["search_contains"] = {"ms": round(t * 1e3, 3), "matches": int(hits), "algorithmic_bytes": alg_s,
-                              "GBps_algorithmic": round(alg_s / t / 1e9, 1)}
+                              "GBps_algorithmic": round(alg_s / t / 1e9, 1), "hbm_traffic_bytes_profiled": tr_s,
+                              "traffic_over_algorithmic": round(tr_s / alg_s, 3) if tr_s else None}
     # ---- round 2's per-column path on the row-major file, for comparison --------------------------------------------
     b = torch.empty(nrec, dtype=torch.int64, device=device)
     e = torch.empty(nrec, dtype=torch.int64, device=device)

@@ -92,6 +92,12 @@ class Stitch(C.Structure):
     ]
 
 
+class MultiShard(C.Structure):
+    """csvsimd_multi_shard: one shard of csvsimd_stage1_index_multi (in: ctx, dbuf, dtape, tape_cap; out: the rest)."""
+    _fields_ = [("ctx", C.c_void_p), ("dbuf", C.c_void_p), ("dtape", C.c_void_p), ("tape_cap", C.c_uint64),
+                ("begin", C.c_uint64), ("end", C.c_uint64), ("result", ShardResult), ("stitch", Stitch)]
+
+
 class _Boundary(C.Structure):
     _fields_ = [("start", C.c_uint64), ("len", C.c_uint64)]
 
@@ -148,6 +154,8 @@ _PROTOTYPES = {
     "csvsimd_stage1_bound": (C.c_int, [C.c_uint64, _u64p]),
     "csvsimd_stage1_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, _u64p,
                                        C.POINTER(C.c_uint32)]),
+    "csvsimd_multi_shard_range": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, _u64p, _u64p]),
+    "csvsimd_stage1_index_multi": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(MultiShard), C.c_uint32, C.c_uint32]),
     "csvsimd_stitch_shards": (C.c_int, [C.POINTER(ShardResult), C.c_uint32, C.c_uint32, C.c_uint32,
                                         C.POINTER(Stitch)]),
     "csvsimd_stitch_shards_device_async": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
@@ -409,6 +417,25 @@ class Comm:
         _check(lib().csvsimd_stage1_index_sharded(ctx._h, self._h, dbuf, length, base_off, file_in_quote_in,
                                                   dtape or None, tape_cap, C.byref(r), C.byref(st), stream or None))
         return r, st
+
+
+def multi_shard_range(length: int, n_shards: int, i: int) -> Tuple[int, int]:
+    b, e = C.c_uint64(), C.c_uint64()
+    _check(lib().csvsimd_multi_shard_range(length, n_shards, i, C.byref(b), C.byref(e)))
+    return b.value, e.value
+
+
+def stage1_index_multi(data: np.ndarray, ctxs: Sequence["Context"], dbufs: Sequence[int], dtapes: Sequence[int],
+                       tape_caps: Sequence[int], file_in_quote_in: int = 0):
+    """One host buffer -> len(ctxs) shards, one per context (contexts may sit on different GPUs of this process):
+    streamed to the devices concurrently, indexed, stitched; bytes and tapes stay on the devices.  Returns the filled
+    MultiShard array (begin, end, result, stitch per shard)."""
+    g = len(ctxs)
+    arr = (MultiShard * g)()
+    for i in range(g):
+        arr[i].ctx, arr[i].dbuf, arr[i].dtape, arr[i].tape_cap = ctxs[i]._h, dbufs[i] or None, dtapes[i] or None, tape_caps[i]
+    _check(lib().csvsimd_stage1_index_multi(data.ctypes.data if data.size else None, data.size, arr, g, file_in_quote_in))
+    return arr
 
 
 def stage1_bound(length: int) -> int:

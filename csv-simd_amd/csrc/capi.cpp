@@ -732,6 +732,110 @@ int csvsimd_stage1_index_dialect(csvsimd_ctx* ctx, const csvsimd_dialect* dialec
     });
 }
 
+/* ---- one host file -> G GPUs of this process ----------------------------------------------------------------------- */
+
+int csvsimd_multi_shard_range(uint64_t len, uint32_t n_shards, uint32_t i, uint64_t* begin, uint64_t* end) {
+    if (!begin || !end || n_shards == 0 || i >= n_shards) return CSVSIMD_ERR_INVALID_ARG;
+    // contiguous byte ranges, interior cuts rounded down to 64 bytes (any cut is legal: the semantics are
+    // blocking-independent; 64 keeps every shard's loads aligned when the file's device copy is)
+    auto cut = [&](uint32_t k) -> uint64_t {
+        if (k == 0) return 0;
+        if (k >= n_shards) return len;
+        return (uint64_t)((unsigned __int128)len * k / n_shards) & ~(uint64_t)63;
+    };
+    *begin = cut(i);
+    *end = cut(i + 1);
+    return CSVSIMD_OK;
+}
+
+namespace {
+// one shard's share of csvsimd_stage1_index_multi, on the calling thread: stream the bytes into the device buffer
+// (two pinned staging slots, the context's own H2D stream), then the first stage-1 pass and its record
+int multi_feed_and_index(csvsimd_multi_shard* sh, const uint8_t* buf, uint32_t in_quote_in) {
+    csvsimd_ctx* ctx = sh->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = pipe_setup(ctx);
+    if (rc != CSVSIMD_OK) return rc;
+    const uint64_t n = sh->end - sh->begin;
+    rc = csvsimd_ctx_reserve(ctx, n);
+    if (rc != CSVSIMD_OK) return rc;
+    constexpr uint64_t kChunk = csvsimd_ctx::kChunk;
+    for (uint64_t off = 0, i = 0; off < n; off += kChunk, ++i) {
+        const int k = (int)(i & 1);
+        const uint64_t clen = std::min<uint64_t>(kChunk, n - off);
+        if (i >= 2) HIP_TRY(hipEventSynchronize(ctx->ev_in[k]));  // the slot's previous chunk has left the staging buffer
+        ctx->copier->copy(ctx->pin_in[k], buf + sh->begin + off, clen);
+        HIP_TRY(hipMemcpyAsync((char*)sh->dbuf + off, ctx->pin_in[k], clen, hipMemcpyHostToDevice, ctx->in_stream));
+        HIP_TRY(hipEventRecord(ctx->ev_in[k], ctx->in_stream));
+    }
+    // the kernel follows the last copy on the device (no host wait in between)
+    if (n) HIP_TRY(hipStreamWaitEvent(ctx->pipe_stream, ctx->ev_in[((n - 1) / kChunk) & 1], 0));
+    rc = csvsimd_stage1_index_device_async(ctx, sh->dbuf, n, sh->begin, in_quote_in, sh->dtape, sh->tape_cap, ctx->d_result,
+                                           ctx->pipe_stream);
+    if (rc != CSVSIMD_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(&sh->result, ctx->d_result, sizeof(sh->result), hipMemcpyDeviceToHost, ctx->pipe_stream));
+    HIP_TRY(hipStreamSynchronize(ctx->in_stream));
+    HIP_TRY(hipStreamSynchronize(ctx->pipe_stream));
+    return CSVSIMD_OK;
+}
+}  // namespace
+
+int csvsimd_stage1_index_multi(const uint8_t* buf, uint64_t len, csvsimd_multi_shard* shards, uint32_t n_shards,
+                               uint32_t file_in_quote_in) {
+    return csvsimd_guarded([&]() -> int {
+    if ((len && !buf) || !shards || n_shards == 0 || n_shards > 64) return CSVSIMD_ERR_INVALID_ARG;
+    for (uint32_t g = 0; g < n_shards; ++g) {
+        csvsimd_multi_shard& sh = shards[g];
+        int rc = csvsimd_multi_shard_range(len, n_shards, g, &sh.begin, &sh.end);
+        if (rc != CSVSIMD_OK) return rc;
+        if (!sh.ctx || (sh.end > sh.begin && !sh.dbuf) || (!sh.dtape && sh.tape_cap) || ((uintptr_t)sh.dtape & 7))
+            return CSVSIMD_ERR_INVALID_ARG;
+        for (uint32_t h = 0; h < g; ++h)
+            if (shards[h].ctx == sh.ctx) return CSVSIMD_ERR_INVALID_ARG;  // one context per shard (they run concurrently)
+    }
+    // one host thread per shard: each owns its device's H2D stream and staging slots; rank 0 knows how the file
+    // starts, every other shard lets the kernel choose its entering state from its own first tiles (CSVSIMD_ENTER_GUESS)
+    std::vector<int> rcs(n_shards, CSVSIMD_OK);
+    std::vector<std::string> errs(n_shards);
+    {
+        std::vector<std::thread> th;
+        th.reserve(n_shards);
+        for (uint32_t g = 1; g < n_shards; ++g)
+            th.emplace_back([&, g] {
+                rcs[g] = csvsimd_guarded([&]() -> int { return multi_feed_and_index(&shards[g], buf, CSVSIMD_ENTER_GUESS); });
+                if (rcs[g] != CSVSIMD_OK) errs[g] = csvsimd_last_error();
+            });
+        rcs[0] = multi_feed_and_index(&shards[0], buf, file_in_quote_in ? 1u : 0u);
+        if (rcs[0] != CSVSIMD_OK) errs[0] = csvsimd_last_error();
+        for (auto& t : th) t.join();
+    }
+    for (uint32_t g = 0; g < n_shards; ++g)
+        if (rcs[g] != CSVSIMD_OK) {
+            g_last_error = errs[g];
+            return rcs[g];
+        }
+    // the exchange: G records of 64 bytes are already on the host; stitch, and re-index only the shards whose first
+    // pass ran under another entering state than the true one (README.md:24)
+    std::vector<csvsimd_shard_result> recs(n_shards);
+    for (uint32_t g = 0; g < n_shards; ++g) recs[g] = shards[g].result;
+    for (uint32_t g = 0; g < n_shards; ++g) {
+        csvsimd_multi_shard& sh = shards[g];
+        int rc = csvsimd_stitch_shards(recs.data(), n_shards, g, file_in_quote_in, &sh.stitch);
+        if (rc != CSVSIMD_OK) return rc;
+        if (sh.stitch.error) { g_last_error = "stage1 kernel: look-back spin bound hit"; return CSVSIMD_ERR_INTERNAL; }
+        if (sh.stitch.reemit) {
+            HIP_TRY(hipSetDevice(sh.ctx->device));
+            rc = csvsimd_stage1_index_device(sh.ctx, sh.dbuf, sh.end - sh.begin, sh.begin, sh.stitch.in_quote_in, sh.dtape,
+                                             sh.tape_cap, &sh.result, sh.ctx->pipe_stream);
+            if (rc != CSVSIMD_OK && rc != CSVSIMD_ERR_TAPE_CAPACITY) return rc;
+        }
+    }
+    for (uint32_t g = 0; g < n_shards; ++g)
+        if (shards[g].dtape && shards[g].result.count > shards[g].tape_cap) return CSVSIMD_ERR_TAPE_CAPACITY;
+    return CSVSIMD_OK;
+    });
+}
+
 int csvsimd_stitch_shards(const csvsimd_shard_result* results, uint32_t n_shards, uint32_t rank,
                           uint32_t file_in_quote_in, csvsimd_stitch* out) {
     if (!results || !out || rank >= n_shards) return CSVSIMD_ERR_INVALID_ARG;

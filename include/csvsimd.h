@@ -213,6 +213,32 @@ int csvsimd_stage1_index_sharded(csvsimd_ctx* ctx, csvsimd_comm* comm, const voi
                                  uint64_t tape_cap, csvsimd_shard_result* result,
                                  csvsimd_stitch* stitch, void* hip_stream);
 
+/* ---- one host file -> the GPUs of ONE process ----------------------------------------------------------------------
+ * csv_simd::create maps a file and hands the whole mapping to reader::read (src/lib.rs:61-74); streaming and splitting
+ * are README TODOs (README.md:23-24).  Here the host side owns the chunking: the buffer is cut into n_shards contiguous
+ * byte ranges (csvsimd_multi_shard_range: cut i at i * len / n_shards, rounded down to 64 bytes), shard g is streamed
+ * into shards[g].dbuf on the device of shards[g].ctx (one host thread, one H2D stream and two pinned staging slots per
+ * shard, all shards concurrently), indexed there — shard 0 under the file's entering state, every other shard under the
+ * state its own first tiles speak for (CSVSIMD_ENTER_GUESS) — the G result records are stitched (csvsimd_stitch_shards)
+ * and only a shard that guessed wrong is indexed again.  The bytes and the tapes STAY on the devices, sharded in order
+ * (absolute offsets: concatenated behind the sentinel 0 they are reader::read's index), ready for the consumers above.
+ * In: ctx (one context per shard; contexts may share a device), dbuf (>= the shard's bytes), dtape / tape_cap.
+ * Out: begin / end (the shard's byte range), result (its final record), stitch (entering state, tape_index_base,
+ * totals).  CSVSIMD_ERR_TAPE_CAPACITY if some shard's tape_cap was too small (its result.count says what it needs).
+ * Multi-process jobs (one rank per GPU, torch.distributed / RCCL) use csvsimd_stage1_index_sharded instead. */
+typedef struct csvsimd_multi_shard {
+    csvsimd_ctx* ctx;
+    void* dbuf;
+    void* dtape;
+    uint64_t tape_cap;
+    uint64_t begin, end;
+    csvsimd_shard_result result;
+    csvsimd_stitch stitch;
+} csvsimd_multi_shard;
+int csvsimd_multi_shard_range(uint64_t len, uint32_t n_shards, uint32_t i, uint64_t* begin, uint64_t* end);
+int csvsimd_stage1_index_multi(const uint8_t* buf, uint64_t len, csvsimd_multi_shard* shards, uint32_t n_shards,
+                               uint32_t file_in_quote_in);
+
 /* ---- tape: host-side, after stage 1 (reference src/tape.rs, src/record_source.rs) ------------ */
 typedef struct csvsimd_tape csvsimd_tape;
 #define CSVSIMD_NEWLINE_LF 0   /* NewLine::LF   (src/stage1.rs:470-480) */

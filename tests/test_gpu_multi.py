@@ -1,0 +1,80 @@
+"""csvsimd_stage1_index_multi: ONE host buffer -> G shards on the GPUs of this process (here: G contexts on the one GPU
+of the box), bytes streamed to the devices concurrently, tapes left sharded in order.  The concatenation of the shard
+tapes behind the sentinel must be the oracle's index of the whole buffer (reference reader::read, src/reader.rs:150-306),
+for every G, with shards that start inside quoted fields."""
+import numpy as np
+import pytest
+
+from conftest import random_csvish
+
+
+def test_multi_shard_ranges_tile_the_file(pkg):
+    for n in (0, 1, 63, 64, 1000, (1 << 33) + 12345):
+        for g in (1, 2, 3, 8):
+            cuts = [pkg.multi_shard_range(n, g, i) for i in range(g)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+            assert all(c[0] % 64 == 0 for c in cuts)
+            assert all(c[1] >= c[0] for c in cuts)
+    with pytest.raises(pkg.StructureError):
+        pkg.multi_shard_range(100, 0, 0)
+    with pytest.raises(pkg.StructureError):
+        pkg.multi_shard_range(100, 2, 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("g", [1, 2, 3])
+def test_one_host_buffer_to_g_shards(pkg, oracle, g):
+    import torch
+    assert torch.cuda.is_available()
+    rng = np.random.default_rng(1000 + g)
+    n = (70 << 20) + 4242                       # > 2 staging chunks per shard at g = 1, ragged
+    d = random_csvish(rng, n, 0.002)            # long quoted stretches: shards 1.. usually start inside or near one
+    ctxs = [pkg.Context(0) for _ in range(g)]
+    ranges = [pkg.multi_shard_range(n, g, i) for i in range(g)]
+    # make sure at least one interior cut lies INSIDE a quoted stretch
+    if g > 1:
+        c = ranges[1][0]
+        d[c - 100] = 0x22
+        d[c - 99: c + 100] = 0x2C               # 199 commas right across the cut, inside the string opened at c - 100 ...
+        state = int(np.count_nonzero(d[: c - 100] == 0x22) & 1)
+        if state:                               # ... unless that quote CLOSED a string: open another one
+            d[c - 101] = 0x22
+    want = oracle.scalar_read(d)
+    dbufs = [torch.zeros(max(e - b, 1), dtype=torch.uint8, device="cuda:0") for b, e in ranges]
+    caps = [(e - b) + 8 for b, e in ranges]
+    dtapes = [torch.full((c,), -1, dtype=torch.int64, device="cuda:0") for c in caps]
+    sh = pkg.stage1_index_multi(d, ctxs, [t.data_ptr() for t in dbufs], [t.data_ptr() for t in dtapes], caps, 0)
+    torch.cuda.synchronize()
+    parts, base, state = [np.zeros(1, dtype=np.uint64)], 1, 0
+    for i in range(g):
+        b, e = ranges[i]
+        assert (sh[i].begin, sh[i].end) == (b, e)
+        assert bytes(dbufs[i][: e - b].cpu().numpy()) == d[b:e].tobytes()          # the bytes are on the device
+        assert sh[i].stitch.tape_index_base == base and sh[i].stitch.in_quote_in == state
+        assert sh[i].result.in_quote_in_used == state and sh[i].result.count == sh[i].stitch.count
+        k = sh[i].result.count
+        parts.append(dtapes[i][:k].cpu().numpy().view(np.uint64))
+        # (behind its k entries a tape may hold leftovers of a first pass that guessed the other entering state)
+        assert k <= caps[i] and sh[i].result.written == k
+        base += k
+        state = sh[i].result.in_quote_out
+    got = np.concatenate(parts)
+    assert sh[g - 1].stitch.total_entries == want.size == got.size
+    assert np.array_equal(got, want)
+    if g > 1:
+        truth = int(np.count_nonzero(d[: ranges[1][0]] == 0x22) & 1)
+        assert truth == 1 and sh[1].stitch.in_quote_in == 1                        # shard 1 really starts inside a string
+    # capacity protocol: a tape that is too small is reported, nothing is written past it
+    small = torch.full((16,), -1, dtype=torch.int64, device="cuda:0")
+    with pytest.raises(pkg.StructureError) as err:
+        pkg.stage1_index_multi(d, ctxs, [t.data_ptr() for t in dbufs], [small.data_ptr()] + [t.data_ptr() for t in dtapes[1:]],
+                               [8] + caps[1:], 0)
+    assert err.value.code == pkg.ERR_TAPE_CAPACITY and bool((small[8:] == -1).all())
+    # the same context twice is refused (shards run concurrently)
+    if g > 1:
+        with pytest.raises(pkg.StructureError) as err:
+            pkg.stage1_index_multi(d, [ctxs[0]] * g, [t.data_ptr() for t in dbufs], [t.data_ptr() for t in dtapes], caps, 0)
+        assert err.value.code == pkg.ERR_INVALID_ARG
+    for c in ctxs:
+        c.close()
