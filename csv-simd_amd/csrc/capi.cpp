@@ -1391,6 +1391,7 @@ int csvsimd_stage1_time_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len,
             L.escape = (uint8_t)e;
         }
     }
+    if (getenv("CSVSIMD_PROBE_NO_HASHED_DIALECT")) L.allow_hashed_dialect = false;  // escape dialects: force the direct compares
     if (const char* e = getenv("CSVSIMD_PROBE_CU_TOKEN")) L.pace_cu_token = atoi(e);
     if (const char* e = getenv("CSVSIMD_PROBE_EMIT_DELAY")) L.pace_emit_delay = atoi(e);
     if (const char* e = getenv("CSVSIMD_PROBE_COUNT_PRIO")) L.pace_count_prio = atoi(e);
@@ -1454,6 +1455,8 @@ int csvsimd_stage1_time_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len,
 const char* csvsimd_stage1_kernel_name(int emit, const csvsimd_dialect* dialect) {
     int d = 0;
     if (dialect) d = dialect->escape ? 2 : (dialect->delimiter != ',' || dialect->quote != '"') ? 1 : 0;
+    csvsimd::DialectHash dh;
+    if (d == 2 && csvsimd::dialect_hash(dialect->delimiter, dialect->quote, dialect->escape, dh)) d = 3;
     return csvsimd::stage1_kernel_name(emit != 0, d);
 }
 

@@ -54,6 +54,7 @@ struct Stage1Launch {
     // dialect extension (csvsimd_dialect): the defaults are the reference's hard-wired dialect
     uint8_t delimiter = ',', quote = '"', escape = 0;
     uint32_t escape_in = 0;
+    bool allow_hashed_dialect = true;  // escape dialects: use the hashed LUT classification when the bytes allow it
 
     static uint64_t scratch_bytes_for(uint64_t len) {
         // + 1 tile: an unaligned dbuf shifts the data by up to 127 bytes
@@ -67,6 +68,11 @@ struct Stage1Launch {
     }
 };
 
+// hashed classification tables of an escape dialect (stage1_kernels.hip: classify_dword_h); false = no collision-free hash
+struct DialectHash {
+    uint32_t sh1, sh2, lut_lo, lut_hi, cls_lo, cls_hi;
+};
+bool dialect_hash(uint32_t delim, uint32_t quote, uint32_t esc, DialectHash& h);
 hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream);
 hipError_t launch_synth(void* dbuf, uint64_t file_off, uint64_t len, uint32_t cols, uint32_t width,
                         uint64_t seed, uint32_t quote_pct, hipStream_t stream);

@@ -171,7 +171,27 @@ __device__ __forceinline__ void classify16(uint4 v, u32& st16, u32& q16) {
 struct DialectRegs {
     u32 delim, quote, esc;  // the byte replicated into all four lanes of a dword
     u32 qmask;              // 0x80808080, or 0 when the dialect has no quote byte
+    // DIALECT 3 (hashed): key = ((b >> sh1) ^ (b >> sh2)) & 7 is distinct for the dialect's special bytes (found by the
+    // host); LUT slot `key` holds the only special byte with that key / its class (0x80 structural, 0x40 quote, 0x20 escape)
+    u32 sh1, sh2, lut_lo, lut_hi, cls_lo, cls_hi;
 };
+
+// DIALECT 3: the default kernel's trick for ANY delimiter / quote / escape byte whose 3-bit two-shift hash is collision
+// free (96 % of all triples; the host searches the two shifts, csvsimd::dialect_hash, and falls back to DIALECT 2's
+// direct compares otherwise): one v_perm LUT for "the only special byte with this key", ONE zero test instead of five,
+// a second v_perm for that byte's class.  15 VALU per dword for three masks (direct compares: 17).
+__device__ __forceinline__ void classify_dword_h(u32 x, u32 w, const DialectRegs& dr, u32& acc_s, u32& acc_q, u32& acc_e) {
+    const u32 key = ((x >> dr.sh1) ^ (x >> dr.sh2)) & 0x07070707u;
+    const u32 e = __builtin_amdgcn_perm(dr.lut_hi, dr.lut_lo, key);
+    const u32 nz = __builtin_amdgcn_lerp(x ^ e, 0xffffffffu, 0u);  // bit 7 of a byte: it is NOT its slot's special byte
+    const u32 cls = __builtin_amdgcn_perm(dr.cls_hi, dr.cls_lo, key);
+    const u32 fs = ~nz & cls & 0x80808080u;
+    const u32 fq = ~nz & (cls << 1) & 0x80808080u;
+    const u32 fe = ~nz & (cls << 2) & 0x80808080u;
+    acc_s = __builtin_amdgcn_udot4(fs, w, acc_s, false);
+    acc_q = __builtin_amdgcn_udot4(fq, w, acc_q, false);
+    acc_e = __builtin_amdgcn_udot4(fe, w, acc_e, false);
+}
 
 template <int DIALECT>
 __device__ __forceinline__ void classify_dword_d(u32 x, u32 w, const DialectRegs& dr, u32& acc_s, u32& acc_q,
@@ -193,10 +213,17 @@ __device__ __forceinline__ void classify_dword_d(u32 x, u32 w, const DialectRegs
 template <int DIALECT>
 __device__ __forceinline__ void classify16_d(uint4 v, const DialectRegs& dr, u32& st16, u32& q16, u32& e16) {
     u32 s_lo = 0, q_lo = 0, e_lo = 0, s_hi = 0, q_hi = 0, e_hi = 0;
-    classify_dword_d<DIALECT>(v.x, 0x08040201u, dr, s_lo, q_lo, e_lo);
-    classify_dword_d<DIALECT>(v.y, 0x80402010u, dr, s_lo, q_lo, e_lo);
-    classify_dword_d<DIALECT>(v.z, 0x08040201u, dr, s_hi, q_hi, e_hi);
-    classify_dword_d<DIALECT>(v.w, 0x80402010u, dr, s_hi, q_hi, e_hi);
+    if (DIALECT == 3) {
+        classify_dword_h(v.x, 0x08040201u, dr, s_lo, q_lo, e_lo);
+        classify_dword_h(v.y, 0x80402010u, dr, s_lo, q_lo, e_lo);
+        classify_dword_h(v.z, 0x08040201u, dr, s_hi, q_hi, e_hi);
+        classify_dword_h(v.w, 0x80402010u, dr, s_hi, q_hi, e_hi);
+    } else {
+        classify_dword_d<DIALECT>(v.x, 0x08040201u, dr, s_lo, q_lo, e_lo);
+        classify_dword_d<DIALECT>(v.y, 0x80402010u, dr, s_lo, q_lo, e_lo);
+        classify_dword_d<DIALECT>(v.z, 0x08040201u, dr, s_hi, q_hi, e_hi);
+        classify_dword_d<DIALECT>(v.w, 0x80402010u, dr, s_hi, q_hi, e_hi);
+    }
     st16 = (s_lo >> 7) | (s_hi << 1);
     q16 = (q_lo >> 7) | (q_hi << 1);
     e16 = (e_lo >> 7) | (e_hi << 1);
@@ -566,7 +593,7 @@ __device__ __forceinline__ void count_phase(rsrc_t rsrc, u32 lane, u32 w, const 
         // opaque: the eight read addresses (4 chunks x 2 images) are cheap to rebuild (one v_xad each) but,
         // hoisted out of the tile loop, they are what hipcc spills — and a scratch reload in here
         // waits for vmcnt(0), i.e. for the LDS-DMA prefetch of the next rounds (measured: -9 %)
-        if (DIALECT == 2) {
+        if (DIALECT >= 2) {
             // the escape variant is short of registers by its third mask: there even `rslot` gets spilled,
             // so it is rebuilt from the lane id (always live) behind the same kind of fence
             u32 l = lane;
@@ -598,7 +625,7 @@ __device__ __forceinline__ void count_phase(rsrc_t rsrc, u32 lane, u32 w, const 
         if (r == 0) keep &= ek.front_keep;
         u64 st = ((u64)(st16[0] | (st16[1] << 16)) | ((u64)(st16[2] | (st16[3] << 16)) << 32)) & keep;
         u64 x = ((u64)(q16[0] | (q16[1] << 16)) | ((u64)(q16[2] | (q16[3] << 16)) << 32)) & keep;
-        if (DIALECT == 2) {
+        if (DIALECT >= 2) {
             u64 bs = ((u64)(e16[0] | (e16[1] << 16)) | ((u64)(e16[2] | (e16[3] << 16)) << 32)) & keep;
             if (r == 0) bs |= ek.front_esc;
             // escape bytes are rare: a round whose 4 KiB hold none, entered with no pending escape, skips the rest
@@ -638,7 +665,7 @@ __device__ __forceinline__ void count_phase(rsrc_t rsrc, u32 lane, u32 w, const 
         cnt_a += (u32)__builtin_popcountll(m[r].st & ~m[r].s);
         cnt_t += (u32)__builtin_popcountll(m[r].st);
         // anchor this round's results here: an opaque asm cannot be sunk or re-ordered
-        if (DIALECT == 2)  // (an "s" operand downstream of the round's uniform branch does not compile: hipcc 7.2)
+        if (DIALECT >= 2)  // (an "s" operand downstream of the round's uniform branch does not compile: hipcc 7.2)
             asm volatile("" : "+v"(m[r].st), "+v"(m[r].s), "+v"(cnt_a), "+v"(cnt_t));
         else
             asm volatile("" : "+v"(m[r].st), "+v"(m[r].s), "+v"(cnt_a), "+v"(cnt_t), "+s"(carry));
@@ -686,6 +713,7 @@ struct KernelArgs {
     // dialect variants only (DIALECT != 0)
     u32 delim, quote, escape;  // bytes; quote / escape 0 = feature off
     u32 escape_in;             // the first byte of the shard is escaped
+    u32 hash_sh1, hash_sh2, hash_lut_lo, hash_lut_hi, hash_cls_lo, hash_cls_hi;  // DIALECT 3 (see DialectRegs)
     // pacing knobs, chosen by the host from the launch size
     u32 emit_delay;  // x 640 cycles of s_sleep between barrier B and the emit phase
     u32 count_prio;  // 1: count phases run at s_setprio 3
@@ -702,9 +730,11 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // launches; re-read where it is needed rather than carried through the tile loop in a register)
 template <int DIALECT>
 __device__ __forceinline__ u32 escape_in_of(const KernelArgs& args) {
-    if (DIALECT != 2) return 0u;
-    if (args.chain)
-        return (u32)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&args.chain->escape_out, __ATOMIC_RELAXED,
+    if (DIALECT < 2) return 0u;
+    const csvsimd_shard_result* c = args.chain;
+    asm volatile("" : "+s"(c));  // the test is redone here, from the SGPR pair: hoisted out of the tile loop it becomes a spilled VGPR
+    if (c)
+        return (u32)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&c->escape_out, __ATOMIC_RELAXED,
                                                                         __HIP_MEMORY_SCOPE_AGENT)) & 1u;
     return args.escape_in;
 }
@@ -872,6 +902,7 @@ __device__ __forceinline__ void finish_launch(const KernelArgs& args, u32 epoch,
     u32 e = 0;
     // CSVSIMD_ENTER_GUESS and this workgroup never resolved a tile: the choice of tile 0's workgroup is there by now
     // (every workgroup has finished); an empty shard has no tile 0 and is "entered outside"
+    if (DIALECT >= 2) asm volatile("" : "+s"(inq_in));  // see uniform_again
     if (inq_in == kEnterGuessFwd) inq_in = args.num_tiles ? wait_for_guess(ctl, e) : 0u;
     u32 state_out = inq_in;
     u64 count = 0;
@@ -889,7 +920,7 @@ __device__ __forceinline__ void finish_launch(const KernelArgs& args, u32 epoch,
     e |= err_seen;  // every other workgroup raised its flag before it counted itself done
     // escape dialect: is the byte after the shard escaped? (chains into the next shard's escape_in)
     u32 esc_out = 0;
-    if (DIALECT == 2)
+    if (DIALECT >= 2)
         esc_out = escape_run_parity(args.abase, args.lo, args.hi, args.hi, args.escape, escape_in_of<DIALECT>(args), lane);
     const u32 next_epoch = (epoch + 1u) & kEpochMask;
     u32 hwm = hwm_seen > args.num_tiles ? hwm_seen : args.num_tiles;
@@ -1044,6 +1075,15 @@ __device__ __forceinline__ u32 wait_for_guess(Control* ctl, u32& err) {
     }
 }
 
+// Escape dialects: a loop-invariant test of a kernel argument (count_prio != 0, in_quote_in == GUESS) is hoisted out of the
+// tile loop by hipcc as a 0/1 VALUE — and, the uniform state of the loop exceeding a wave's SGPRs, that value ends up in a
+// VGPR, which is then spilled to scratch.  Behind this fence the test is redone where it is used, from the SGPR.
+template <int DIALECT>
+__device__ __forceinline__ u32 uniform_again(u32 v) {
+    if (DIALECT >= 2) asm volatile("" : "+s"(v));
+    return v;
+}
+
 template <bool EMIT, int DBG = 0, int DIALECT = 0>
 __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
     __shared__ u32 s_tile;
@@ -1055,6 +1095,10 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
     __shared__ uint4 s_stage[kWaves][kRoundBytes / 16];
     __shared__ uint4 s_stage_b[kWaves][kRoundBytes / 16];
     static_assert(kCompCap * 2 <= kRoundBytes, "compaction window must fit the stage image");
+    // escape dialects only (the array does not exist in the other instantiations): the masks of the held tile's LAST
+    // round are parked here across the count phase of the next tile — those variants are four VGPRs short there (a third
+    // mask and the run-parity chain are in flight), and what hipcc spills otherwise is exactly this pair, to scratch
+    __shared__ uint4 s_park[DIALECT >= 2 ? kWaves : 1][DIALECT >= 2 ? 64 : 1];
 
     const u32 t = threadIdx.x;
     const u32 lane = t & 63u;
@@ -1174,15 +1218,23 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
             // ---- count phase: masks for the whole span stay in registers ---------------------
             u32 carry = 0, cnt_a = 0, cnt_t = 0;
             const EdgeKeep ek = edge_keep_of_tile(lane, w, lo_rel, hi_rel, escape_in_of<DIALECT>(args));
-            DialectRegs dr = {0, 0, 0, 0};
+            DialectRegs dr = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             u32 esc_carry = 0;
-            if (DIALECT != 0) {
+            if (DIALECT == 1 || DIALECT == 2) {
                 dr.delim = args.delim * 0x01010101u;
                 dr.quote = args.quote * 0x01010101u;
                 dr.esc = args.escape * 0x01010101u;
                 dr.qmask = args.quote ? 0x80808080u : 0u;
             }
-            if (DIALECT == 2) {
+            if (DIALECT == 3) {
+                dr.sh1 = args.hash_sh1;
+                dr.sh2 = args.hash_sh2;
+                dr.lut_lo = args.hash_lut_lo;
+                dr.lut_hi = args.hash_lut_hi;
+                dr.cls_lo = args.hash_cls_lo;
+                dr.cls_hi = args.hash_cls_hi;
+            }
+            if (DIALECT >= 2) {
                 // escape state entering this wave span: parity of the escape run that ends right
                 // before it (one 64-byte peek; a misaligned shard start is handled by ek.front_esc)
                 const u64 span0 = tile0 + (u64)w * kSpanBytes;
@@ -1205,10 +1257,10 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
             } else {
                 // pacing (DESIGN.md §4 "Pacing"): the phase that keeps HBM loads in flight gets the SIMD's issue
                 // priority over the partner workgroup's resolve / emit phase
-                if (args.count_prio) __builtin_amdgcn_s_setprio(3);
+                if (uniform_again<DIALECT>(args.count_prio)) __builtin_amdgcn_s_setprio(3);
                 count_phase<DIALECT>(rsrc, lane, w, ek, s_stage[w], s_stage_b[w], m, carry, cnt_a, cnt_t, dr,
                                      esc_carry);
-                if (args.count_prio) __builtin_amdgcn_s_setprio(0);
+                if (uniform_again<DIALECT>(args.count_prio)) __builtin_amdgcn_s_setprio(0);
             }
             const u32 wave_a = wave_sum(cnt_a);
             const u32 wave_t = wave_sum(cnt_t);
@@ -1251,7 +1303,7 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
                 wg_tot += (u64)(u32)__builtin_amdgcn_readfirstlane((int)(agg.a + agg.b));
             }
             // a shard whose entering state nobody knows: the first kGuessTiles tiles vote (see guess_vote)
-            if (inq_in == kEnterGuess && have_cur && tile < kGuessTiles && !(DBG & 4))
+            if (uniform_again<DIALECT>(inq_in) == kEnterGuess && have_cur && tile < kGuessTiles && !(DBG & 4))
                 guess_vote(args.desc, args.ctl, args.num_tiles, epoch, lane, err);
             // into wave 0's second stage image: idle until the next count phase
             if (have_held && !(DBG & 4)) lookback_issue(args.desc, held_tile, lane, s_stage_b[0]);
@@ -1261,6 +1313,11 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
         const u32 spec_state = spec_pin ^ held_before.p;             // this wave's entering state under it
         const u32 spec_n = spec_state ? held_wb : held_wa;           // ... and its entry count
         if (EMIT && have_held && !(DBG & 16) && spec_n <= (u32)kCompCap) {
+            if (DIALECT >= 2) {
+                const uint4 pk = s_park[w][lane];
+                held[kRounds - 1].st = ((u64)pk.y << 32) | pk.x;
+                held[kRounds - 1].s = ((u64)pk.w << 32) | pk.z;
+            }
             scatter_span_spec(held, lane, spec_state, reinterpret_cast<unsigned short*>(s_stage[w]));
             spec_done = true;
         }
@@ -1270,7 +1327,8 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
             if (!(DBG & 4)) {
                 u64 pre[4];
                 // CSVSIMD_ENTER_GUESS: the choice was published before tile 0's aggregate, a tile-time ago at least
-                const u32 inq_eff = inq_in == kEnterGuess ? wait_for_guess(args.ctl, err) : inq_in;
+                const u32 inq_now = uniform_again<DIALECT>(inq_in);
+                const u32 inq_eff = inq_now == kEnterGuess ? wait_for_guess(args.ctl, err) : inq_now;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef CSVSIMD_DEV_PROBES
                 if (DBG & 32) trace_landed = __builtin_amdgcn_s_memrealtime();
@@ -1321,6 +1379,11 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
                              args.base_off + span0 - args.lo, lane);
                 wave_lds_fence();
             } else {
+                if (DIALECT >= 2) {  // (the speculative scatter may not have run: the pair is fetched again)
+                    const uint4 pk = s_park[w][lane];
+                    held[kRounds - 1].st = ((u64)pk.y << 32) | pk.x;
+                    held[kRounds - 1].s = ((u64)pk.w << 32) | pk.z;
+                }
                 emit_span<(DBG & 16) != 0>(args, held, lane, span0, wstate, run,
                                            reinterpret_cast<unsigned short*>(s_stage[w]));
             }
@@ -1343,7 +1406,10 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
         held_wa = cur_wa;
         held_wb = cur_wb;
 #pragma unroll
-        for (int r = 0; r < kRounds; ++r) held[r] = m[r];
+        for (int r = 0; r < kRounds - (DIALECT >= 2 ? 1 : 0); ++r) held[r] = m[r];
+        if (DIALECT >= 2)
+            s_park[w][lane] = make_uint4((u32)m[kRounds - 1].st, (u32)(m[kRounds - 1].st >> 32), (u32)m[kRounds - 1].s,
+                                         (u32)(m[kRounds - 1].s >> 32));
         CSVSIMD_STAMP(5)  // emit
         // the tickets are exhausted for good and nothing is held any more: leave without another trip through the token
         // and the ticket counter.  Measured and rejected around this hand-off (ab_variants, 8 GiB / 1 GiB):
@@ -1617,6 +1683,45 @@ __global__ void stitch_kernel(const csvsimd_shard_result* __restrict__ results, 
     }
 #endif
 
+// DIALECT 3's tables for the special bytes {delimiter, CR, LF, quote, escape} (quote 0 = none): two shifts in 0..5 (the
+// three key bits of a byte must not reach into the next byte of the dword) whose xor gives every special byte its own
+// 3-bit key.  An unused LUT slot holds a special byte whose OWN key is another one, so no byte with that key can equal it.
+bool dialect_hash(u32 delim, u32 quote, u32 esc, DialectHash& h) {
+    u32 sp[5], cls[5], n = 0;
+    sp[n] = delim; cls[n++] = 0x80;
+    sp[n] = 0x0d; cls[n++] = 0x80;
+    sp[n] = 0x0a; cls[n++] = 0x80;
+    if (quote) { sp[n] = quote; cls[n++] = 0x40; }
+    if (esc) { sp[n] = esc; cls[n++] = 0x20; }
+    for (u32 s1 = 0; s1 <= 5; ++s1)
+        for (u32 s2 = s1 + 1; s2 <= 5; ++s2) {
+            u32 key[5], seen = 0;
+            bool ok = true;
+            for (u32 i = 0; i < n && ok; ++i) {
+                key[i] = ((sp[i] >> s1) ^ (sp[i] >> s2)) & 7u;
+                ok = !((seen >> key[i]) & 1u);
+                seen |= 1u << key[i];
+            }
+            if (!ok) continue;
+            uint8_t lut[8], cl[8];
+            for (u32 k = 0; k < 8; ++k) {
+                u32 pick = 0;
+                while (key[pick] == k) ++pick;  // n >= 3 distinct keys: one of the first two differs from k
+                lut[k] = (uint8_t)sp[pick];
+                cl[k] = 0;
+            }
+            for (u32 i = 0; i < n; ++i) { lut[key[i]] = (uint8_t)sp[i]; cl[key[i]] = (uint8_t)cls[i]; }
+            h.sh1 = s1;
+            h.sh2 = s2;
+            h.lut_lo = lut[0] | lut[1] << 8 | lut[2] << 16 | (u32)lut[3] << 24;
+            h.lut_hi = lut[4] | lut[5] << 8 | lut[6] << 16 | (u32)lut[7] << 24;
+            h.cls_lo = cl[0] | cl[1] << 8 | cl[2] << 16 | (u32)cl[3] << 24;
+            h.cls_hi = cl[4] | cl[5] << 8 | cl[6] << 16 | (u32)cl[7] << 24;
+            return true;
+        }
+    return false;
+}
+
 hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream) {
     const uintptr_t addr = (uintptr_t)L.dbuf;
     KernelArgs a;
@@ -1659,8 +1764,17 @@ hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream) {
 #ifdef CSVSIMD_DEV_PROBES
     a.prof = L.scratch_prof;
 #endif
-    // 0 = the reference dialect (the tuned LUT classification), 1 = other delimiter / quote, 2 = + escape
-    const int dialect = L.escape ? 2 : (L.delimiter != ',' || L.quote != '"') ? 1 : 0;
+    // 0 = the reference dialect (the tuned LUT classification), 1 = other delimiter / quote, 2 = + escape (direct
+    // compares), 3 = + escape with the hashed LUT classification (when the special bytes have a collision-free hash)
+    int dialect = L.escape ? 2 : (L.delimiter != ',' || L.quote != '"') ? 1 : 0;
+    a.hash_sh1 = a.hash_sh2 = a.hash_lut_lo = a.hash_lut_hi = a.hash_cls_lo = a.hash_cls_hi = 0;
+    DialectHash dh;
+    if (dialect == 2 && L.allow_hashed_dialect && dialect_hash(L.delimiter, L.quote, L.escape, dh)) {
+        dialect = 3;
+        a.hash_sh1 = dh.sh1; a.hash_sh2 = dh.sh2;
+        a.hash_lut_lo = dh.lut_lo; a.hash_lut_hi = dh.lut_hi;
+        a.hash_cls_lo = dh.cls_lo; a.hash_cls_hi = dh.cls_hi;
+    }
 
     // ONE kernel per launch: an empty shard still runs one workgroup, which writes the result record
     const u32 want = a.num_tiles ? a.num_tiles : 1u;
@@ -1679,7 +1793,11 @@ hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream) {
     CSVSIMD_PROBE_LAUNCH(8, false)
 #endif
     if (launched) {
-    } else if (dialect == 2 && a.tape)
+    } else if (dialect == 3 && a.tape)
+        hipLaunchKernelGGL((stage1_kernel<true, 0, 3>), dim3(grid), dim3(kThreads), 0, stream, a);
+    else if (dialect == 3)
+        hipLaunchKernelGGL((stage1_kernel<false, 0, 3>), dim3(grid), dim3(kThreads), 0, stream, a);
+    else if (dialect == 2 && a.tape)
         hipLaunchKernelGGL((stage1_kernel<true, 0, 2>), dim3(grid), dim3(kThreads), 0, stream, a);
     else if (dialect == 2)
         hipLaunchKernelGGL((stage1_kernel<false, 0, 2>), dim3(grid), dim3(kThreads), 0, stream, a);
@@ -1699,14 +1817,16 @@ hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream) {
 
 // name of the kernel launch_stage1 runs for this configuration (bench.py reports it next to the time)
 const char* stage1_kernel_name(bool emit, int dialect) {
-    static const char* names[2][3] = {
+    static const char* names[2][4] = {
         {"void csvsimd::stage1_kernel<false, 0, 0>(csvsimd::KernelArgs)",
          "void csvsimd::stage1_kernel<false, 0, 1>(csvsimd::KernelArgs)",
-         "void csvsimd::stage1_kernel<false, 0, 2>(csvsimd::KernelArgs)"},
+         "void csvsimd::stage1_kernel<false, 0, 2>(csvsimd::KernelArgs)",
+         "void csvsimd::stage1_kernel<false, 0, 3>(csvsimd::KernelArgs)"},
         {"void csvsimd::stage1_kernel<true, 0, 0>(csvsimd::KernelArgs)",
          "void csvsimd::stage1_kernel<true, 0, 1>(csvsimd::KernelArgs)",
-         "void csvsimd::stage1_kernel<true, 0, 2>(csvsimd::KernelArgs)"}};
-    return names[emit ? 1 : 0][dialect < 0 || dialect > 2 ? 0 : dialect];
+         "void csvsimd::stage1_kernel<true, 0, 2>(csvsimd::KernelArgs)",
+         "void csvsimd::stage1_kernel<true, 0, 3>(csvsimd::KernelArgs)"}};
+    return names[emit ? 1 : 0][dialect < 0 || dialect > 3 ? 0 : dialect];
 }
 
 hipError_t launch_synth(void* dbuf, u64 file_off, u64 len, u32 cols, u32 width, u64 seed, u32 quote_pct,

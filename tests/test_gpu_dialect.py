@@ -121,6 +121,37 @@ def test_escape_with_other_delimiters_and_without_quoting(ctx, pkg, torch_cuda, 
                 check(ctx, pkg, torch_cuda, oracle, d, dia, in_quote_in=int(rng.integers(0, 2)), misalign=mis)
 
 
+def test_escape_hashed_and_compare_classification_agree_with_the_definition(ctx, pkg, torch_cuda, oracle):
+    """An escape dialect runs one of two classifications: the hashed LUT (kernel <..., 3>: the special bytes have a
+    collision-free 3-bit hash, most triples) or the direct compares (<..., 2>: the fallback).  The library says which
+    (csvsimd_stage1_kernel_name); triples of BOTH kinds — and all 256 byte values in the data — against the scalar
+    definition, with and without a quote byte, across tile boundaries and misaligned."""
+    torch = torch_cuda
+    rng = np.random.default_rng(2718)
+    T = pkg.tile_bytes()
+    cand = [(d, q, e) for d in (0x2C, 0x3B, 0x09, 0x7C, 0x20, 0x3A, 0x41, 0xE9) for q in (0x22, 0x27, 0x60, 0, 0xAB)
+            for e in (0x5C, 0x5E, 0x7E, 0x25, 0x2F, 0xB1) if len({d, q, e, 0x0A, 0x0D}) == 5 or (q == 0 and len({d, e, 0x0A, 0x0D}) == 4)]
+    kinds = {2: [], 3: []}
+    for d, q, e in cand:
+        name = pkg.stage1_kernel_name(True, pkg.Dialect(d, q or None, e))
+        kinds[int(name.split(",")[-1].split(">")[0])].append((d, q, e))
+    assert len(kinds[3]) > len(kinds[2]) > 0, {k: len(v) for k, v in kinds.items()}     # both paths exist in this sample
+    for kind in (2, 3):
+        for d, q, e in kinds[kind][:6]:
+            dia = pkg.Dialect(d, q or None, e)
+            special = np.array([d, e, 0x0A, 0x0D] + ([q] if q else []), dtype=np.uint8)
+            n = 2 * T + 777
+            data = rng.integers(0, 256, size=n, dtype=np.uint8)                          # every byte value occurs
+            hit = rng.random(n) < 0.15
+            data[hit] = special[rng.integers(0, special.size, size=int(hit.sum()))]      # ... and the special ones often
+            for mis in (0, 5):
+                check(ctx, pkg, torch, oracle, data, dia, misalign=mis, in_quote_in=mis & 1)
+            # neighbours of every special byte (one bit away): never classified as special
+            near = np.array(sorted({int(b) ^ (1 << k) for b in special for k in range(8)} - set(int(b) for b in special)),
+                            dtype=np.uint8)
+            check(ctx, pkg, torch, oracle, np.tile(near, 300), dia)
+
+
 def test_escape_runs_across_every_boundary(ctx, pkg, torch_cuda, oracle):
     # runs of escape bytes that end at / straddle stripe (64 B), round (4 KiB), wave-span (32 KiB)
     # and tile boundaries, including runs longer than one and two whole stripes
