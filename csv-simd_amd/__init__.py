@@ -92,6 +92,12 @@ class Stitch(C.Structure):
     ]
 
 
+class BatchItem(C.Structure):
+    """csvsimd_batch_item: one buffer of csvsimd_stage1_index_batch_device_async."""
+    _fields_ = [("dbuf", C.c_void_p), ("len", C.c_uint64), ("base_off", C.c_uint64), ("dtape", C.c_void_p),
+                ("tape_cap", C.c_uint64), ("in_quote_in", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 class MultiShard(C.Structure):
     """csvsimd_multi_shard: one shard of csvsimd_stage1_index_multi (in: ctx, dbuf, dtape, tape_cap; out: the rest)."""
     _fields_ = [("ctx", C.c_void_p), ("dbuf", C.c_void_p), ("dtape", C.c_void_p), ("tape_cap", C.c_uint64),
@@ -154,6 +160,8 @@ _PROTOTYPES = {
     "csvsimd_stage1_bound": (C.c_int, [C.c_uint64, _u64p]),
     "csvsimd_stage1_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, _u64p,
                                        C.POINTER(C.c_uint32)]),
+    "csvsimd_stage1_index_batch_device_async": (C.c_int, [C.c_void_p, C.POINTER(BatchItem), C.c_uint32, C.c_void_p,
+                                                          C.c_void_p]),
     "csvsimd_multi_shard_range": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, _u64p, _u64p]),
     "csvsimd_stage1_index_multi": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(MultiShard), C.c_uint32, C.c_uint32]),
     "csvsimd_stitch_shards": (C.c_int, [C.POINTER(ShardResult), C.c_uint32, C.c_uint32, C.c_uint32,
@@ -296,6 +304,15 @@ class Context:
                                   tape_cap: int, d_result: int, stream: int = 0) -> None:
         _check(lib().csvsimd_stage1_index_device_async(self._h, dbuf, length, base_off, in_quote_in,
                                                        dtape or None, tape_cap, d_result, stream or None))
+
+    def stage1_index_batch_device_async(self, items, d_results: int, stream: int = 0) -> None:
+        """ONE launch over many buffers: items = [(dbuf, length, base_off, dtape, tape_cap, in_quote_in), ...]; record i
+        of d_results (device, 64 bytes each) is what stage1_index_device_async would have written for buffer i alone."""
+        arr = (BatchItem * len(items))()
+        for i, (dbuf, length, base_off, dtape, cap, inq) in enumerate(items):
+            arr[i].dbuf, arr[i].len, arr[i].base_off = dbuf or None, length, base_off
+            arr[i].dtape, arr[i].tape_cap, arr[i].in_quote_in = dtape or None, cap, inq
+        _check(lib().csvsimd_stage1_index_batch_device_async(self._h, arr, len(items), d_results, stream or None))
 
     def stage1_reemit_device_async(self, dbuf: int, length: int, base_off: int, d_stitch: int, dtape: int,
                                    tape_cap: int, d_result: int, stream: int = 0) -> None:

@@ -237,6 +237,8 @@ struct csvsimd_ctx {
     csvsimd_shard_result* h_res = nullptr;     // pinned, 2 records
     hipEvent_t ev_rec[2] = {nullptr, nullptr}; // result record of the slot's chunk has landed in h_res[k] (and its tape in pin_out[k])
     std::unique_ptr<CopyPool> copier;         // host-side slices of the staging copies
+    void* d_batch = nullptr;                  // csvsimd_stage1_index_batch_device_async: the buffers' table (64 B per buffer)
+    uint32_t d_batch_items = 0;
 };
 
 extern "C" {
@@ -307,6 +309,7 @@ void csvsimd_ctx_destroy(csvsimd_ctx* ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->d_result) (void)hipFree(ctx->d_result);
     if (ctx->d_small) (void)hipFree(ctx->d_small);
+    if (ctx->d_batch) (void)hipFree(ctx->d_batch);
     for (int k = 0; k < 2; ++k) {
         if (ctx->pin_in[k]) (void)hipHostFree(ctx->pin_in[k]);
         if (ctx->pin_out[k]) (void)hipHostFree(ctx->pin_out[k]);
@@ -412,6 +415,60 @@ int csvsimd_stitch_shards_device_async(const void* d_results, uint32_t n_shards,
     if (csvsimd_device_count() <= 0) return CSVSIMD_ERR_NO_DEVICE;
     HIP_TRY(csvsimd::launch_stitch(d_results, n_shards, rank, file_in_quote_in, d_stitch, (hipStream_t)hip_stream));
     return CSVSIMD_OK;
+}
+
+/* ---- K independent buffers in ONE persistent launch ------------------------------------------------------------ */
+int csvsimd_stage1_index_batch_device_async(csvsimd_ctx* ctx, const csvsimd_batch_item* items, uint32_t n_items,
+                                            void* d_results, void* hip_stream) {
+    return csvsimd_guarded([&]() -> int {
+    if (!ctx || !items || n_items == 0 || n_items > 65536 || !d_results || ((uintptr_t)d_results & 15))
+        return CSVSIMD_ERR_INVALID_ARG;
+    std::vector<csvsimd::BatchItemHost> table(n_items);
+    uint64_t tiles = 0;
+    for (uint32_t i = 0; i < n_items; ++i) {
+        const csvsimd_batch_item& it = items[i];
+        if ((it.len && !it.dbuf) || (!it.dtape && it.tape_cap) || ((uintptr_t)it.dtape & 7) || it.in_quote_in > 1 ||
+            it.len >= (1ull << 39))
+            return CSVSIMD_ERR_INVALID_ARG;
+        const uintptr_t addr = (uintptr_t)it.dbuf;
+        csvsimd::BatchItemHost& t = table[i];
+        t.abase = (const void*)(addr & ~(uintptr_t)15);
+        t.lo = addr & 15;
+        t.hi = t.lo + it.len;
+        t.base_off = it.base_off;
+        t.tape = it.dtape;
+        t.tape_cap = it.dtape ? it.tape_cap : 0;
+        t.first_tile = (uint32_t)tiles;
+        t.in_quote_in = it.in_quote_in;
+        t.tot = 0;
+        tiles += it.len ? (t.hi + CSVSIMD_TILE_BYTES - 1) / CSVSIMD_TILE_BYTES : 0;
+        if (tiles >= (1ull << 31)) return CSVSIMD_ERR_INVALID_ARG;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    // scratch: one descriptor word per tile of the whole batch (allocates + synchronises only when it has to grow)
+    int rc = csvsimd_ctx_reserve(ctx, tiles * CSVSIMD_TILE_BYTES);
+    if (rc != CSVSIMD_OK) return rc;
+    if (ctx->d_batch_items < n_items) {
+        if (ctx->launched) HIP_TRY(hipDeviceSynchronize());  // an earlier batch may still be reading the old table
+        if (ctx->d_batch) HIP_TRY(hipFree(ctx->d_batch));
+        ctx->d_batch = nullptr;
+        ctx->d_batch_items = 0;
+        const uint32_t cap = std::max<uint32_t>(64, n_items);
+        HIP_TRY(hipMalloc(&ctx->d_batch, (size_t)cap * sizeof(csvsimd::BatchItemHost)));
+        ctx->d_batch_items = cap;
+    }
+    hipStream_t s = (hipStream_t)hip_stream;
+    // from pageable memory: the runtime has taken its copy of `table` when this returns, and the transfer itself is
+    // ordered on the stream behind whatever batch is still running from the device table
+    HIP_TRY(hipMemcpyAsync(ctx->d_batch, table.data(), (size_t)n_items * sizeof(csvsimd::BatchItemHost), hipMemcpyHostToDevice, s));
+    csvsimd::Stage1Launch L;
+    L.bind_scratch(ctx->scratch);
+    ctx->last_stream = s;
+    ctx->launched = true;
+    HIP_TRY(csvsimd::launch_stage1_batch(ctx->d_batch, n_items, (uint32_t)tiles, (csvsimd_shard_result*)d_results, ctx->scratch,
+                                         L.scratch_desc, ctx->max_blocks, s));
+    return CSVSIMD_OK;
+    });
 }
 
 int csvsimd_dialect_init(csvsimd_dialect* d) {

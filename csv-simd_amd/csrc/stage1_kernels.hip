@@ -363,7 +363,9 @@ __device__ __forceinline__ void lookback_fetch(const uint4* lds, u32 tile, u32 l
 template <bool PRE = false>
 __device__ __forceinline__ void resolve(u64* desc, u32 tile, u32 epoch, Desc agg, u32 in_quote_in, u32 lane_in,
                                         u32& pin_out, u64& base_out, u32& err, const u64* pre = nullptr,
-                                        u32* dbg_windows_spins = nullptr) {
+                                        u32* dbg_windows_spins = nullptr, u32 first_tile = 0) {
+    // first_tile: batched launches — the first tile of the BUFFER `tile` belongs to (tiles of all buffers share one index
+    // space and one descriptor array); the words before it are other buffers' and read as the virtual word
     const u32 lane = lane_in;
     u32 dbg_windows = 0;
     u32 pin = in_quote_in;
@@ -377,7 +379,7 @@ __device__ __forceinline__ void resolve(u64* desc, u32 tile, u32 epoch, Desc agg
     // before this tile and normally publishes last of the ~100 tiles the window needs; 1024 control
     // waves each re-reading 256 words every few hundred cycles would cost more fabric bandwidth than
     // the CSV stream itself (measured: -20 % chip throughput).
-    if (!PRE && tile != 0) {
+    if (!PRE && tile != first_tile) {
         for (;;) {
             u64 x;
             const u32 st = decode_desc(load_desc(desc + (tile - 1)), epoch, x);
@@ -397,7 +399,7 @@ __device__ __forceinline__ void resolve(u64* desc, u32 tile, u32 epoch, Desc agg
             const int64_t j = hi - (int64_t)(4 * lane + i);
             // virtual tile -1 = inclusive (in_quote_in, 0): the shard's entering state
             d[i] = encode_desc(kStatusInc, epoch, (u64)in_quote_in);
-            if (j >= 0) d[i] = (PRE && use_pre) ? pre[i] : load_desc(desc + j);
+            if (j >= (int64_t)first_tile) d[i] = (PRE && use_pre) ? pre[i] : load_desc(desc + j);
         }
         use_pre = false;
 #pragma unroll
@@ -690,6 +692,18 @@ struct Control {
 };
 static_assert(sizeof(Control) <= CSVSIMD_SCRATCH_CTL_BYTES, "control block must fit its slot");
 
+struct BatchItem {          // device, 64 bytes; written by the host before the launch (csvsimd_stage1_index_batch_device_async)
+    const uint8_t* abase;   // 16-byte aligned
+    u64 lo, hi;             // valid bytes are abase[lo, hi)
+    u64 base_off;           // tape value of byte abase[lo]
+    u64* tape;
+    u64 tape_cap;
+    u32 first_tile;         // global index of this buffer's first tile
+    u32 in_quote_in;        // 0 / 1
+    u64 tot;                // comma/CR/LF bytes of the buffer: added to by the launch, read and reset by its last workgroup
+};
+static_assert(sizeof(BatchItem) == 64, "one line per buffer");
+
 struct KernelArgs {
     const uint8_t* abase;  // 16-byte aligned
     u64 lo, hi;            // valid bytes are abase[lo, hi)
@@ -710,6 +724,12 @@ struct KernelArgs {
     // enqueued behind chunk i without the host ever reading chunk i's record: the two values the reference carries
     // between 64-byte blocks (inside_str, src/reader.rs:218) carried between launches on the device.
     const csvsimd_shard_result* chain;
+    // optional (batched launch, BATCH instantiation): n_items independent buffers in ONE persistent launch.  Their tiles
+    // share one index space (buffer b owns tiles [first_tile[b], first_tile[b + 1])), one ticket, one descriptor array;
+    // a tile's look-back stops at its buffer's first tile.  abase / lo / hi / base_off / in_quote_in / tape / tape_cap above
+    // are unused then, `result` is an array of n_items records.
+    struct BatchItem* batch;
+    u32 n_items;
     // dialect variants only (DIALECT != 0)
     u32 delim, quote, escape;  // bytes; quote / escape 0 = feature off
     u32 escape_in;             // the first byte of the shard is escaped
@@ -760,12 +780,11 @@ __device__ __forceinline__ u32 comp_slot(u32 k) {
 // Writes window entries comp[0, n) (u16 offsets relative to the span) to tape[run, run + n) as
 // fully coalesced non-temporal stores, 16 bytes (two entries) per lane wherever the address allows.
 template <bool NOSTORE = false>
-__device__ __forceinline__ void flush_window(const KernelArgs& args, const unsigned short* comp, u32 n, u64 run,
+__device__ __forceinline__ void flush_window(u64* const tape, const u64 tape_cap_in, const unsigned short* comp, u32 n, u64 run,
                                              u64 span_off, u32 lane) {
     if (n == 0) return;
     // NOSTORE (development probe): an impossible capacity keeps the loop but drops the stores
-    u64* const tape = args.tape;
-    const u64 tape_cap = NOSTORE ? (args.tape_cap & 1ull) : args.tape_cap;
+    const u64 tape_cap = NOSTORE ? (tape_cap_in & 1ull) : tape_cap_in;
     // Entry k sits at byte address tape + 8 (run + k).  Head entries are peeled so that the main
     // loop's wave stores start on a 128-byte boundary (the L2 line): each 1-KiB store then covers
     // whole lines only.  Measured (scripts/ubench_mem.hip, scripts/exp_width.py): wave stores that
@@ -822,10 +841,10 @@ __device__ __forceinline__ void scatter_bits(unsigned short* comp, u64 R, u32 p,
 // (CSV with long fields) leaves as one long run of 16-byte stores.
 //   wstate: absolute in-string state entering the span; run: tape index of the span's first entry
 template <bool NOSTORE = false>
-__device__ __forceinline__ void emit_span(const KernelArgs& args, const RoundMasks (&m)[kRounds], u32 lane, u64 span0,
-                                          u32 wstate, u64 run, unsigned short* comp) {
+__device__ __forceinline__ void emit_span(u64* const tape, const u64 tape_cap, const RoundMasks (&m)[kRounds], u32 lane,
+                                          const u64 span_off /* tape value of the span's byte 0 */, u32 wstate, u64 run,
+                                          unsigned short* comp) {
     const u64 flipall = wstate ? ~0ull : 0ull;
-    const u64 span_off = args.base_off + span0 - args.lo;  // tape value of the span's byte 0
     u32 fill = 0;                                           // entries waiting in the window
 
     // wave-uniform by construction; tell the compiler (it arrives through LDS, i.e. in a VGPR)
@@ -846,7 +865,7 @@ __device__ __forceinline__ void emit_span(const KernelArgs& args, const RoundMas
         const u32 stripe_rel = roff + lane * 64u;
         if (fill + n_r > (u32)kCompCap) {
             wave_lds_fence();
-            flush_window<NOSTORE>(args, comp, fill, run, span_off, lane);
+            flush_window<NOSTORE>(tape, tape_cap, comp, fill, run, span_off, lane);
             wave_lds_fence();
             run += fill;
             fill = 0;
@@ -860,7 +879,7 @@ __device__ __forceinline__ void emit_span(const KernelArgs& args, const RoundMas
                 scatter_bits(comp, R, excl - win, stripe_rel);
                 wave_lds_fence();
                 const u32 n_win = (n_r - win) < (u32)kCompCap ? (n_r - win) : (u32)kCompCap;
-                flush_window<NOSTORE>(args, comp, n_win, run, span_off, lane);
+                flush_window<NOSTORE>(tape, tape_cap, comp, n_win, run, span_off, lane);
                 wave_lds_fence();
                 run += n_win;
             }
@@ -870,7 +889,7 @@ __device__ __forceinline__ void emit_span(const KernelArgs& args, const RoundMas
         __builtin_amdgcn_sched_barrier(0);
     }
     wave_lds_fence();
-    flush_window<NOSTORE>(args, comp, fill, run, span_off, lane);
+    flush_window<NOSTORE>(tape, tape_cap, comp, fill, run, span_off, lane);
     wave_lds_fence();
 }
 
@@ -880,7 +899,7 @@ __device__ __forceinline__ void emit_span(const KernelArgs& args, const RoundMas
 struct Control;
 __device__ __forceinline__ u32 wait_for_guess(Control* ctl, u32& err);
 constexpr u32 kEnterGuessFwd = CSVSIMD_ENTER_GUESS;
-template <int DIALECT, bool NO_LOOKBACK>
+template <int DIALECT, bool NO_LOOKBACK, bool BATCH = false>
 __device__ __forceinline__ void finish_launch(const KernelArgs& args, u32 epoch, u32 inq_in, u64 wg_tot, u32 err, u32 lane) {
     Control* const ctl = args.ctl;
     if (err && lane == 0) atomicOr(&ctl->err, 1u);
@@ -906,7 +925,7 @@ __device__ __forceinline__ void finish_launch(const KernelArgs& args, u32 epoch,
     if (inq_in == kEnterGuessFwd) inq_in = args.num_tiles ? wait_for_guess(ctl, e) : 0u;
     u32 state_out = inq_in;
     u64 count = 0;
-    if (args.num_tiles > 0 && !NO_LOOKBACK) {
+    if (args.num_tiles > 0 && !NO_LOOKBACK && !BATCH) {
         // published by whichever workgroup resolved the last tile, before it counted itself done
         u64 x = 0;
         for (u32 spins = 0;; ++spins) {
@@ -930,8 +949,47 @@ __device__ __forceinline__ void finish_launch(const KernelArgs& args, u32 epoch,
         for (u32 i = lane; i < hwm; i += 64u) args.desc[i] = 0;
         hwm = 0;
     }
+    if (BATCH) {
+        // one record per buffer, 64 buffers at a time: the inclusive word of the buffer's LAST tile holds its count and
+        // leaving state (published by whichever workgroup resolved that tile, before it counted itself done); an empty
+        // buffer has no tile: nothing counted, the state passes through
+        for (u32 b = lane; b < args.n_items; b += 64u) {
+            BatchItem* const it = args.batch + b;
+            const u32 first = it->first_tile;
+            const u32 next = b + 1u < args.n_items ? args.batch[b + 1u].first_tile : args.num_tiles;
+            const u32 inq = it->in_quote_in & 1u;
+            u32 st = inq, eb = e;
+            u64 cnt = 0;
+            if (next > first) {
+                u64 x = 0;
+                for (u32 spins = 0;; ++spins) {
+                    if (decode_desc(load_desc(args.desc + (next - 1u)), epoch, x) == kStatusInc) break;
+                    if (spins > kSpinLimit) { eb = 1; x = inq; break; }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                st = (u32)x & 1u;
+                cnt = x >> 1;
+            }
+            const u64 tot = __hip_atomic_load(&it->tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            csvsimd_shard_result* const r = args.result + b;
+            r->count = cnt;
+            r->count_enter_outside = inq ? tot - cnt : cnt;
+            r->count_enter_inside = inq ? cnt : tot - cnt;
+            r->quote_parity = st ^ inq;
+            r->in_quote_out = st;
+            r->error = eb;
+            r->escape_out = 0;
+            const u64 cap = it->tape ? it->tape_cap : 0;
+            r->written = cnt < cap ? cnt : cap;
+            r->in_quote_in_used = inq;
+            r->reserved0 = 0;
+            r->reserved1 = 0;
+            it->tot = 0;  // the table is ready for the next launch over the same buffers (a replayed graph)
+        }
+    }
     if (lane == 0) {
-        csvsimd_shard_result* const r = args.result;
+        csvsimd_shard_result* const r = BATCH ? nullptr : args.result;
+        if (!BATCH) {
         r->count = count;
         // total = count_enter_outside + count_enter_inside, whichever hypothesis was run
         r->count_enter_outside = inq_in ? total - count : count;
@@ -944,6 +1002,7 @@ __device__ __forceinline__ void finish_launch(const KernelArgs& args, u32 epoch,
         r->in_quote_in_used = inq_in;
         r->reserved0 = 0;
         r->reserved1 = 0;
+        }
         // ready for the next launch (made visible by the end-of-kernel release)
         ctl->ticket = 0;
         ctl->done_tot = 0;
@@ -1078,13 +1137,28 @@ __device__ __forceinline__ u32 wait_for_guess(Control* ctl, u32& err) {
 // Escape dialects: a loop-invariant test of a kernel argument (count_prio != 0, in_quote_in == GUESS) is hoisted out of the
 // tile loop by hipcc as a 0/1 VALUE — and, the uniform state of the loop exceeding a wave's SGPRs, that value ends up in a
 // VGPR, which is then spilled to scratch.  Behind this fence the test is redone where it is used, from the SGPR.
-template <int DIALECT>
+template <bool FENCE>
 __device__ __forceinline__ u32 uniform_again(u32 v) {
-    if (DIALECT >= 2) asm volatile("" : "+s"(v));
+    if (FENCE) asm volatile("" : "+s"(v));
     return v;
 }
 
-template <bool EMIT, int DBG = 0, int DIALECT = 0>
+// Batched launches (BATCH): which buffer does `tile` belong to?  first_tile[] ascends; the buffer is the LAST one whose
+// first tile is <= tile (empty buffers share their successor's first tile and are never chosen).  All 64 lanes look at 64
+// table lines at once: one load + one ballot per 64 buffers.  Wave-uniform result.
+__device__ __forceinline__ u32 batch_item_of(const BatchItem* batch, u32 n_items, u32 tile, u32 lane) {
+    u32 idx = 0;
+    for (u32 b0 = 0; b0 < n_items; b0 += 64u) {
+        const bool le = b0 + lane < n_items && batch[b0 + lane].first_tile <= tile;
+        const u64 m = __ballot(le);
+        if (m == 0) break;
+        idx = b0 + 63u - (u32)__builtin_clzll(m);
+        if (m != ~0ull) break;
+    }
+    return (u32)__builtin_amdgcn_readfirstlane((int)idx);
+}
+
+template <bool EMIT, int DBG = 0, int DIALECT = 0, bool BATCH = false>
 __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
     __shared__ u32 s_tile;
     __shared__ u32 s_wdesc[kWaves][3];
@@ -1098,7 +1172,8 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
     // escape dialects only (the array does not exist in the other instantiations): the masks of the held tile's LAST
     // round are parked here across the count phase of the next tile — those variants are four VGPRs short there (a third
     // mask and the run-parity chain are in flight), and what hipcc spills otherwise is exactly this pair, to scratch
-    __shared__ uint4 s_park[DIALECT >= 2 ? kWaves : 1][DIALECT >= 2 ? 64 : 1];
+    constexpr bool kPark = DIALECT >= 2 || BATCH;  // (a batched launch carries the held tile's buffer on top: same squeeze)
+    __shared__ uint4 s_park[kPark ? kWaves : 1][kPark ? 64 : 1];
 
     const u32 t = threadIdx.x;
     const u32 lane = t & 63u;
@@ -1125,6 +1200,7 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
     RoundMasks held[kRounds];
     Desc held_agg = {0, 0, 0}, held_before = {0, 0, 0};
     u32 held_tile = 0, held_wa = 0, held_wb = 0;  // wa / wb: this wave's own entry counts (entered outside / inside)
+    u32 held_item = 0;                            // BATCH: the buffer the held tile belongs to
     bool have_held = false;
     u64 wg_tot = 0;  // wave 0: comma/CR/LF bytes in this workgroup's tiles
 
@@ -1202,18 +1278,31 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
         RoundMasks m[kRounds];
         Desc agg = {0, 0, 0}, before = {0, 0, 0};
         u32 cur_wa = 0, cur_wb = 0;
+        u32 cur_item = 0;
         if (have_cur) {
-            const u64 tile0 = (u64)tile * kTileBytes;  // relative to abase
+            // the buffer this tile reads: the launch's one buffer, or (BATCH) the one the tile index falls into
+            const uint8_t* t_abase = args.abase;
+            u64 t_lo = args.lo, t_hi = args.hi;
+            u32 t_first = 0;
+            if (BATCH) {
+                cur_item = batch_item_of(args.batch, args.n_items, tile, lane);
+                const BatchItem* const it = args.batch + cur_item;
+                t_abase = it->abase;
+                t_lo = it->lo;
+                t_hi = it->hi;
+                t_first = it->first_tile;
+            }
+            const u64 tile0 = (u64)(tile - t_first) * kTileBytes;  // relative to abase
             // descriptor over this tile's valid bytes, rounded up to whole 16-byte chunks (a chunk
             // never straddles a page, so the <= 15 extra bytes are always mapped)
-            const u64 hi16 = (args.hi + 15) & ~15ull;
+            const u64 hi16 = (t_hi + 15) & ~15ull;
             const u64 avail = hi16 - tile0;
             const rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<uint8_t*>(args.abase) + tile0, 0,
+                const_cast<uint8_t*>(t_abase) + tile0, 0,
                 (int)(avail < (u64)kTileBytes ? avail : (u64)kTileBytes), 0x00020000);
             // valid bytes of this tile are [lo_rel, hi_rel) relative to the tile start
-            const u32 lo_rel = args.lo > tile0 ? (u32)(args.lo - tile0) : 0u;  // lo < 16
-            const u32 hi_rel = args.hi - tile0 < (u64)kTileBytes ? (u32)(args.hi - tile0) : (u32)kTileBytes;
+            const u32 lo_rel = t_lo > tile0 ? (u32)(t_lo - tile0) : 0u;  // lo < 16
+            const u32 hi_rel = t_hi - tile0 < (u64)kTileBytes ? (u32)(t_hi - tile0) : (u32)kTileBytes;
 
             // ---- count phase: masks for the whole span stay in registers ---------------------
             u32 carry = 0, cnt_a = 0, cnt_t = 0;
@@ -1257,10 +1346,10 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
             } else {
                 // pacing (DESIGN.md §4 "Pacing"): the phase that keeps HBM loads in flight gets the SIMD's issue
                 // priority over the partner workgroup's resolve / emit phase
-                if (uniform_again<DIALECT>(args.count_prio)) __builtin_amdgcn_s_setprio(3);
+                if (uniform_again<(DIALECT >= 2 || BATCH)>(args.count_prio)) __builtin_amdgcn_s_setprio(3);
                 count_phase<DIALECT>(rsrc, lane, w, ek, s_stage[w], s_stage_b[w], m, carry, cnt_a, cnt_t, dr,
                                      esc_carry);
-                if (uniform_again<DIALECT>(args.count_prio)) __builtin_amdgcn_s_setprio(0);
+                if (uniform_again<(DIALECT >= 2 || BATCH)>(args.count_prio)) __builtin_amdgcn_s_setprio(0);
             }
             const u32 wave_a = wave_sum(cnt_a);
             const u32 wave_t = wave_sum(cnt_t);
@@ -1301,9 +1390,11 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
             if (have_cur) {
                 if (!(DBG & 4) && lane == 0) publish_aggregate(args.desc, tile, epoch, agg);
                 wg_tot += (u64)(u32)__builtin_amdgcn_readfirstlane((int)(agg.a + agg.b));
+                if (BATCH && lane == 0)  // the buffer's own comma/CR/LF total, for its result record
+                    atomicAdd((unsigned long long*)&args.batch[cur_item].tot, (unsigned long long)(agg.a + agg.b));
             }
             // a shard whose entering state nobody knows: the first kGuessTiles tiles vote (see guess_vote)
-            if (uniform_again<DIALECT>(inq_in) == kEnterGuess && have_cur && tile < kGuessTiles && !(DBG & 4))
+            if (uniform_again<(DIALECT >= 2 || BATCH)>(inq_in) == kEnterGuess && have_cur && tile < kGuessTiles && !(DBG & 4))
                 guess_vote(args.desc, args.ctl, args.num_tiles, epoch, lane, err);
             // into wave 0's second stage image: idle until the next count phase
             if (have_held && !(DBG & 4)) lookback_issue(args.desc, held_tile, lane, s_stage_b[0]);
@@ -1313,7 +1404,7 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
         const u32 spec_state = spec_pin ^ held_before.p;             // this wave's entering state under it
         const u32 spec_n = spec_state ? held_wb : held_wa;           // ... and its entry count
         if (EMIT && have_held && !(DBG & 16) && spec_n <= (u32)kCompCap) {
-            if (DIALECT >= 2) {
+            if (kPark) {
                 const uint4 pk = s_park[w][lane];
                 held[kRounds - 1].st = ((u64)pk.y << 32) | pk.x;
                 held[kRounds - 1].s = ((u64)pk.w << 32) | pk.z;
@@ -1327,17 +1418,22 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
             if (!(DBG & 4)) {
                 u64 pre[4];
                 // CSVSIMD_ENTER_GUESS: the choice was published before tile 0's aggregate, a tile-time ago at least
-                const u32 inq_now = uniform_again<DIALECT>(inq_in);
-                const u32 inq_eff = inq_now == kEnterGuess ? wait_for_guess(args.ctl, err) : inq_now;
+                const u32 inq_now = uniform_again<(DIALECT >= 2 || BATCH)>(inq_in);
+                u32 inq_eff = inq_now == kEnterGuess ? wait_for_guess(args.ctl, err) : inq_now;
+                u32 held_first = 0;
+                if (BATCH) {
+                    inq_eff = args.batch[held_item].in_quote_in & 1u;
+                    held_first = args.batch[held_item].first_tile;
+                }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef CSVSIMD_DEV_PROBES
                 if (DBG & 32) trace_landed = __builtin_amdgcn_s_memrealtime();
                 lookback_fetch(s_stage_b[0], held_tile, lane, pre);
                 resolve<true>(args.desc, held_tile, epoch, held_agg, inq_eff, lane, pin, base, err, pre,
-                              (DBG & 32) ? &trace_ws : nullptr);
+                              (DBG & 32) ? &trace_ws : nullptr, held_first);
 #else
                 lookback_fetch(s_stage_b[0], held_tile, lane, pre);
-                resolve<true>(args.desc, held_tile, epoch, held_agg, inq_eff, lane, pin, base, err, pre);
+                resolve<true>(args.desc, held_tile, epoch, held_agg, inq_eff, lane, pin, base, err, pre, nullptr, held_first);
 #endif
             }
             if (lane == 0) {
@@ -1369,22 +1465,33 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
             // state entering this wave's span and tape index of its first entry
             const u32 wstate = pin ^ held_before.p;
             const u64 run = s_base + (pin ? held_before.b : held_before.a);
-            const u64 span0 = (u64)held_tile * kTileBytes + (u64)w * kSpanBytes;
+            // where the held tile's entries go, and the tape value of this span's byte 0
+            u64* e_tape = args.tape;
+            u64 e_cap = args.tape_cap, e_off = args.base_off - args.lo;
+            u32 e_first = 0;
+            if (BATCH) {
+                const BatchItem* const it = args.batch + held_item;
+                e_tape = it->tape;
+                e_cap = it->tape ? it->tape_cap : 0;
+                e_off = it->base_off - it->lo;
+                e_first = it->first_tile;
+            }
+            const u64 span0 = (u64)(held_tile - e_first) * kTileBytes + (u64)w * kSpanBytes;
             if (spec_done && pin == (held_agg.b > held_agg.a ? 1u : 0u)) {
                 // the guess was right: the window already holds the span's entries, only the stores are left
                 wave_lds_fence();
-                flush_window(args, reinterpret_cast<unsigned short*>(s_stage[w]), spec_n,
+                flush_window(e_tape, e_cap, reinterpret_cast<unsigned short*>(s_stage[w]), spec_n,
                              ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(run >> 32)) << 32) |
                                  (u32)__builtin_amdgcn_readfirstlane((int)(u32)run),
-                             args.base_off + span0 - args.lo, lane);
+                             e_off + span0, lane);
                 wave_lds_fence();
             } else {
-                if (DIALECT >= 2) {  // (the speculative scatter may not have run: the pair is fetched again)
+                if (kPark) {  // (the speculative scatter may not have run: the pair is fetched again)
                     const uint4 pk = s_park[w][lane];
                     held[kRounds - 1].st = ((u64)pk.y << 32) | pk.x;
                     held[kRounds - 1].s = ((u64)pk.w << 32) | pk.z;
                 }
-                emit_span<(DBG & 16) != 0>(args, held, lane, span0, wstate, run,
+                emit_span<(DBG & 16) != 0>(e_tape, e_cap, held, lane, e_off + span0, wstate, run,
                                            reinterpret_cast<unsigned short*>(s_stage[w]));
             }
         }
@@ -1401,13 +1508,14 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
         // the tile counted in this iteration becomes the held one
         have_held = have_cur;
         held_tile = tile;
+        held_item = cur_item;
         held_agg = agg;
         held_before = before;
         held_wa = cur_wa;
         held_wb = cur_wb;
 #pragma unroll
-        for (int r = 0; r < kRounds - (DIALECT >= 2 ? 1 : 0); ++r) held[r] = m[r];
-        if (DIALECT >= 2)
+        for (int r = 0; r < kRounds - (kPark ? 1 : 0); ++r) held[r] = m[r];
+        if (kPark)
             s_park[w][lane] = make_uint4((u32)m[kRounds - 1].st, (u32)(m[kRounds - 1].st >> 32), (u32)m[kRounds - 1].s,
                                          (u32)(m[kRounds - 1].s >> 32));
         CSVSIMD_STAMP(5)  // emit
@@ -1437,7 +1545,7 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
 
     // ---- this workgroup is done; the last one to get here completes the launch --------------------
     if (w != 0) return;
-    finish_launch<DIALECT, (DBG & 4) != 0>(args, (u32)__builtin_amdgcn_readfirstlane((int)epoch_v) & kEpochMask, inq_in,
+    finish_launch<DIALECT, (DBG & 4) != 0, BATCH>(args, (u32)__builtin_amdgcn_readfirstlane((int)epoch_v) & kEpochMask, inq_in,
                                            wg_tot, err,
                                            // the lane id again, from the execution mask: `lane` as derived from threadIdx.x
                                            // would otherwise have to survive the tile loop in a register the loop needs
@@ -1815,17 +1923,37 @@ hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream) {
     return hipSuccess;
 }
 
+// Batched launch: `d_items` = n_items BatchItem lines in device memory (first_tile ascending, filled by the host),
+// `d_results` = n_items result records.  Reference dialect, entering states 0 / 1 only.
+hipError_t launch_stage1_batch(void* d_items, u32 n_items, u32 total_tiles, csvsimd_shard_result* d_results,
+                               void* scratch_base, u64* scratch_desc, u32 max_blocks, hipStream_t stream) {
+    KernelArgs a = {};
+    a.num_tiles = total_tiles;
+    a.desc = scratch_desc;
+    a.ctl = reinterpret_cast<Control*>(scratch_base);
+    a.result = d_results;
+    a.batch = reinterpret_cast<BatchItem*>(d_items);
+    a.n_items = n_items;
+    a.count_prio = 1u;
+    a.cu_token = reinterpret_cast<u32*>(reinterpret_cast<char*>(scratch_base) + CSVSIMD_SCRATCH_TOKEN_OFFSET);
+    a.token_mode = 1u;
+    const u32 want = total_tiles ? total_tiles : 1u;
+    const u32 grid = want < max_blocks ? want : max_blocks;
+    hipLaunchKernelGGL((stage1_kernel<true, 0, 0, true>), dim3(grid), dim3(kThreads), 0, stream, a);
+    return hipGetLastError();
+}
+
 // name of the kernel launch_stage1 runs for this configuration (bench.py reports it next to the time)
 const char* stage1_kernel_name(bool emit, int dialect) {
     static const char* names[2][4] = {
-        {"void csvsimd::stage1_kernel<false, 0, 0>(csvsimd::KernelArgs)",
-         "void csvsimd::stage1_kernel<false, 0, 1>(csvsimd::KernelArgs)",
-         "void csvsimd::stage1_kernel<false, 0, 2>(csvsimd::KernelArgs)",
-         "void csvsimd::stage1_kernel<false, 0, 3>(csvsimd::KernelArgs)"},
-        {"void csvsimd::stage1_kernel<true, 0, 0>(csvsimd::KernelArgs)",
-         "void csvsimd::stage1_kernel<true, 0, 1>(csvsimd::KernelArgs)",
-         "void csvsimd::stage1_kernel<true, 0, 2>(csvsimd::KernelArgs)",
-         "void csvsimd::stage1_kernel<true, 0, 3>(csvsimd::KernelArgs)"}};
+        {"void csvsimd::stage1_kernel<false, 0, 0, false>(csvsimd::KernelArgs)",
+         "void csvsimd::stage1_kernel<false, 0, 1, false>(csvsimd::KernelArgs)",
+         "void csvsimd::stage1_kernel<false, 0, 2, false>(csvsimd::KernelArgs)",
+         "void csvsimd::stage1_kernel<false, 0, 3, false>(csvsimd::KernelArgs)"},
+        {"void csvsimd::stage1_kernel<true, 0, 0, false>(csvsimd::KernelArgs)",
+         "void csvsimd::stage1_kernel<true, 0, 1, false>(csvsimd::KernelArgs)",
+         "void csvsimd::stage1_kernel<true, 0, 2, false>(csvsimd::KernelArgs)",
+         "void csvsimd::stage1_kernel<true, 0, 3, false>(csvsimd::KernelArgs)"}};
     return names[emit ? 1 : 0][dialect < 0 || dialect > 3 ? 0 : dialect];
 }
 

@@ -115,6 +115,28 @@ int csvsimd_stage1_index_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len
                                 uint64_t base_off, uint32_t in_quote_in, void* dtape,
                                 uint64_t tape_cap, csvsimd_shard_result* result, void* hip_stream);
 
+/* ---- stage 1, many device-resident buffers in ONE launch --------------------------------------------------------
+ * A launch has a fixed cost of ~20 us (its fill and drain: DESIGN.md); a 128-MiB buffer indexed alone runs at 40 % of
+ * HBM read bandwidth where a 1-GiB one reaches 60 %.  Many files — csv_simd::create per file, src/lib.rs:61-74, is the
+ * reference's unit of work — should not pay it per file: n_items independent buffers (any sizes, any alignments, each
+ * with its own tape, base offset and entering state 0 / 1) are indexed by ONE persistent kernel whose workgroups draw
+ * tiles of all buffers from one ticket; a tile's look-back stops at its buffer's first tile.  d_results = n_items
+ * csvsimd_shard_result records in DEVICE memory (16-byte aligned), record i for items[i], valid once the stream has
+ * drained: exactly what csvsimd_stage1_index_device_async would have written for that buffer alone (same tape, same
+ * counts).  items is HOST memory (read before the call returns).  Reference dialect only.  Asynchronous on hip_stream;
+ * allocates / synchronises only when the context's scratch or its buffer table has to grow. */
+typedef struct csvsimd_batch_item {
+    const void* dbuf;
+    uint64_t len;
+    uint64_t base_off;
+    void* dtape;
+    uint64_t tape_cap;
+    uint32_t in_quote_in; /* CSVSIMD_ENTER_OUTSIDE / CSVSIMD_ENTER_INSIDE */
+    uint32_t reserved;
+} csvsimd_batch_item;
+int csvsimd_stage1_index_batch_device_async(csvsimd_ctx* ctx, const csvsimd_batch_item* items, uint32_t n_items,
+                                            void* d_results, void* hip_stream);
+
 /* ---- stage 1, host buffer: the drop-in for `reader::read(&Mmap) -> StructureIndex` -----------
  * (src/reader.rs:150).  buf = the mmap; tape = caller-owned uint64_t[tape_cap]; on return
  * tape[0] = 0 (sentinel, src/reader.rs:216) followed by every structural offset relative to

@@ -26,7 +26,7 @@ def main():
             for row in csv.DictReader(f):
                 kn = row.get("Kernel_Name", "")
                 flat = kn.replace(" ", "")
-                if KERNEL not in flat or not ("<true,0,0>" in flat or "<true,0>" in flat or "<true>" in flat):
+                if KERNEL not in flat or not ("<true,0,0,false>" in flat or "<true,0,0>" in flat or "<true,0>" in flat or "<true>" in flat):
                     continue  # only the reference-dialect, non-probe instantiation
                 name_seen.add(kn)
                 key = (os.path.basename(os.path.dirname(path)), row.get("Dispatch_Id"))
