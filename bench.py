@@ -631,6 +631,67 @@ def consumers_leg(pkg, oracle, device):
     return res
 
 
+def batch_leg(pkg, device):
+    """Many files: 8 buffers of 128 MiB (the 16x32 corpus, whole rows each) indexed by EIGHT launches back to back and by
+    ONE batched launch (csvsimd_stage1_index_batch_device_async: the tiles of all buffers share one ticket, a look-back
+    stops at its buffer's first tile).  A launch's fixed cost (fill + drain, ~20 us) is paid once instead of eight times.
+    Times = torch events on the launch stream around 20 repetitions after a settle; every tape checked against the closed form."""
+    name = "16x32_noquote"
+    cols, width, seed, q = pkg.WORKLOADS[name]
+    k, per = 8, pkg.workload_len(name, 128 << 20)
+    pitch = width + 1
+    dbuf = torch.empty(k * per, dtype=torch.uint8, device=device)
+    pkg.synth_fill_device(dbuf.data_ptr(), 0, k * per, cols, width, seed, q)
+    cap = per // pitch + 64
+    tapes = [torch.empty(cap, dtype=torch.int64, device=device) for _ in range(k)]
+    dres = torch.zeros((k, 8), dtype=torch.int64, device=device)
+    ctx = pkg.Context(device.index)
+    ctx.reserve(k * per + (k << 18))
+    stream = torch.cuda.current_stream(device).cuda_stream
+    items = [(dbuf.data_ptr() + i * per, per, i * per, tapes[i].data_ptr(), cap, 0) for i in range(k)]
+
+    def separate():
+        for i in range(k):
+            ctx.stage1_index_device_async(items[i][0], per, i * per, 0, items[i][3], cap, dres[i].data_ptr(), stream)
+
+    def batched():
+        ctx.stage1_index_batch_device_async(items, dres.data_ptr(), stream)
+
+    def timed(fn, reps=20):
+        for _ in range(settle_count(k * per)):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    def verify():
+        torch.cuda.synchronize(device)
+        ok = True
+        for i in range(k):
+            cnt = int(dres[i, 0])
+            k0 = (i * per) // pitch
+            want = torch.arange(k0, k0 + per // pitch, dtype=torch.int64, device=device) * pitch + width
+            ok = ok and cnt == per // pitch and torch.equal(tapes[i][:cnt], want)
+        return bool(ok)
+
+    ms_sep = timed(separate)
+    ok = verify()
+    for t in tapes:
+        t.fill_(-1)
+    ms_bat = timed(batched)
+    ok = ok and verify()
+    ctx.close()
+    frac = lambda ms: round(k * per / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+    return {"workload": f"{k} buffers x {per / 2**20:.0f} MiB of the {name} corpus",
+            "eight_launches_ms": round(ms_sep, 4), "eight_launches_hbm_read_frac": frac(ms_sep),
+            "one_batched_launch_ms": round(ms_bat, 4), "one_batched_launch_hbm_read_frac": frac(ms_bat),
+            "verified": ok}
+
+
 def dense_ceiling(sb):
     """What bare streams reach with the dense corpus's write share (1.6 B of tape per byte read), next to an
     INDEPENDENT yardstick: a plain copy — hipMemcpyDtoD and the textbook one-16-byte-element-per-thread
@@ -786,6 +847,7 @@ def main():
     ap.add_argument("--native-rccl", action="store_true",
                     help="do the sharded step inside the C ABI (csvsimd_stage1_index_sharded: ncclAllGather "
                          "from C++) instead of torch.distributed.all_gather_into_tensor")
+    ap.add_argument("--only-batch", action="store_true", help="development: run the `batch_many_files` leg alone")
     ap.add_argument("--only-consumers", action="store_true",
                     help="development / profiling: run the `consumers` leg alone and print its record (not the "
                          "contract line)")
@@ -828,6 +890,9 @@ def main():
     oracle = graft.load_oracle() if not (args.no_verify and args.no_cpu_baseline) else None
     if args.only_consumers:
         print(json.dumps({"consumers": consumers_leg(pkg, oracle or graft.load_oracle(), device)}))
+        return
+    if args.only_batch:
+        print(json.dumps({"batch_many_files": batch_leg(pkg, device)}))
         return
 
     strong = args.scaling == "strong"
@@ -1004,6 +1069,8 @@ def main():
                 del_sb.release()
                 del del_sb
             out["other_workloads"] = extra
+            out["batch_many_files"] = batch_leg(pkg, device)
+            failed = failed or not out["batch_many_files"]["verified"]
             out["consumers"] = consumers_leg(pkg, oracle, device)
             failed = failed or not out["consumers"]["verified"]
         if not args.no_ingest:

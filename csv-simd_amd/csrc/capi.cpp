@@ -237,8 +237,8 @@ struct csvsimd_ctx {
     csvsimd_shard_result* h_res = nullptr;     // pinned, 2 records
     hipEvent_t ev_rec[2] = {nullptr, nullptr}; // result record of the slot's chunk has landed in h_res[k] (and its tape in pin_out[k])
     std::unique_ptr<CopyPool> copier;         // host-side slices of the staging copies
-    void* d_batch = nullptr;                  // csvsimd_stage1_index_batch_device_async: the buffers' table (64 B per buffer)
-    uint32_t d_batch_items = 0;
+    void* d_batch = nullptr;                  // csvsimd_stage1_index_batch_device_async: the buffers' table block
+    size_t d_batch_bytes = 0;
 };
 
 extern "C" {
@@ -423,7 +423,13 @@ int csvsimd_stage1_index_batch_device_async(csvsimd_ctx* ctx, const csvsimd_batc
     return csvsimd_guarded([&]() -> int {
     if (!ctx || !items || n_items == 0 || n_items > 65536 || !d_results || ((uintptr_t)d_results & 15))
         return CSVSIMD_ERR_INVALID_ARG;
-    std::vector<csvsimd::BatchItemHost> table(n_items);
+    // one block: [n items x 64 B | n first tiles x 4 B, padded to 64 | n totals x 8 B (zero)]
+    const size_t off_first = (size_t)n_items * sizeof(csvsimd::BatchItemHost);
+    const size_t off_tot = off_first + (((size_t)n_items * 4 + 63) & ~(size_t)63);
+    const size_t block = off_tot + (size_t)n_items * 8;
+    std::vector<unsigned char> host(block, 0);
+    csvsimd::BatchItemHost* const table = reinterpret_cast<csvsimd::BatchItemHost*>(host.data());
+    uint32_t* const firsts = reinterpret_cast<uint32_t*>(host.data() + off_first);
     uint64_t tiles = 0;
     for (uint32_t i = 0; i < n_items; ++i) {
         const csvsimd_batch_item& it = items[i];
@@ -438,9 +444,9 @@ int csvsimd_stage1_index_batch_device_async(csvsimd_ctx* ctx, const csvsimd_batc
         t.base_off = it.base_off;
         t.tape = it.dtape;
         t.tape_cap = it.dtape ? it.tape_cap : 0;
-        t.first_tile = (uint32_t)tiles;
+        t.first_tile = firsts[i] = (uint32_t)tiles;
         t.in_quote_in = it.in_quote_in;
-        t.tot = 0;
+        t.reserved = 0;
         tiles += it.len ? (t.hi + CSVSIMD_TILE_BYTES - 1) / CSVSIMD_TILE_BYTES : 0;
         if (tiles >= (1ull << 31)) return CSVSIMD_ERR_INVALID_ARG;
     }
@@ -448,25 +454,26 @@ int csvsimd_stage1_index_batch_device_async(csvsimd_ctx* ctx, const csvsimd_batc
     // scratch: one descriptor word per tile of the whole batch (allocates + synchronises only when it has to grow)
     int rc = csvsimd_ctx_reserve(ctx, tiles * CSVSIMD_TILE_BYTES);
     if (rc != CSVSIMD_OK) return rc;
-    if (ctx->d_batch_items < n_items) {
+    if (ctx->d_batch_bytes < block) {
         if (ctx->launched) HIP_TRY(hipDeviceSynchronize());  // an earlier batch may still be reading the old table
         if (ctx->d_batch) HIP_TRY(hipFree(ctx->d_batch));
         ctx->d_batch = nullptr;
-        ctx->d_batch_items = 0;
-        const uint32_t cap = std::max<uint32_t>(64, n_items);
-        HIP_TRY(hipMalloc(&ctx->d_batch, (size_t)cap * sizeof(csvsimd::BatchItemHost)));
-        ctx->d_batch_items = cap;
+        ctx->d_batch_bytes = 0;
+        const size_t cap = std::max<size_t>(8192, block * 2);
+        HIP_TRY(hipMalloc(&ctx->d_batch, cap));
+        ctx->d_batch_bytes = cap;
     }
     hipStream_t s = (hipStream_t)hip_stream;
-    // from pageable memory: the runtime has taken its copy of `table` when this returns, and the transfer itself is
+    // from pageable memory: the runtime has taken its copy of the block when this returns, and the transfer itself is
     // ordered on the stream behind whatever batch is still running from the device table
-    HIP_TRY(hipMemcpyAsync(ctx->d_batch, table.data(), (size_t)n_items * sizeof(csvsimd::BatchItemHost), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ctx->d_batch, host.data(), block, hipMemcpyHostToDevice, s));
     csvsimd::Stage1Launch L;
     L.bind_scratch(ctx->scratch);
     ctx->last_stream = s;
     ctx->launched = true;
-    HIP_TRY(csvsimd::launch_stage1_batch(ctx->d_batch, n_items, (uint32_t)tiles, (csvsimd_shard_result*)d_results, ctx->scratch,
-                                         L.scratch_desc, ctx->max_blocks, s));
+    HIP_TRY(csvsimd::launch_stage1_batch(ctx->d_batch, (char*)ctx->d_batch + off_first, (char*)ctx->d_batch + off_tot, n_items,
+                                         (uint32_t)tiles, (csvsimd_shard_result*)d_results, ctx->scratch, L.scratch_desc,
+                                         ctx->max_blocks, s));
     return CSVSIMD_OK;
     });
 }

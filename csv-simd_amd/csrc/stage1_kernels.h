@@ -87,18 +87,20 @@ hipError_t launch_copy_probe(const void* din, void* dout, uint64_t len, int mode
 hipError_t launch_stitch(const void* d_results, uint32_t n_shards, uint32_t rank, uint32_t file_in_quote_in,
                          void* d_stitch, hipStream_t stream);
 // one persistent launch over n_items independent buffers; d_items = device table of 64-byte lines laid out as
-// stage1_kernels.hip's BatchItem {abase, lo, hi, base_off, tape, tape_cap, first_tile, in_quote_in, tot = 0}
+// stage1_kernels.hip's BatchItem {abase, lo, hi, base_off, tape, tape_cap, first_tile, in_quote_in, 0}; d_first_tiles =
+// the first_tile fields again, compact (u32 each); d_tots = n_items zeroed u64 counters
 struct BatchItemHost {
     const void* abase;
     uint64_t lo, hi, base_off;
     void* tape;
     uint64_t tape_cap;
     uint32_t first_tile, in_quote_in;
-    uint64_t tot;
+    uint64_t reserved;
 };
 static_assert(sizeof(BatchItemHost) == 64, "mirrors the device-side BatchItem");
-hipError_t launch_stage1_batch(void* d_items, uint32_t n_items, uint32_t total_tiles, csvsimd_shard_result* d_results,
-                               void* scratch_base, uint64_t* scratch_desc, uint32_t max_blocks, hipStream_t stream);
+hipError_t launch_stage1_batch(void* d_items, void* d_first_tiles, void* d_tots, uint32_t n_items, uint32_t total_tiles,
+                               csvsimd_shard_result* d_results, void* scratch_base, uint64_t* scratch_desc,
+                               uint32_t max_blocks, hipStream_t stream);
 const char* stage1_kernel_name(bool emit, int dialect);
 // consumer_kernels.hip: consumers of a finished, device-resident tape
 hipError_t launch_chunk_spans(const void* dindex, uint64_t first_key, uint64_t jump, uint32_t field, uint32_t fields,

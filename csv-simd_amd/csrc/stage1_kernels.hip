@@ -700,8 +700,13 @@ struct BatchItem {          // device, 64 bytes; written by the host before the 
     u64 tape_cap;
     u32 first_tile;         // global index of this buffer's first tile
     u32 in_quote_in;        // 0 / 1
-    u64 tot;                // comma/CR/LF bytes of the buffer: added to by the launch, read and reset by its last workgroup
+    u64 reserved;
 };
+// The table never changes while a launch runs, and every wave reads it with wave-uniform addresses: through the
+// CONSTANT address space those reads are scalar loads (s_load via the scalar cache) — measured, the same reads as
+// vector loads queue behind the CU's streaming input for 3-5 us each and cost a batched launch 50 % of its rate.
+typedef const __attribute__((address_space(4))) BatchItem* batch_cptr;
+typedef const __attribute__((address_space(4))) u32* u32_cptr;
 static_assert(sizeof(BatchItem) == 64, "one line per buffer");
 
 struct KernelArgs {
@@ -728,7 +733,9 @@ struct KernelArgs {
     // share one index space (buffer b owns tiles [first_tile[b], first_tile[b + 1])), one ticket, one descriptor array;
     // a tile's look-back stops at its buffer's first tile.  abase / lo / hi / base_off / in_quote_in / tape / tape_cap above
     // are unused then, `result` is an array of n_items records.
-    struct BatchItem* batch;
+    const struct BatchItem* batch;
+    const u32* batch_first;  // first_tile of every buffer again, compact: what the tile -> buffer search reads
+    u64* batch_tot;          // per buffer: comma/CR/LF bytes, added to by the launch, read and reset by its last workgroup
     u32 n_items;
     // dialect variants only (DIALECT != 0)
     u32 delim, quote, escape;  // bytes; quote / escape 0 = feature off
@@ -954,7 +961,7 @@ __device__ __forceinline__ void finish_launch(const KernelArgs& args, u32 epoch,
         // leaving state (published by whichever workgroup resolved that tile, before it counted itself done); an empty
         // buffer has no tile: nothing counted, the state passes through
         for (u32 b = lane; b < args.n_items; b += 64u) {
-            BatchItem* const it = args.batch + b;
+            const BatchItem* const it = args.batch + b;
             const u32 first = it->first_tile;
             const u32 next = b + 1u < args.n_items ? args.batch[b + 1u].first_tile : args.num_tiles;
             const u32 inq = it->in_quote_in & 1u;
@@ -970,7 +977,7 @@ __device__ __forceinline__ void finish_launch(const KernelArgs& args, u32 epoch,
                 st = (u32)x & 1u;
                 cnt = x >> 1;
             }
-            const u64 tot = __hip_atomic_load(&it->tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u64 tot = __hip_atomic_load(&args.batch_tot[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             csvsimd_shard_result* const r = args.result + b;
             r->count = cnt;
             r->count_enter_outside = inq ? tot - cnt : cnt;
@@ -984,7 +991,7 @@ __device__ __forceinline__ void finish_launch(const KernelArgs& args, u32 epoch,
             r->in_quote_in_used = inq;
             r->reserved0 = 0;
             r->reserved1 = 0;
-            it->tot = 0;  // the table is ready for the next launch over the same buffers (a replayed graph)
+            args.batch_tot[b] = 0;  // ready for the next launch over the same buffers (a replayed graph)
         }
     }
     if (lane == 0) {
@@ -1144,18 +1151,19 @@ __device__ __forceinline__ u32 uniform_again(u32 v) {
 }
 
 // Batched launches (BATCH): which buffer does `tile` belong to?  first_tile[] ascends; the buffer is the LAST one whose
-// first tile is <= tile (empty buffers share their successor's first tile and are never chosen).  All 64 lanes look at 64
-// table lines at once: one load + one ballot per 64 buffers.  Wave-uniform result.
-__device__ __forceinline__ u32 batch_item_of(const BatchItem* batch, u32 n_items, u32 tile, u32 lane) {
-    u32 idx = 0;
-    for (u32 b0 = 0; b0 < n_items; b0 += 64u) {
-        const bool le = b0 + lane < n_items && batch[b0 + lane].first_tile <= tile;
-        const u64 m = __ballot(le);
-        if (m == 0) break;
-        idx = b0 + 63u - (u32)__builtin_clzll(m);
-        if (m != ~0ull) break;
+// first tile is <= tile (empty buffers share their successor's first tile and are never chosen).  Scalar code on scalar
+// loads: a binary search down to a window of 16, then the window's loads go out together.
+__device__ __forceinline__ u32 batch_item_of(const u32* first_tiles, u32 n_items, u32 tile) {
+    const u32_cptr ft = (u32_cptr)first_tiles;
+    u32 lo = 0, hi = n_items;
+    while (hi - lo > 16u) {
+        const u32 mid = (lo + hi) >> 1;
+        if (ft[mid] <= tile) lo = mid; else hi = mid;
     }
-    return (u32)__builtin_amdgcn_readfirstlane((int)idx);
+    u32 idx = lo;
+    for (u32 j = lo + 1u; j < hi; ++j)
+        if (ft[j] <= tile) idx = j;
+    return idx;
 }
 
 template <bool EMIT, int DBG = 0, int DIALECT = 0, bool BATCH = false>
@@ -1285,8 +1293,8 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
             u64 t_lo = args.lo, t_hi = args.hi;
             u32 t_first = 0;
             if (BATCH) {
-                cur_item = batch_item_of(args.batch, args.n_items, tile, lane);
-                const BatchItem* const it = args.batch + cur_item;
+                cur_item = batch_item_of(args.batch_first, args.n_items, tile);
+                const batch_cptr it = (batch_cptr)args.batch + cur_item;
                 t_abase = it->abase;
                 t_lo = it->lo;
                 t_hi = it->hi;
@@ -1391,7 +1399,7 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
                 if (!(DBG & 4) && lane == 0) publish_aggregate(args.desc, tile, epoch, agg);
                 wg_tot += (u64)(u32)__builtin_amdgcn_readfirstlane((int)(agg.a + agg.b));
                 if (BATCH && lane == 0)  // the buffer's own comma/CR/LF total, for its result record
-                    atomicAdd((unsigned long long*)&args.batch[cur_item].tot, (unsigned long long)(agg.a + agg.b));
+                    atomicAdd((unsigned long long*)&args.batch_tot[cur_item], (unsigned long long)(agg.a + agg.b));
             }
             // a shard whose entering state nobody knows: the first kGuessTiles tiles vote (see guess_vote)
             if (uniform_again<(DIALECT >= 2 || BATCH)>(inq_in) == kEnterGuess && have_cur && tile < kGuessTiles && !(DBG & 4))
@@ -1422,8 +1430,9 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
                 u32 inq_eff = inq_now == kEnterGuess ? wait_for_guess(args.ctl, err) : inq_now;
                 u32 held_first = 0;
                 if (BATCH) {
-                    inq_eff = args.batch[held_item].in_quote_in & 1u;
-                    held_first = args.batch[held_item].first_tile;
+                    const batch_cptr it = (batch_cptr)args.batch + held_item;
+                    inq_eff = it->in_quote_in & 1u;
+                    held_first = it->first_tile;
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef CSVSIMD_DEV_PROBES
@@ -1470,7 +1479,7 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
             u64 e_cap = args.tape_cap, e_off = args.base_off - args.lo;
             u32 e_first = 0;
             if (BATCH) {
-                const BatchItem* const it = args.batch + held_item;
+                const batch_cptr it = (batch_cptr)args.batch + held_item;
                 e_tape = it->tape;
                 e_cap = it->tape ? it->tape_cap : 0;
                 e_off = it->base_off - it->lo;
@@ -1924,15 +1933,19 @@ hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream) {
 }
 
 // Batched launch: `d_items` = n_items BatchItem lines in device memory (first_tile ascending, filled by the host),
+// `d_first_tiles` = their first_tile fields again as a compact u32 array, `d_tots` = n_items zeroed u64 counters,
 // `d_results` = n_items result records.  Reference dialect, entering states 0 / 1 only.
-hipError_t launch_stage1_batch(void* d_items, u32 n_items, u32 total_tiles, csvsimd_shard_result* d_results,
-                               void* scratch_base, u64* scratch_desc, u32 max_blocks, hipStream_t stream) {
+hipError_t launch_stage1_batch(void* d_items, void* d_first_tiles, void* d_tots, u32 n_items, u32 total_tiles,
+                               csvsimd_shard_result* d_results, void* scratch_base, u64* scratch_desc, u32 max_blocks,
+                               hipStream_t stream) {
     KernelArgs a = {};
     a.num_tiles = total_tiles;
     a.desc = scratch_desc;
     a.ctl = reinterpret_cast<Control*>(scratch_base);
     a.result = d_results;
-    a.batch = reinterpret_cast<BatchItem*>(d_items);
+    a.batch = reinterpret_cast<const BatchItem*>(d_items);
+    a.batch_first = reinterpret_cast<const u32*>(d_first_tiles);
+    a.batch_tot = reinterpret_cast<u64*>(d_tots);
     a.n_items = n_items;
     a.count_prio = 1u;
     a.cu_token = reinterpret_cast<u32*>(reinterpret_cast<char*>(scratch_base) + CSVSIMD_SCRATCH_TOKEN_OFFSET);
