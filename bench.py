@@ -982,6 +982,7 @@ def main():
                    "steps_in_flight": state["pipeline_depth"],   # 2: step i+1 enqueued before step i's record is read
                    "first_pass": state["first_pass"] if world > 1 else "one rank: the file's entering state is known",
                    "rccl_world": dist.get_world_size() if (dist_on and backend == "nccl") else None,
+                   "collective_world": dist.get_world_size() if dist_on else None,   # ranks the process group reports
                    "collective_backend": backend,
                    "parallelism": f"chunk-sharded x{world}; collective: {collective}"
                                   + (" [REHEARSAL: all ranks on one GPU, gloo]" if rehearsal else "")},
