@@ -98,7 +98,7 @@ static void expand_streaming(uint64_t* dst, const uint32_t* src, size_t n, uint6
 
 // Host-side copies of the ingest pipeline (user buffer -> pinned staging, pinned 32-bit tape -> user tape).
 // One thread moves ~10-30 GB/s, less than the PCIe link it feeds, so the copies are sliced over a few
-// persistent workers (measured on the MI355X host: 22 -> 39 GiB/s host buffer to tape).
+// persistent workers (measured on the MI355X host: 22 -> 39 GiB/s host buffer to tape, NOTEBOOK.md).
 class CopyPool {
 public:
     explicit CopyPool(int workers) {

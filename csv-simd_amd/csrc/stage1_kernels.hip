@@ -6,7 +6,7 @@
 //                               (src/avx/stage1.rs:342-407), emitted ascending as u64
 //                               (src/stage1.rs:162-296).
 //
-// How (MI355X-first; nothing here mirrors the SSE code's structure) — DESIGN.md §4 has the numbers:
+// How (MI355X-first; nothing here mirrors the SSE code's structure) — DESIGN.md §4 / §7 have the numbers:
 //   * one pass over the input: every byte is read once from HBM by LDS-DMA
 //     (buffer_load_dwordx4 ... lds, non-temporal, 1 KiB per wave instruction, fully coalesced, no
 //     VGPRs); the buffer descriptor's range check makes the ragged last tile branch-free.
@@ -1352,7 +1352,7 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
                 }
                 cnt_a = acc & 1u;
             } else {
-                // pacing (DESIGN.md §4 "Pacing"): the phase that keeps HBM loads in flight gets the SIMD's issue
+                // pacing (NOTEBOOK.md "Pacing"): the phase that keeps HBM loads in flight gets the SIMD's issue
                 // priority over the partner workgroup's resolve / emit phase
                 if (uniform_again<(DIALECT >= 2 || BATCH)>(args.count_prio)) __builtin_amdgcn_s_setprio(3);
                 count_phase<DIALECT>(rsrc, lane, w, ek, s_stage[w], s_stage_b[w], m, carry, cnt_a, cnt_t, dr,
