@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256) void to_columns_kernel(const ToColumnsArgs a) 
     const u32 t = threadIdx.x;
     const u32 spr = a.stride >> 4;  // 16-byte pieces per output row
     const float inv_spr = 1.0f / (float)spr;
+    const int spr_shift = (spr & (spr - 1u)) == 0u ? (int)__builtin_ctz(spr) : -1;
     const u64 n_blocks = (a.n_rows + a.rows_per_block - 1) / a.rows_per_block;
     const uintptr_t base = (uintptr_t)a.bytes;
     // the two tape entries that bound a run of rows: every lane loads both (one broadcast transaction each), and the
@@ -129,9 +130,14 @@ __global__ __launch_bounds__(256) void to_columns_kernel(const ToColumnsArgs a) 
             const u32x4c* src = reinterpret_cast<const u32x4c*>(a0);
             for (u32 i = t; i < n16; i += 256) reinterpret_cast<u32x4c*>(s_bytes)[i] = __builtin_nontemporal_load(src + i);
             __syncthreads();
-            for (u32 q = t; q < items; q += 256) {
-                const u32 c = div_small(q, per_col, inv_per_col), j = q - c * per_col;
-                const u32 r = div_small(j, spr, inv_spr), k = j - r * spr;
+            // item q = (column c, piece j of the column's rb x spr pieces): q advances by 256 per step, so (c, j) is
+            // carried along instead of divided out — a step crosses a handful of columns at most
+            u32 c = div_small(t, per_col, inv_per_col), j = t - c * per_col;
+            for (u32 q = t; q < items; q += 256, j += 256) {
+                while (j >= per_col) { j -= per_col; ++c; }
+                u32 r, k;
+                if (spr_shift >= 0) { r = j >> spr_shift; k = j & (spr - 1u); }   // (wave-uniform: the stride is a power of two)
+                else { r = div_small(j, spr, inv_spr); k = j - r * spr; }
                 const u32 f = a.fields ? a.fields[c] : c;
                 // the first entry of the window is the line end BEFORE the first row: offset -1 if that row starts the
                 // window's first 16-byte line, hence the 16-bit wrap-around of "+ 1"
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(256) void to_columns_kernel(const ToColumnsArgs a) 
                     v.y = __builtin_amdgcn_alignbyte(d2, d1, sh);
                     v.z = __builtin_amdgcn_alignbyte(d3, d2, sh);
                     v.w = __builtin_amdgcn_alignbyte(d4, d3, sh);
-                    v = keep_first_bytes(v, nvalid);
+                    if (nvalid < 16u) v = keep_first_bytes(v, nvalid);
                 }
                 const u64 row = (u64)c * a.n_rows + r0 + r;
                 __builtin_nontemporal_store(v, reinterpret_cast<u32x4c*>(a.cols + row * a.stride + 16 * k));

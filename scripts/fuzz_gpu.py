@@ -88,14 +88,54 @@ def main():
     cases = bytes_total = 0
     bad = []
     while time.time() < t_end and not bad:
+        mode = int(rng.integers(0, 8))
+        if mode == 0:
+            # a BATCH of buffers in one launch: every record and every tape must be the buffer's own
+            k = int(rng.integers(1, 12))
+            bufs = [make_case(rng)[: int(rng.integers(0, 6 << 20))] for _ in range(k)]
+            states = [int(rng.integers(0, 2)) for _ in range(k)]
+            bases = [int(rng.integers(0, 1 << 40)) for _ in range(k)]
+            miss = [int(rng.integers(0, 128)) for _ in range(k)]
+            dbufs, dtapes, items = [], [], []
+            for b, st, ba, mi in zip(bufs, states, bases, miss):
+                t = torch.full((b.size + 256,), 0x2C, dtype=torch.uint8, device="cuda:0")
+                if b.size:
+                    t[mi: mi + b.size] = torch.from_numpy(b)
+                tp = torch.full((b.size + 9,), -1, dtype=torch.int64, device="cuda:0")
+                dbufs.append(t); dtapes.append(tp)
+                items.append((t.data_ptr() + mi, b.size, ba, tp.data_ptr(), b.size + 1, st))
+            dres = torch.zeros((k, 8), dtype=torch.int64, device="cuda:0")
+            ctx.stage1_index_batch_device_async(items, dres.data_ptr())
+            torch.cuda.synchronize()
+            for i, b in enumerate(bufs):
+                want, q = oracle.scalar_index(b, base_off=bases[i], in_quote_in=states[i])
+                r = pkg.ShardResult.from_buffer_copy(dres[i].cpu().numpy().tobytes())
+                got = dtapes[i][: want.size].cpu().numpy().view(np.uint64)
+                if not (r.count == want.size and r.in_quote_out == q and r.error == 0 and np.array_equal(got, want)
+                        and bool((dtapes[i][want.size:] == -1).all())):
+                    bad.append({"case": cases, "mode": "batch", "item": i, "n": int(b.size), "count": int(r.count), "want": int(want.size)})
+            cases += 1
+            bytes_total += sum(int(b.size) for b in bufs)
+            continue
+        if mode == 1:
+            # the host-buffer entry point: chunks chained on the device, tape returned as 32-bit offsets, dense retries
+            d = make_case(rng)
+            want = oracle.scalar_read(d)
+            got = ctx.read(d)
+            if not (got.size == want.size and np.array_equal(got, want)):
+                bad.append({"case": cases, "mode": "host", "n": int(d.size), "count": int(got.size), "want": int(want.size)})
+                np.save(os.path.join(ROOT, "gpurun_out", f"fuzz_fail_host_{seed}_{cases}.npy"), d)
+            cases += 1
+            bytes_total += int(d.size)
+            continue
         d = make_case(rng)
         n = d.size
         mis = int(rng.integers(0, 128))
         inq = int(rng.integers(0, 3))   # 2 = CSVSIMD_ENTER_GUESS: the kernel chooses; the record says what it used
         base = int(rng.integers(0, 1 << 40))
         if inq == 2:
-            _, a0, b0 = oracle.shard_descriptor(d[: pkg.tile_bytes()])
-            used = int(b0 > a0)             # the documented rule: the state under which the first tile has more entries
+            _, a0, b0 = oracle.shard_descriptor(d[: 8 * pkg.tile_bytes()])
+            used = int(b0 > a0)             # the documented rule: the state under which the first EIGHT tiles have more entries
         else:
             used = inq
         want, q = oracle.scalar_index(d, base_off=base, in_quote_in=used)
