@@ -35,16 +35,18 @@ typedef uint32_t u32x4cu __attribute__((ext_vector_type(4), aligned(1)));
 // row-major -> columnar
 // ---------------------------------------------------------------------------------------------
 #ifndef CSVSIMD_COLWIN_BYTES
-#define CSVSIMD_COLWIN_BYTES 24576
+#define CSVSIMD_COLWIN_BYTES 16384
 #endif
 #ifndef CSVSIMD_COLWIN_ENTRIES
-#define CSVSIMD_COLWIN_ENTRIES 3072
+#define CSVSIMD_COLWIN_ENTRIES 2048
 #endif
 static constexpr u32 kWinBytes = CSVSIMD_COLWIN_BYTES;      // bytes of whole rows a workgroup stages per step
 static constexpr u32 kWinEntries = CSVSIMD_COLWIN_ENTRIES;  // tape entries (+ 1) it stages with them, as 16-bit offsets
 static_assert(kWinBytes + 16 < 65536, "staged tape entries are 16-bit offsets into the window");
-// LDS per workgroup: 24 KiB + 6 KiB -> five workgroups (20 waves) per CU, each at another point of its
-// load -> stage -> write cycle: that overlap is what keeps HBM busy (a workgroup alone is a chain of dependent steps)
+// LDS per workgroup: 16 KiB + 4 KiB -> seven workgroups (28 waves) per CU, each at another point of its
+// load -> stage -> write cycle: that overlap is what keeps HBM busy (a workgroup alone is a chain of dependent steps).
+// Measured (scripts/ab_columns.py, 16x32 1 GiB -> 16 columns, kernel ms): windows of 32 / 24 / 16 / 12 KiB:
+// 0.67 / 0.48 / 0.43 / 0.46 — more resident workgroups win until a run of rows becomes too short to write long segments.
 
 struct ToColumnsArgs {
     const uint8_t* bytes;
@@ -226,7 +228,7 @@ hipError_t launch_to_columns(const void* dbytes, u64 bytes_len, const void* dind
     if (r < 1) r = 1;
     a.rows_per_block = r;
     const u64 n_blocks = (n_rows + r - 1) / r;
-    const u64 cap = (u64)(n_cus > 0 ? n_cus : 256) * 20;  // 5 resident workgroups per CU (LDS), four rounds of them
+    const u64 cap = (u64)(n_cus > 0 ? n_cus : 256) * 28;  // 7 resident workgroups per CU (LDS), four rounds of them
     hipLaunchKernelGGL(to_columns_kernel, dim3((u32)(n_blocks < cap ? n_blocks : cap)), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
