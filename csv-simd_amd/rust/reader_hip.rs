@@ -19,6 +19,7 @@ pub struct CsvsimdCtx {
 }
 
 extern "C" {
+    fn csvsimd_abi_version() -> u32;
     fn csvsimd_ctx_create(device: c_int, out: *mut *mut CsvsimdCtx) -> c_int;
     fn csvsimd_ctx_destroy(ctx: *mut CsvsimdCtx);
     fn csvsimd_stage1_index(
@@ -33,11 +34,15 @@ extern "C" {
 }
 
 const CSVSIMD_ERR_TAPE_CAPACITY: c_int = -11;
+/// The C ABI this file was written against (include/csvsimd.h): entry points changed their argument lists between
+/// versions, so a library of another version is refused instead of called.
+const CSVSIMD_ABI_VERSION: u32 = 3;
 
 /// Same signature and result as `reader::read`.  Panics on a GPU/runtime failure, like the
 /// reference panics on its own unsupported inputs (its signature has no `Result`).
 pub fn read(memmap: &Mmap) -> StructureIndex {
     unsafe {
+        assert_eq!(csvsimd_abi_version(), CSVSIMD_ABI_VERSION, "libcsvsimd_hip.so: unexpected C ABI version");
         let mut ctx: *mut CsvsimdCtx = std::ptr::null_mut();
         assert_eq!(csvsimd_ctx_create(0, &mut ctx), 0, "csvsimd: no usable HIP device");
         // first guess: one structural byte per 8 bytes of input; exact retry if the file is denser
