@@ -239,6 +239,13 @@ struct csvsimd_ctx {
     std::unique_ptr<CopyPool> copier;         // host-side slices of the staging copies
     void* d_batch = nullptr;                  // csvsimd_stage1_index_batch_device_async: the buffers' table block
     size_t d_batch_bytes = 0;
+    // small host -> device uploads of the asynchronous entry points (a batch's table, a field list): the caller's memory
+    // is copied into one of two pinned blocks before the call returns, the transfer itself is stream ordered
+    void* pin_up[2] = {nullptr, nullptr};
+    size_t pin_up_bytes[2] = {0, 0};
+    hipEvent_t ev_up[2] = {nullptr, nullptr};
+    bool up_pending[2] = {false, false};
+    unsigned up_next = 0;
 };
 
 extern "C" {
@@ -311,6 +318,10 @@ void csvsimd_ctx_destroy(csvsimd_ctx* ctx) {
     if (ctx->d_small) (void)hipFree(ctx->d_small);
     if (ctx->d_batch) (void)hipFree(ctx->d_batch);
     for (int k = 0; k < 2; ++k) {
+        if (ctx->pin_up[k]) (void)hipHostFree(ctx->pin_up[k]);
+        if (ctx->ev_up[k]) (void)hipEventDestroy(ctx->ev_up[k]);
+    }
+    for (int k = 0; k < 2; ++k) {
         if (ctx->pin_in[k]) (void)hipHostFree(ctx->pin_in[k]);
         if (ctx->pin_out[k]) (void)hipHostFree(ctx->pin_out[k]);
         if (ctx->d_in[k]) (void)hipFree(ctx->d_in[k]);
@@ -343,6 +354,29 @@ int csvsimd_ctx_reserve(csvsimd_ctx* ctx, uint64_t max_len) {
     HIP_TRY(hipMemset(ctx->scratch, 0, need));
     ctx->scratch_bytes = need;
     ctx->launched = false;
+    return CSVSIMD_OK;
+}
+
+// Stream-ordered upload of a few KiB of the CALLER's (pageable, possibly temporary) memory: staged in a context-owned
+// pinned block, so nothing of the caller's is referenced once this returns and the copy engine never reads pageable
+// memory.  Two blocks alternate: the host may run two asynchronous calls ahead of the device.
+static int ctx_upload(csvsimd_ctx* ctx, void* d_dst, const void* src, size_t n, hipStream_t s) {
+    const unsigned k = ctx->up_next++ & 1u;
+    if (!ctx->ev_up[k]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_up[k], hipEventDisableTiming));
+    if (ctx->up_pending[k]) HIP_TRY(hipEventSynchronize(ctx->ev_up[k]));  // the block's previous upload has left it
+    ctx->up_pending[k] = false;
+    if (ctx->pin_up_bytes[k] < n) {
+        if (ctx->pin_up[k]) HIP_TRY(hipHostFree(ctx->pin_up[k]));
+        ctx->pin_up[k] = nullptr;
+        ctx->pin_up_bytes[k] = 0;
+        const size_t cap = std::max<size_t>(65536, n * 2);
+        HIP_TRY(hipHostMalloc(&ctx->pin_up[k], cap, hipHostMallocDefault));
+        ctx->pin_up_bytes[k] = cap;
+    }
+    memcpy(ctx->pin_up[k], src, n);
+    HIP_TRY(hipMemcpyAsync(d_dst, ctx->pin_up[k], n, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(ctx->ev_up[k], s));
+    ctx->up_pending[k] = true;
     return CSVSIMD_OK;
 }
 
@@ -464,9 +498,10 @@ int csvsimd_stage1_index_batch_device_async(csvsimd_ctx* ctx, const csvsimd_batc
         ctx->d_batch_bytes = cap;
     }
     hipStream_t s = (hipStream_t)hip_stream;
-    // from pageable memory: the runtime has taken its copy of the block when this returns, and the transfer itself is
-    // ordered on the stream behind whatever batch is still running from the device table
-    HIP_TRY(hipMemcpyAsync(ctx->d_batch, host.data(), block, hipMemcpyHostToDevice, s));
+    // staged in the context's pinned block; the transfer is ordered on the stream behind whatever batch is still
+    // running from the device table
+    rc = ctx_upload(ctx, ctx->d_batch, host.data(), block, s);
+    if (rc != CSVSIMD_OK) return rc;
     csvsimd::Stage1Launch L;
     L.bind_scratch(ctx->scratch);
     ctx->last_stream = s;
@@ -864,12 +899,17 @@ int csvsimd_stage1_index_multi(const uint8_t* buf, uint64_t len, csvsimd_multi_s
     {
         std::vector<std::thread> th;
         th.reserve(n_shards);
-        for (uint32_t g = 1; g < n_shards; ++g)
-            th.emplace_back([&, g] {
-                rcs[g] = csvsimd_guarded([&]() -> int { return multi_feed_and_index(&shards[g], buf, CSVSIMD_ENTER_GUESS); });
-                if (rcs[g] != CSVSIMD_OK) errs[g] = csvsimd_last_error();
-            });
-        rcs[0] = multi_feed_and_index(&shards[0], buf, file_in_quote_in ? 1u : 0u);
+        try {
+            for (uint32_t g = 1; g < n_shards; ++g)
+                th.emplace_back([&, g] {
+                    rcs[g] = csvsimd_guarded([&]() -> int { return multi_feed_and_index(&shards[g], buf, CSVSIMD_ENTER_GUESS); });
+                    if (rcs[g] != CSVSIMD_OK) errs[g] = csvsimd_last_error();
+                });
+        } catch (...) {  // a thread could not be created: the ones that did start are joined before the exception leaves
+            for (auto& t : th) t.join();
+            throw;
+        }
+        rcs[0] = csvsimd_guarded([&]() -> int { return multi_feed_and_index(&shards[0], buf, file_in_quote_in ? 1u : 0u); });
         if (rcs[0] != CSVSIMD_OK) errs[0] = csvsimd_last_error();
         for (auto& t : th) t.join();
     }
@@ -1289,7 +1329,8 @@ int csvsimd_chunk_to_columns_device(csvsimd_ctx* ctx, const void* dbytes, uint64
     void* d_fields = nullptr;
     if (fields) {
         d_fields = (char*)ctx->d_small + 1024;
-        HIP_TRY(hipMemcpyAsync(d_fields, fields, n_fields * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        rc = ctx_upload(ctx, d_fields, fields, n_fields * sizeof(uint32_t), s);
+        if (rc != CSVSIMD_OK) return rc;
     }
     // rows staged per workgroup step: what fits the window on average, with a fifth of it to spare for longer rows
     const uint64_t avg_row = std::max<uint64_t>(1, bytes_len / std::max<uint64_t>(1, record_cnt));
