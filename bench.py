@@ -5,8 +5,8 @@
 
 A "step" is one pass of the hot path over one batch of synthetic CSV already resident in HBM:
 each rank indexes its contiguous byte shard of the file (first stage-1 launch through the C ABI: rank 0
-knows how the file starts, every other rank lets the kernel choose the entering state its first tile
-speaks for, CSVSIMD_ENTER_GUESS), the ranks exchange their shard descriptors with ONE all-gather over
+knows how the file starts, every other rank lets the kernel choose the entering state its first eight tiles
+speak for, CSVSIMD_ENTER_GUESS), the ranks exchange their shard descriptors with ONE all-gather over
 RCCL (N > 1), a one-lane kernel stitches quote parity / tape bases ON THE DEVICE, and a second launch
 re-emits the shard iff its first pass turns out to have used the wrong entering state (flag read from
 device memory).  Nothing between the first
@@ -741,12 +741,12 @@ def run_sharded(pkg, sb, device, dist_on, rehearsal, comm, steps, warmup):
     depth = PIPELINE_DEPTH if os.environ.get("CSVSIMD_BENCH_PIPELINE", "1") != "0" and comm is None else 1
     stepper = (sharded.ShardedStep(device, gather_via_host=rehearsal, depth=depth)
                if (dist_on and comm is None) else None)
-    # rank 0 knows how the file starts; every other rank lets the kernel choose the entering state its first tile speaks
+    # rank 0 knows how the file starts; every other rank lets the kernel choose the entering state its first eight tiles speak
     # for (CSVSIMD_ENTER_GUESS) — only a rank that chose wrong re-emits.  CSVSIMD_BENCH_NO_GUESS=1: speculate "outside"
     # everywhere, as round 1 did (then every rank that really starts inside a string re-emits).
     guess = os.environ.get("CSVSIMD_BENCH_NO_GUESS") != "1"
     first_state = pkg.ENTER_GUESS if (guess and sb.rank > 0) else 0
-    state["first_pass"] = "rank 0: entering state known; ranks > 0: " + ("the kernel's guess from its first tile"
+    state["first_pass"] = "rank 0: entering state known; ranks > 0: " + ("the kernel's guess from its first eight tiles"
                                                                         if guess else "speculated 'outside'")
     inflight = []          # slots enqueued and not yet collected, oldest first
     counter = [0]

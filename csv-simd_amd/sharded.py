@@ -11,7 +11,7 @@ string and obtains the composable shard descriptor
 `array_idx`: src/reader.rs:217-218).  ONE all-gather of the 64-byte result record per rank stitches
 them (RCCL has no exclusive scan; the payload is latency-bound, so the 7 x ~153 GB/s xGMI links
 are irrelevant).  Rank 0 knows how the file starts; the other ranks either speculate (first_state 0) or let the kernel
-choose the entering state its first tile speaks for (first_state ENTER_GUESS).  Only a rank whose first pass turns out to
+choose the entering state its first eight tiles (2 MiB) speak for (first_state ENTER_GUESS).  Only a rank whose first pass turns out to
 have used the wrong state re-emits its shard (never on quote-free corpora; with ENTER_GUESS not on quoted CSV either).  The tape stays sharded in rank order with
 absolute offsets: concatenating the shards, after the sentinel 0, is the reference's tape.
 """
@@ -142,7 +142,7 @@ class ShardedStep:
             raise RuntimeError("ShardedStep: slot enqueued again before it was collected")
         sl.err = None
         try:
-            launch(first_state)   # 0 = speculate "entered outside"; ENTER_GUESS = the kernel chooses from its first tile
+            launch(first_state)   # 0 = speculate "entered outside"; ENTER_GUESS = the kernel chooses from its first eight tiles
         except Exception as e:  # still join the collective: the peers are about to block in it
             sl.err = e
             sl.d_result.zero_()
@@ -198,7 +198,7 @@ def index_sharded(launch: Callable[[int], None], d_result: torch.Tensor, group=N
     re-emit, and as the arithmetic the gloo tests compare the device stitch with):
     launch(first_state) -> ONE all-gather of the result records -> copy to the host -> csvsimd_stitch_shards ->
     launch(true state) only if the first pass ran with another entering state than the true one
-    (first_state: 0 = speculate "outside", ENTER_GUESS = let the kernel choose from the shard's first tile).
+    (first_state: 0 = speculate "outside", ENTER_GUESS = let the kernel choose from the shard's first eight tiles).
     Returns (stitch, final result of this rank, re_emitted).  Every rank joins the collective even if its
     own launch raises."""
     rank = dist.get_rank(group)

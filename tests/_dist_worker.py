@@ -39,8 +39,8 @@ def worker(rank, world, port, n, seed, p_quote, skew, outdir, device_flow=False,
         def run_pass(in_quote_in):
             passes.append(in_quote_in)
             if in_quote_in == pkg.ENTER_GUESS:
-                # what the kernel does: the state under which the shard's first tile has more entries
-                _, a0, b0 = oracle.shard_descriptor(shard[: pkg.tile_bytes()])
+                # what the kernel does: the state under which the shard's first eight tiles have more entries
+                _, a0, b0 = oracle.shard_descriptor(shard[: 8 * pkg.tile_bytes()])
                 in_quote_in = int(b0 > a0)
             entries, inq_out = oracle.scalar_index(shard, base_off=lo, in_quote_in=in_quote_in)
             p, c0, c1 = oracle.shard_descriptor(shard)

@@ -899,7 +899,7 @@ def test_device_stitch_and_reemit_three_shards_one_gpu(pkg, torch_cuda, oracle, 
                 for r in range(world):
                     lo, hi = cuts[r], cuts[r + 1]
                     tapes[r].fill_(-1)
-                    # first pass: speculate "entered outside", or (guess) let ranks > 0 choose from their first tile
+                    # first pass: speculate "entered outside", or (guess) let ranks > 0 choose from their first eight tiles
                     first = pkg.ENTER_GUESS if (guess and r > 0) else 0
                     ctxs[r].stage1_index_device_async(dbuf.data_ptr() + lo, hi - lo, lo, first, tapes[r].data_ptr(),
                                                       tapes[r].numel(), d_fin[r].data_ptr(), s)
