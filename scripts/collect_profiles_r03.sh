@@ -8,7 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_r03
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-FLAGS="--steps 10 --warmup 2 --no-extra --no-cpu-baseline --no-verify --no-q10-check --no-ingest --no-strong-check"
+FLAGS="--steps 60 --warmup 2 --no-extra --no-cpu-baseline --no-verify --no-q10-check --no-ingest --no-strong-check"
 BENCH="python3 $REPO/bench.py $FLAGS"
 DENSE="python3 $REPO/bench.py --workload 1024x4_dense --gib-per-gpu 1 $FLAGS"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/stats.log" 2>&1
