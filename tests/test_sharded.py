@@ -1,5 +1,5 @@
 """Multi-rank stitch: host arithmetic (csvsimd_stitch_shards) and the N>1 control flow over a
-real torch.distributed group (gloo, CPU, world_size 2 and 3)."""
+real torch.distributed group (gloo, CPU, world_size 2, 3, 4 and 8)."""
 import os
 import socket
 import sys
@@ -63,7 +63,9 @@ def test_stitch_host_arithmetic(pkg, oracle):
                           (3, 0.1, 13, False, False), (2, 0.06, 777, True, False), (4, 0.1, 13, True, False),
                           (2, 0.1, 777, 2, False), (3, 0.06, 13, 2, False),
                           # ranks > 0 let the pass choose its entering state (CSVSIMD_ENTER_GUESS)
-                          (3, 0.1, 13, False, True), (4, 0.06, 777, True, True), (3, 0.1, 13, 2, True)])
+                          (3, 0.1, 13, False, True), (4, 0.06, 777, True, True), (3, 0.1, 13, 2, True),
+                          # BASELINE config 4's rank count: 8 shards, cut mid-row, device flow, two steps in flight
+                          (8, 0.1, 777, 2, True)])
 def test_gloo_sharded_stitch(pkg, oracle, tmp_path, world, p_quote, skew, device_flow, guess):
     import torch.multiprocessing as mp
     n, seed = 40000, 4242
