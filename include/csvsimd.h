@@ -123,8 +123,11 @@ int csvsimd_stage1_index_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len
  * tiles of all buffers from one ticket; a tile's look-back stops at its buffer's first tile.  d_results = n_items
  * csvsimd_shard_result records in DEVICE memory (16-byte aligned), record i for items[i], valid once the stream has
  * drained: exactly what csvsimd_stage1_index_device_async would have written for that buffer alone (same tape, same
- * counts).  items is HOST memory (read before the call returns).  Reference dialect only.  Asynchronous on hip_stream;
- * allocates / synchronises only when the context's scratch or its buffer table has to grow. */
+ * counts).  items is HOST memory (read before the call returns).  Reference dialect only.  Asynchronous on hip_stream:
+ * nothing it enqueues is waited for; it allocates / synchronises only when the context's scratch or its buffer table has
+ * to grow, and it may wait for the table upload of the call before the previous one (two staging blocks alternate).
+ * Not capturable into a hipGraph (the table travels by a host-staged copy): capture
+ * csvsimd_stage1_index_device_async launches instead. */
 typedef struct csvsimd_batch_item {
     const void* dbuf;
     uint64_t len;
