@@ -604,6 +604,19 @@ def consumers_leg(pkg, oracle, device):
                                       "point at a representative record and compare bytes: exact, no verification pass), "
                                       "compact; algorithmic bytes = the column + its lengths read, 16 B per distinct value "
                                       "written"}
+    # ... and of a column of FEW distinct values (100 of them over the same 2.03 M records): the workgroup-local LDS stage
+    # keeps the hot values off the global table (all 2 M records would otherwise hammer 100 slots)
+    vocab = ccols[field][:100].clone()
+    pick = torch.randint(0, 100, (nrec,), device=device)
+    few = vocab[pick].contiguous()
+    t_few, st_few = best(lambda: pkg.columnar_frequency_device(ctx, few.data_ptr(), 0, nrec, stride, 0, scratch.data_ptr(), slots,
+                                                           ent.data_ptr(), ent.shape[0]))
+    cnt_few = torch.bincount(pick, minlength=100)
+    got_few = ent[: st_few.n_distinct].cpu()
+    ok = ok and st_few.n_distinct == 100 and int(got_few[:, 1].sum()) == nrec
+    ok = ok and sorted(got_few[:, 1].tolist()) == sorted(cnt_few.cpu().tolist())
+    res["frequency_count"]["few_distinct_values"] = {"ms": round(t_few * 1e3, 3), "distinct": int(st_few.n_distinct)}
+    del few, pick
     # ---- search -----------------------------------------------------------------------------------------------------
     needle = host[int(hidx[1000 * cols + field]) + 4: int(hidx[1000 * cols + field]) + 10]
     bm = torch.zeros((nrec + 63) // 64 + 1, dtype=torch.int64, device=device)
