@@ -948,14 +948,6 @@ __device__ __forceinline__ void finish_launch(const KernelArgs& args, u32 epoch,
     u32 esc_out = 0;
     if (DIALECT >= 2)
         esc_out = escape_run_parity(args.abase, args.lo, args.hi, args.hi, args.escape, escape_in_of<DIALECT>(args), lane);
-    const u32 next_epoch = (epoch + 1u) & kEpochMask;
-    u32 hwm = hwm_seen > args.num_tiles ? hwm_seen : args.num_tiles;
-    if (next_epoch == 0u) {
-        // the epoch wraps: words tagged in earlier rounds of the counter must not be mistaken for
-        // the next round's, so everything used since the last wrap is cleared (once per 1024 launches)
-        for (u32 i = lane; i < hwm; i += 64u) args.desc[i] = 0;
-        hwm = 0;
-    }
     if (BATCH) {
         // one record per buffer, 64 buffers at a time: the inclusive word of the buffer's LAST tile holds its count and
         // leaving state (published by whichever workgroup resolved that tile, before it counted itself done); an empty
@@ -993,6 +985,18 @@ __device__ __forceinline__ void finish_launch(const KernelArgs& args, u32 epoch,
             r->reserved1 = 0;
             args.batch_tot[b] = 0;  // ready for the next launch over the same buffers (a replayed graph)
         }
+    }
+    // ONLY NOW — every inclusive word this function reads (the shard's last tile above, every buffer's last tile in the
+    // batched loop) has been read — may the words be cleared:
+    const u32 next_epoch = (epoch + 1u) & kEpochMask;
+    u32 hwm = hwm_seen > args.num_tiles ? hwm_seen : args.num_tiles;
+    if (next_epoch == 0u) {
+        // the epoch wraps: words tagged in earlier rounds of the counter must not be mistaken for
+        // the next round's, so everything used since the last wrap is cleared (once per 1024 launches)
+        // (round 3's first batched kernel cleared BEFORE its per-buffer loop: every 1024th batch reported the spin bound —
+        // found by scripts/soak.py's batched mode, pinned by test_batch_across_an_epoch_wrap)
+        for (u32 i = lane; i < hwm; i += 64u) args.desc[i] = 0;
+        hwm = 0;
     }
     if (lane == 0) {
         csvsimd_shard_result* const r = BATCH ? nullptr : args.result;

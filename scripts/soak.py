@@ -56,7 +56,31 @@ def main():
                 ref[key] = sig
             hist["ok" if sig == ref[key] else f"MISMATCH case {ci} {name} inq {inq}: {sig} != {ref[key]}"] += 1
             launches += 1
-    print(json.dumps({"seconds": seconds, "launches": launches, "cases": len(cases), "hist": dict(hist)}))
+    # batched launches: slices of the corpora above as independent buffers (ragged sizes, both entering states), the
+    # same batch again and again: every record and every tape checksum must repeat
+    import numpy as np
+    bt_end = time.time() + max(10.0, seconds / 4)
+    name, n, dbuf, dtape, cap, _, _ = cases[0]
+    sizes = [3 * 262144 + 17, 1, 262144, 5 * 262144 - 64, 0, 40 * 262144 + 4097, 777, 12 * 262144]
+    offs = np.cumsum([0] + [s_ + 4096 for s_ in sizes])
+    btapes = [torch.empty(max(s_, 1) // 8 + 64, dtype=torch.int64, device=dev) for s_ in sizes]
+    items = [(dbuf.data_ptr() + int(offs[i]) + (i % 3), sizes[i], int(offs[i]), btapes[i].data_ptr(), btapes[i].numel(), i & 1)
+             for i in range(len(sizes))]
+    bres = torch.zeros((len(sizes), 8), dtype=torch.int64, device=dev)
+    bref, batches = None, 0
+    while time.time() < bt_end:
+        ctx.stage1_index_batch_device_async(items, bres.data_ptr())
+        recs = bres.cpu().numpy().copy()
+        sig = [recs.tobytes()]
+        for i in range(len(sizes)):
+            dsum.zero_()
+            pkg.tape_checksum_device(btapes[i].data_ptr(), min(int(recs[i, 0]), btapes[i].numel()), 0, dsum.data_ptr())
+            sig.append(tuple(dsum.tolist()))
+        if bref is None:
+            bref = sig
+        hist["ok" if sig == bref else f"MISMATCH batch {batches}"] += 1
+        batches += 1
+    print(json.dumps({"seconds": seconds, "launches": launches, "batched_launches": batches, "cases": len(cases), "hist": dict(hist)}))
     return 0 if set(hist) == {"ok"} else 1
 
 

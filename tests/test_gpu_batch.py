@@ -97,3 +97,39 @@ def test_batch_capacity_protocol_and_argument_checks(ctx, pkg, oracle):
         ctx.stage1_index_batch_device_async([(d.data_ptr(), 64, 0, 0, 5, 0)], dres.data_ptr())
     with pytest.raises(pkg.StructureError):   # no buffers
         ctx.stage1_index_batch_device_async([], dres.data_ptr())
+
+
+def test_batch_across_an_epoch_wrap(pkg, oracle):
+    """The look-back words carry a 10-bit launch epoch; when it wraps (every 1024 launches of a context) the last
+    workgroup clears the words used since the last wrap — AFTER it has read every buffer's last word.  (Round 3's first
+    batched kernel cleared first: every 1024th batch came back with the spin-bound error flag; found by scripts/soak.py.)
+    1 100 batched launches on a fresh context, mixed with single-buffer launches: every record equals the first's."""
+    import torch
+    rng = np.random.default_rng(1024)
+    T = pkg.tile_bytes()
+    ctx = pkg.Context(0)
+    bufs = [random_csvish(rng, n, 0.05) for n in (2 * T + 5, 100, 3 * T - 1)]
+    dbufs = [torch.from_numpy(b).cuda() for b in bufs]
+    tapes = [torch.full((b.size + 1,), -1, dtype=torch.int64, device="cuda:0") for b in bufs]
+    items = [(d.data_ptr(), b.size, 0, t.data_ptr(), t.numel(), i & 1) for i, (d, b, t) in enumerate(zip(dbufs, bufs, tapes))]
+    dres = torch.zeros((3, 8), dtype=torch.int64, device="cuda:0")
+    dsingle = torch.zeros(8, dtype=torch.int64, device="cuda:0")
+    first = None
+    for it in range(1100):
+        ctx.stage1_index_batch_device_async(items, dres.data_ptr())
+        got = dres.cpu()
+        if first is None:
+            first = got.clone()
+            for i, b in enumerate(bufs):
+                want, q = oracle.scalar_index(b, in_quote_in=i & 1)
+                assert int(got[i, 0]) == want.size and (int(got[i, 4]) & 0xFFFFFFFF) == 0
+                assert np.array_equal(tapes[i][: want.size].cpu().numpy().view(np.uint64), want)
+        assert torch.equal(got, first), it
+        if it % 3 == 0:   # single-buffer launches share the context's epoch counter
+            ctx.stage1_index_device_async(dbufs[0].data_ptr(), bufs[0].size, 0, 0, tapes[0].data_ptr(), tapes[0].numel(),
+                                          dsingle.data_ptr())
+    torch.cuda.synchronize()
+    for i, b in enumerate(bufs[1:], start=1):
+        want, _ = oracle.scalar_index(b, in_quote_in=i & 1)
+        assert np.array_equal(tapes[i][: want.size].cpu().numpy().view(np.uint64), want)
+    ctx.close()
