@@ -31,10 +31,19 @@ checked; all K records are checked inside the timed region, which is bracketed b
 Rank 0 prints ONE JSON line.  value = whole-job GiB/s (all ranks' bytes / max-over-ranks time).
 roofline: HBM-bound, algorithmic bytes = 1 byte read per CSV byte scanned (SURVEY.md §8d);
 duration = the stage-1 kernel's average launch time from HIP events recorded on its own stream
-(a launch is exactly one kernel).  cpu_baseline: the oracle's faithful SSE restatement of the reference
-loop ("ref_sse_1t": 1 thread like the reference, growing Vec) timed on this host over a bounded sample
-of the same bytes.  ingest: the host-buffer drop-in (PCIe-inclusive) next to the probed H2D rate —
-never part of `value`.
+(a launch is exactly one kernel), on every rank: frac is the slowest rank's.  The CPU beside it, on rank 0's host cores,
+same bytes, same run, at EVERY N: cpu_baseline = the oracle's faithful SSE restatement of the reference loop
+("ref_sse_1t": 1 thread like the reference, growing Vec) over a bounded sample; cpu_baseline_mt (chunked over the
+stated number of threads), ref_sse_1t_native, scalar_1t.
+
+Scaling: weak by default (every rank holds --gib-per-gpu bytes at every N).  --scaling strong cuts ONE --total-gib file
+into one shard per rank; the default line also carries that leg (strong_scaling_check: the same 64 GiB file — BASELINE
+config 4 — indexed and verified at this N: all of it on one GPU at N = 1, 8 GiB each at N = 8).
+
+N = 1 only: other_workloads (the 1-GiB configs 2, 3, 5, timed and verified; an independent plain-copy yardstick next to
+the dense corpus' bare-stream probe), batch_many_files (8 x 128 MiB: eight launches vs ONE batched launch), consumers
+(file + tape -> columns in one pass, frequency count and search on a column, PMC traffic of the committed profile),
+ingest (the host-buffer drop-in, PCIe-inclusive, next to the probed H2D rate — never part of `value`).
 """
 import argparse
 import json
