@@ -872,25 +872,26 @@ def test_launch_epochs_wrap_and_shard_sizes_change(pkg, torch_cuda, oracle):
         c.close()
 
 
+@pytest.mark.parametrize("world,shard_tiles", [(3, 1), (8, 9)])
 @pytest.mark.parametrize("guess", [False, True])
-def test_device_stitch_and_reemit_three_shards_one_gpu(pkg, torch_cuda, oracle, guess):
-    # the N > 1 step as bench.py / csvsimd_stage1_index_sharded drive it, with three shards on ONE GPU and
-    # a device-to-device copy standing in for the all-gather: speculative pass -> records side by side in
-    # device memory -> stitch kernel -> re-emit launch that reads its entering state from device memory.
-    # No host value is used between the first launch and the final copy-out.
+def test_device_stitch_and_reemit_three_shards_one_gpu(pkg, torch_cuda, oracle, guess, world, shard_tiles):
+    # the N > 1 step as bench.py / csvsimd_stage1_index_sharded drive it, with three (or, BASELINE config 4's shape,
+    # eight) shards on ONE GPU and a device-to-device copy standing in for the all-gather: speculative pass -> records
+    # side by side in device memory -> stitch kernel -> re-emit launch that reads its entering state from device
+    # memory.  No host value is used between the first launch and the final copy-out.  Nine tiles per shard: the
+    # eight-tile vote of CSVSIMD_ENTER_GUESS sees a full window and a tile it does not look at.
     torch = torch_cuda
     from csv_simd_amd import sharded
     rng = np.random.default_rng(5150)
     T = pkg.tile_bytes()
     for trial, p_quote in enumerate((0.0, 0.02, 0.11, 0.5)):
-        n = 3 * T + 1000 * trial + 99
+        n = world * shard_tiles * T + 1000 * trial + 99
         d = random_csvish(rng, n, p_quote)
-        cuts = [0, T + 777, 2 * T + 13, n]
+        cuts = [0] + [r * shard_tiles * T + int(rng.integers(-T // 2, T // 2)) for r in range(1, world)] + [n]
         dbuf = torch.from_numpy(d).cuda()
-        world = 3
         ctxs = [pkg.Context(0) for _ in range(world)]
         try:
-            tapes = [torch.full((n + 8,), -1, dtype=torch.int64, device="cuda:0") for _ in range(world)]
+            tapes = [torch.full((cuts[r + 1] - cuts[r] + 8,), -1, dtype=torch.int64, device="cuda:0") for r in range(world)]
             d_all = torch.zeros(8 * world, dtype=torch.int64, device="cuda:0")
             d_st = torch.zeros((world, sharded.STITCH_WORDS), dtype=torch.int64, device="cuda:0")
             d_fin = torch.zeros((world, 8), dtype=torch.int64, device="cuda:0")
