@@ -5,7 +5,8 @@ here: scripts/ never ship).  Every case is a random RECTANGULAR file: 1..3000 co
 beyond the LDS window (rows longer than 16 KiB, more than 2048 tape entries per row), quoted fields holding separators
 and line ends, a low-cardinality vocabulary mixed in; random chunking, field lists (with repeats), strides; every cell
 (or a sample of 4000 on large cases) must be seek_field's text truncated and zero padded, every length exact, the count a
-collections.Counter and the search Python's == / startswith / in.  usage: fuzz_columnar.py [seconds] [seed]"""
+collections.Counter and the search Python's == / startswith / in; then the per-column consumers on the row-major file
+itself (chunk spans, exact count over all chunks with values of any length, search).  usage: fuzz_columnar.py [seconds] [seed]"""
 import json
 import os
 import sys
@@ -163,7 +164,64 @@ def one_case(rng, ctx):
             if got_n != len(want_ids) or got_ids != want_ids:
                 return cells, {"what": "search", "mode": mode, "needle": needle.hex(), "got": got_n, "want": len(want_ids),
                                "stride": stride, "n": n}
-    return cells, None
+    return cells, rowmajor_consumers(rng, ctx, data, index, tape, dbuf, mis, dindex)
+
+
+def rowmajor_consumers(rng, ctx, data, index, tape, dbuf, mis, dindex):
+    """the per-column consumers on the row-major file itself (consumer_kernels.hip): spans, exact count, search"""
+    F, crlf = tape.field_cnt, tape.new_line == "CRLF"
+    chunks = tape.chunks(min(int(rng.integers(1, 6)), tape.record_cnt - 1))
+    f = int(rng.integers(0, F))
+    dbytes = dbuf.data_ptr() + mis
+    ch = chunks[int(rng.integers(0, len(chunks)))]
+    n = ch[3]
+    recs = list(oracle.chunk_record_ids(ch, F, crlf))
+    texts = [oracle.seek_field(data, index, F, crlf, r, f) for r in recs]
+    b = torch.full((n + 1,), -1, dtype=torch.int64, device="cuda:0")
+    e = torch.full((n + 1,), -1, dtype=torch.int64, device="cuda:0")
+    got_n = pkg.chunk_field_spans_device(dindex.data_ptr(), index.size, F, tape.new_line, ch, f, b.data_ptr(), e.data_ptr())
+    bh, eh = b.cpu().tolist(), e.cpu().tolist()
+    if got_n != n or bh[n] != -1 or any(data[bh[k]: eh[k]] != texts[k] for k in range(n)):
+        return {"what": "spans", "field": f, "chunk": list(ch)}
+    all_texts = [oracle.seek_field(data, index, F, crlf, r, f) for c in chunks for r in oracle.chunk_record_ids(c, F, crlf)]
+    first_rec = next(iter(oracle.chunk_record_ids(chunks[0], F, crlf)))
+    want = Counter(all_texts)
+    slots = 64
+    while slots < 2 * len(want) + 2:
+        slots *= 2
+    scratch = torch.empty(pkg.column_frequency_scratch_bytes(slots), dtype=torch.uint8, device="cuda:0")
+    ent = torch.zeros((len(want) + 2, 4), dtype=torch.int64, device="cuda:0")
+    st = pkg.column_frequency_device(ctx, dbytes, dindex.data_ptr(), index.size, F, tape.new_line, chunks, f,
+                                     scratch.data_ptr(), slots, ent.data_ptr(), ent.shape[0])
+    got, first_of = {}, {}
+    for i, t in enumerate(all_texts):
+        first_of.setdefault(t, i)
+    for first, bb, ee, cnt in ent[: st.n_distinct].cpu().tolist():
+        t = data[bb:ee]
+        if t in got or first_of.get(t) != first - first_rec:
+            return {"what": "row-major freq entry", "first": first, "field": f}
+        got[t] = cnt
+    if st.n_distinct != len(want) or got != dict(want) or st.n_records != len(all_texts):
+        return {"what": "row-major freq", "distinct": st.n_distinct, "want": len(want), "field": f}
+    for _ in range(3):
+        mode = int(rng.integers(0, 3))
+        src = texts[int(rng.integers(0, n))]
+        if rng.random() < 0.7 and src:
+            a = int(rng.integers(0, len(src)))
+            k = int(rng.integers(0, min(len(src) - a, 256) + 1))
+            needle = src[a: a + k] if mode == 2 else src[:k] if mode == 1 else src[:256]
+        else:
+            needle = bytes(rng.integers(97, 100, size=int(rng.integers(0, 4)), dtype=np.uint8))
+        test = (lambda v: v == needle, lambda v: v.startswith(needle), lambda v: needle in v)[mode]
+        want_ids = [i for i, t in enumerate(texts) if test(t)]
+        bm = torch.zeros((n + 63) // 64 + 1, dtype=torch.int64, device="cuda:0")
+        got_n = pkg.column_search_device(ctx, dbytes, len(data), dindex.data_ptr(), index.size, F, tape.new_line, ch, f,
+                                         needle, mode, bm.data_ptr())
+        bits = np.unpackbits(bm.cpu().numpy().view(np.uint8), bitorder="little")
+        if got_n != len(want_ids) or np.flatnonzero(bits).tolist() != want_ids:
+            return {"what": "row-major search", "mode": mode, "needle": needle.hex(), "got": got_n, "want": len(want_ids),
+                    "field": f, "chunk": list(ch)}
+    return None
 
 
 def main():
