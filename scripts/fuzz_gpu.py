@@ -4,7 +4,8 @@ infrastructure, allowed here: scripts/ never ship).  Every case: random size (1 
 boundaries), a random mixture of generators (uniform random bytes over the special alphabet, CSV-like rows, blocks that
 make the speculative scatter guess right or wrong with either entering state, dense runs), random misalignment,
 base offset, entering state and tape capacity.  The whole tape, the count, the leaving state and the two hypothesis
-counts must equal the oracle's.  usage: fuzz_gpu.py [seconds] [seed]"""
+counts must equal the oracle's.  Three more modes: a batch of buffers per launch, the host-buffer entry point, the dialect
+extension with random delimiter / quote / escape bytes, and the UTF-8 validation pass against CPython's decoder.  usage: fuzz_gpu.py [seconds] [seed] [only this mode]"""
 import json
 import os
 import sys
@@ -82,13 +83,14 @@ def make_case(rng):
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+    only_mode = int(sys.argv[3]) if len(sys.argv) > 3 else None   # 0 batch, 1 host buffer, 2 dialect, 3 UTF-8, 4.. device entry
     rng = np.random.default_rng(seed)
     ctx = pkg.Context(0)
     t_end = time.time() + seconds
     cases = bytes_total = 0
     bad = []
     while time.time() < t_end and not bad:
-        mode = int(rng.integers(0, 8))
+        mode = int(rng.integers(0, 8)) if only_mode is None else only_mode
         if mode == 0:
             # a BATCH of buffers in one launch: every record and every tape must be the buffer's own
             k = int(rng.integers(1, 12))
@@ -127,6 +129,71 @@ def main():
                 np.save(os.path.join(ROOT, "gpurun_out", f"fuzz_fail_host_{seed}_{cases}.npy"), d)
             cases += 1
             bytes_total += int(d.size)
+            continue
+        if mode == 2:
+            # the dialect extension: ANY delimiter / quote / escape bytes (every triple takes the hashed or the compare
+            # classification, whichever the host search finds), every byte value in the data, the special ones often
+            while True:
+                dl, qu, es = int(rng.integers(1, 256)), int(rng.integers(0, 256)), int(rng.integers(0, 256))
+                qu = 0 if rng.random() < 0.15 else qu
+                es = 0 if rng.random() < 0.3 else es
+                if dl in (10, 13) or qu in (dl, 10, 13) or es in (dl, 10, 13) or (es and es == qu):
+                    continue
+                break
+            n = int(rng.choice([int(rng.integers(1, 5000)), int(rng.integers(1, 3 * pkg.tile_bytes()))]))
+            d = rng.integers(0, 256, size=n, dtype=np.uint8)
+            special = np.array([b for b in (dl, qu, es, 10, 13) if b], dtype=np.uint8)
+            near = np.array([int(b) ^ (1 << k) for b in special for k in range(8)], dtype=np.uint8)   # one bit off
+            u = rng.random(n)
+            p_sp = rng.choice([0.02, 0.15, 0.6])
+            d[u < p_sp] = special[rng.integers(0, special.size, size=int((u < p_sp).sum()))]
+            d[u > 0.9] = near[rng.integers(0, near.size, size=int((u > 0.9).sum()))]
+            dia = pkg.Dialect(dl, qu or None, es or None, escape_in=int(rng.integers(0, 2)) if es else 0)
+            inq, base, mis = int(rng.integers(0, 2)), int(rng.integers(0, 1 << 40)), int(rng.integers(0, 128))
+            want, q, e = oracle.dialect_index(d, dl, qu, es, base_off=base, in_quote_in=inq, escape_in=dia.escape_in)
+            dbuf = torch.full((n + 256,), es or dl, dtype=torch.uint8, device="cuda:0")
+            dbuf[mis: mis + n] = torch.from_numpy(d)
+            dtape = torch.full((n + 9,), -1, dtype=torch.int64, device="cuda:0")
+            dres = torch.zeros(8, dtype=torch.int64, device="cuda:0")
+            ctx.stage1_index_device_dialect_async(dia, dbuf.data_ptr() + mis, n, base, inq, dtape.data_ptr(), n + 1,
+                                                  dres.data_ptr())
+            torch.cuda.synchronize()
+            r = pkg.ShardResult.from_buffer_copy(dres.cpu().numpy().tobytes())
+            got = dtape[: want.size].cpu().numpy().view(np.uint64)
+            if not (r.error == 0 and r.count == want.size and r.written == r.count and np.array_equal(got, want)
+                    and bool((dtape[want.size:] == -1).all()) and r.in_quote_out == q and (not es or r.escape_out == e)):
+                bad.append({"case": cases, "mode": "dialect", "dialect": [dl, qu, es, int(dia.escape_in)], "n": n,
+                            "count": int(r.count), "want": int(want.size)})
+                np.save(os.path.join(ROOT, "gpurun_out", f"fuzz_fail_dialect_{seed}_{cases}.npy"), d)
+            cases += 1
+            bytes_total += n
+            continue
+        if mode == 3:
+            # UTF-8 validation (extension): text in one to four byte sequences, a few random corruptions, random cut
+            cps = np.concatenate([rng.integers(0x20, 0x7F, size=int(rng.integers(0, 30000))),
+                                  rng.integers(0xA0, 0x7FF, size=int(rng.integers(0, 20000))),
+                                  rng.integers(0x800, 0xD7FF, size=int(rng.integers(0, 20000))),
+                                  rng.integers(0xE000, 0xFFFF, size=int(rng.integers(0, 3000))),
+                                  rng.integers(0x10000, 0x10FFFF, size=int(rng.integers(0, 20000)))])
+            rng.shuffle(cps)
+            d = np.frombuffer("".join(map(chr, cps.tolist())).encode("utf-8"), dtype=np.uint8).copy()
+            if d.size == 0:
+                continue
+            d = d[int(rng.integers(0, min(4, d.size))): d.size - int(rng.integers(0, min(4, d.size)))]
+            for p_ in rng.integers(0, max(d.size, 1), size=int(rng.integers(0, 4))):
+                if d.size:
+                    d[p_] = rng.integers(0, 256)
+            n, mis = d.size, int(rng.integers(0, 128))
+            dbuf = torch.full((n + 256,), int(rng.choice([0xFF, 0x80, 0xE2])), dtype=torch.uint8, device="cuda:0")
+            if n:
+                dbuf[mis: mis + n] = torch.from_numpy(d)
+            got = ctx.utf8_validate_device(dbuf.data_ptr() + mis, n)
+            want = oracle.utf8_first_invalid(d)
+            if got != want:
+                bad.append({"case": cases, "mode": "utf8", "n": n, "got": got, "want": want})
+                np.save(os.path.join(ROOT, "gpurun_out", f"fuzz_fail_utf8_{seed}_{cases}.npy"), d)
+            cases += 1
+            bytes_total += n
             continue
         d = make_case(rng)
         n = d.size
