@@ -232,7 +232,11 @@ def main():
     t_end = time.time() + seconds
     cases = cells = 0
     bad = []
+    t_say = time.time() + 60
     while time.time() < t_end and not bad:
+        if time.time() > t_say:   # a line a minute: a silent GPU command is taken for hung after seven
+            print(f"# {cases} cases", file=sys.stderr, flush=True)
+            t_say = time.time() + 60
         state = rng.bit_generator.state
         k, err = one_case(rng, ctx)
         cells += k

@@ -89,7 +89,11 @@ def main():
     t_end = time.time() + seconds
     cases = bytes_total = 0
     bad = []
+    t_say = time.time() + 60
     while time.time() < t_end and not bad:
+        if time.time() > t_say:   # a line a minute: a silent GPU command is taken for hung after seven
+            print(f"# {cases} cases", file=sys.stderr, flush=True)
+            t_say = time.time() + 60
         mode = int(rng.integers(0, 8)) if only_mode is None else only_mode
         if mode == 0:
             # a BATCH of buffers in one launch: every record and every tape must be the buffer's own

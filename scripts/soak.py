@@ -38,7 +38,11 @@ def main():
     hist = collections.Counter()
     t_end = time.time() + seconds
     launches = 0
+    t_say = time.time() + 60
     while time.time() < t_end:
+        if time.time() > t_say:   # a line a minute: a silent GPU command is taken for hung after seven
+            print(f"# {launches} launches, {sum(v for k, v in hist.items() if k != 'ok')} mismatches", file=sys.stderr, flush=True)
+            t_say = time.time() + 60
         for ci, (name, n, dbuf, dtape, cap, dialect, mis) in enumerate(cases):
             inq = launches % 3   # 0, 1, and 2 = CSVSIMD_ENTER_GUESS (the kernel's own choice must be the same every time too)
             if dialect is None:
@@ -69,6 +73,9 @@ def main():
     bres = torch.zeros((len(sizes), 8), dtype=torch.int64, device=dev)
     bref, batches = None, 0
     while time.time() < bt_end:
+        if time.time() > t_say:
+            print(f"# {batches} batched launches", file=sys.stderr, flush=True)
+            t_say = time.time() + 60
         ctx.stage1_index_batch_device_async(items, bres.data_ptr())
         recs = bres.cpu().numpy().copy()
         sig = [recs.tobytes()]
