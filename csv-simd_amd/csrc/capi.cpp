@@ -1503,9 +1503,9 @@ int csvsimd_stage1_time_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len,
     if (L.debug_mode == 8) HIP_TRY(hipMemsetAsync(L.scratch_prof, 0, 17 * 8, s));
     uint64_t* d_trace = nullptr;
     const uint64_t trace_tiles = (len + 127 + CSVSIMD_TILE_BYTES - 1) / CSVSIMD_TILE_BYTES + 1;
-    if (L.debug_mode == 40) {  // per-tile timeline (scripts/trace_tiles.py): its own buffer, slots as in CSVSIMD_TRACE
-        HIP_TRY(hipMalloc((void**)&d_trace, (32 + trace_tiles * 8) * 8));
-        HIP_TRY(hipMemset(d_trace, 0, (32 + trace_tiles * 8) * 8));
+    if (L.debug_mode == 40 || L.debug_mode == 56) {  // per-tile timeline (scripts/trace_tiles.py): its own buffer, slots as in CSVSIMD_TRACE
+        HIP_TRY(hipMalloc((void**)&d_trace, (32 + trace_tiles * 16) * 8));   // two 8-slot records per tile
+        HIP_TRY(hipMemset(d_trace, 0, (32 + trace_tiles * 16) * 8));
         L.scratch_prof = d_trace;
     }
 #endif
@@ -1531,12 +1531,12 @@ int csvsimd_stage1_time_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len,
     *avg_ms = (float)(total / iters);
 #ifdef CSVSIMD_DEV_PROBES
     if (d_trace) {
-        std::vector<uint64_t> h(32 + trace_tiles * 8);
+        std::vector<uint64_t> h(32 + trace_tiles * 16);   // the second records start 8 * num_tiles words in
         HIP_TRY(hipMemcpy(h.data(), d_trace, h.size() * 8, hipMemcpyDeviceToHost));
         (void)hipFree(d_trace);
         const char* path = getenv("CSVSIMD_PROBE_TRACE");
         if (FILE* f = fopen(path ? path : "/tmp/csvsimd_trace.bin", "wb")) {
-            fwrite(h.data() + 32, 8, trace_tiles * 8, f);
+            fwrite(h.data() + 32, 8, trace_tiles * 16, f);
             fclose(f);
         }
     }

@@ -1231,10 +1231,18 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
 #define CSVSIMD_TRACE(k, tid)                                                                          \
     if ((DBG & 32) && w == 0 && lane == 0 && (tid) < args.num_tiles)                                   \
         args.prof[32 + (u64)(tid) * 8 + (k)] = __builtin_amdgcn_s_memrealtime();
+    // second record per tile, behind the first ones (args.prof + 32 + 8 * num_tiles): stamps of the iteration that RESOLVES
+    // the tile — k = 0 loop top, 1 past barrier A, 2 wave 0's speculative scatter done, 3 look-back window landed, 4 the
+    // last wave's scatter done (arrives at barrier B), 5 the last wave past barrier B, 6 the last wave's stores issued,
+    // 7 wave 0 about to flush
+#define CSVSIMD_TRACEX(k, tid, wave, value)                                                            \
+    if ((DBG & 32) && w == (u32)(wave) && lane == 0 && (tid) < args.num_tiles)                         \
+        args.prof[32 + ((u64)args.num_tiles + (u64)(tid)) * 8 + (k)] = (value);
     if (DBG & 8) stamp = __builtin_amdgcn_s_memrealtime();
 #else
 #define CSVSIMD_STAMP(k)
 #define CSVSIMD_TRACE(k, tid)
+#define CSVSIMD_TRACEX(k, tid, wave, value)
 #endif
 
     // the physical CU this workgroup runs on (fixed for its lifetime): XCC id x the cu/sh/se bits of HW_ID
@@ -1424,6 +1432,10 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
             scatter_span_spec(held, lane, spec_state, reinterpret_cast<unsigned short*>(s_stage[w]));
             spec_done = true;
         }
+        if (have_held) {
+            CSVSIMD_TRACEX(2, held_tile, 0, __builtin_amdgcn_s_memrealtime())
+            CSVSIMD_TRACEX(4, held_tile, kWaves - 1, __builtin_amdgcn_s_memrealtime())
+        }
         if (w == 0 && have_held) {
             u32 pin = 0;
             u64 base = 0;
@@ -1464,6 +1476,9 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
             u32* const s6 = reinterpret_cast<u32*>(&args.prof[32 + (u64)held_tile * 8 + 6]);
             u32* const s7 = reinterpret_cast<u32*>(&args.prof[32 + (u64)held_tile * 8 + 7]);
             const u32 d_top = (u32)(trace_t - trace_top), d_cnt = (u32)(trace_a - trace_t), d_land = (u32)(trace_landed - trace_a);
+            CSVSIMD_TRACEX(0, held_tile, 0, trace_top)
+            CSVSIMD_TRACEX(1, held_tile, 0, trace_a)
+            CSVSIMD_TRACEX(3, held_tile, 0, trace_landed)
             s6[1] = (d_top > 0xffffu ? 0xffffu : d_top) | ((d_cnt > 0xffffu ? 0xffffu : d_cnt) << 16);
             s7[1] = ((d_land > 0xfffu ? 0xfffu : d_land) << 20) | ((trace_ws >> 16 > 15u ? 15u : trace_ws >> 16) << 16) | (trace_ws & 0xffffu);
         }
@@ -1471,6 +1486,7 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
         wg_barrier();     // barrier B
         CSVSIMD_STAMP(4)
         if (have_held) { CSVSIMD_TRACE(4, held_tile) }
+        if (have_held) { CSVSIMD_TRACEX(5, held_tile, kWaves - 1, __builtin_amdgcn_s_memrealtime()) }
         if (EMIT && have_held) {
             // pacing knob, 0 by default since the per-CU token: a pause between barrier B and the flush
             for (u32 z = 0; z < args.emit_delay; ++z) __builtin_amdgcn_s_sleep(10);
@@ -1490,6 +1506,7 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
                 e_first = it->first_tile;
             }
             const u64 span0 = (u64)(held_tile - e_first) * kTileBytes + (u64)w * kSpanBytes;
+            CSVSIMD_TRACEX(7, held_tile, 0, __builtin_amdgcn_s_memrealtime())
             if (spec_done && pin == (held_agg.b > held_agg.a ? 1u : 0u)) {
                 // the guess was right: the window already holds the span's entries, only the stores are left
                 wave_lds_fence();
@@ -1509,6 +1526,7 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
             }
         }
         if (have_held) { CSVSIMD_TRACE(5, held_tile) }
+        if (have_held) { CSVSIMD_TRACEX(6, held_tile, kWaves - 1, __builtin_amdgcn_s_memrealtime()) }
 #ifdef CSVSIMD_DEV_PROBES
         if ((DBG & 32) && w == 0 && lane == 0 && have_cur) {
             // lower halves only: the upper halves belong to the iteration that resolves this tile (above)
@@ -1555,6 +1573,7 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
 #endif
 #undef CSVSIMD_STAMP
 #undef CSVSIMD_TRACE
+#undef CSVSIMD_TRACEX
 
     // ---- this workgroup is done; the last one to get here completes the launch --------------------
     if (w != 0) return;
@@ -1911,6 +1930,7 @@ hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream) {
     CSVSIMD_PROBE_LAUNCH(16, true)
     CSVSIMD_PROBE_LAUNCH(8, true)
     CSVSIMD_PROBE_LAUNCH(40, true)
+    CSVSIMD_PROBE_LAUNCH(56, true)   // the timeline of a launch whose emit phases drop their tape stores
     CSVSIMD_PROBE_LAUNCH(8, false)
 #endif
     if (launched) {

@@ -22,11 +22,12 @@ dres = torch.zeros(8, dtype=torch.int64, device="cuda:0")
 ctx.reserve(n)
 s = torch.cuda.current_stream().cuda_stream
 path = os.environ.setdefault("CSVSIMD_PROBE_TRACE", "/tmp/csvsimd_trace.bin")
-os.environ["CSVSIMD_PROBE_MODE"] = "40"
+os.environ.setdefault("CSVSIMD_PROBE_MODE", "40")   # 56: the same launch without its tape stores
 ms = ctx.stage1_time_device(dbuf.data_ptr(), n, dtape.data_ptr(), cap, dres.data_ptr(), s, 2, 3)
 tr = np.fromfile(path, dtype=np.uint64).reshape(-1, 8)
 T = pkg.tile_bytes()
 nt = (n + T - 1) // T
+xr = tr[nt: 2 * nt].astype(np.float64)   # second record per tile: stamps of the iteration that resolves it
 tr = tr[:nt].astype(np.float64)
 t0 = tr[:, 0].min()
 us = (tr[:, :6] - t0) / 100.0          # s_memrealtime ticks at 100 MHz
@@ -104,3 +105,33 @@ for p_ in range(int(pos.max()) + 1):
         continue
     print(f"   {p_:3d} {np.median(it_top[m]):7.2f} {np.median(it_cnt[m]):6.2f} {np.median(it_land[m]):8.2f} "
           f"{np.median(it_win[m]):8.1f} {np.median(it_spin[m]):6.1f}   (max windows {it_win[m].max()}, max spins {it_spin[m].max()})")
+
+# the resolving iteration in absolute stamps (second record): where does a tile's time go between its barrier A and its
+# last store?  columns relative to the launch's first ticket
+xs = (xr - t0) / 100.0
+ok = xr[:, 0] > 0
+print("resolving iteration, medians by position (us since launch start):")
+print("  pos |  A(count)  top      A'       w0 scattered  landed   resolved | w7 scattered  B(w0)    B(w7)  | w0 flush begins  w0 stores issued  w7 stores issued")
+for p_ in range(int(pos.max()) + 1):
+    m = (pos == p_) & ok
+    if m.sum() == 0:
+        continue
+    md = lambda a: np.median(a[m])
+    print(f"  {p_:3d} | {md(us[:, 2]):8.1f} {md(xs[:, 0]):8.1f} {md(xs[:, 1]):8.1f} {md(xs[:, 2]):10.1f} {md(xs[:, 3]):10.1f} {md(us[:, 3]):9.1f} |"
+          f" {md(xs[:, 4]):10.1f} {md(us[:, 4]):9.1f} {md(xs[:, 5]):8.1f} | {md(xs[:, 7]):12.1f} {md(us[:, 5]):16.1f} {md(xs[:, 6]):16.1f}")
+print("the same for the twelve tiles whose stores are issued last:")
+for i in np.argsort(np.maximum(us[:, 5], xs[:, 6]))[-12:]:
+    print(f"  tile {int(i):5d} wg {int(blk[i]):3d} pos {int(pos[i])} | {us[i, 2]:8.1f} {xs[i, 0]:8.1f} {xs[i, 1]:8.1f} {xs[i, 2]:10.1f} {xs[i, 3]:10.1f} {us[i, 3]:9.1f} |"
+          f" {xs[i, 4]:10.1f} {us[i, 4]:9.1f} {xs[i, 5]:8.1f} | {xs[i, 7]:12.1f} {us[i, 5]:16.1f} {xs[i, 6]:16.1f}")
+# durations of the pieces, all tiles vs the tiles resolved after the last count phase ended
+def piece(name, a, b, m):
+    d = (b - a)[m]
+    return f"{name} {np.median(d):.2f} / {np.percentile(d, 90):.2f}"
+for label, m in (("all tiles", ok), ("tiles resolved after the last count ended", ok & (us[:, 3] > cend))):
+    if m.sum() == 0:
+        continue
+    print(f"{label} ({int(m.sum())}), median / p90 us: " + "; ".join([
+        piece("A' -> w0 scattered", xs[:, 1], xs[:, 2], m), piece("w0 scattered -> landed", xs[:, 2], xs[:, 3], m),
+        piece("landed -> resolved", xs[:, 3], us[:, 3], m), piece("A' -> w7 scattered", xs[:, 1], xs[:, 4], m),
+        piece("resolved -> B", us[:, 3], us[:, 4], m), piece("B -> w0 flush begins", us[:, 4], xs[:, 7], m),
+        piece("w0 flush", xs[:, 7], us[:, 5], m), piece("B(w7) -> w7 stores issued", xs[:, 5], xs[:, 6], m)]))
