@@ -1217,8 +1217,14 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
     if (args.chain)  // chained launch: the state the previous chunk left (written by a launch earlier on this stream)
         inq_in = (u32)__builtin_amdgcn_readfirstlane(
                      (int)__hip_atomic_load(&args.chain->in_quote_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 1u;
-    // requested now, consumed after the first count phase (the load's latency hides behind it)
-    const u32 epoch_v = __hip_atomic_load(&args.ctl->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // A SCALAR load: the word was written by the previous launch's last workgroup (a kernel boundary in between) and is
+    // advanced again only when every workgroup of this launch is done.  As a vector load, its first use cost every wave
+    // an `s_waitcnt vmcnt(0)` behind barrier A in EVERY iteration (loads and stores share one in-order counter) — on
+    // wave 0 that is the acknowledgement of the token-release store, in front of the aggregate's publication: the tiles
+    // behind it resolved that much later.  +1.1 % on the 8-GiB shard (profiles/r03_ab_epoch.txt); a launch of one tile
+    // per workgroup pays the dependent scalar load once (+0.8 us).
+    typedef const __attribute__((address_space(4))) Control* ctl_cptr;
+    const u32 epoch_v = ((ctl_cptr)args.ctl)->epoch;
 
     RoundMasks held[kRounds];
     Desc held_agg = {0, 0, 0}, held_before = {0, 0, 0};
@@ -1403,7 +1409,7 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
         CSVSIMD_STAMP(2)
         CSVSIMD_TRACE(2, tile)
 
-        const u32 epoch = (u32)__builtin_amdgcn_readfirstlane((int)epoch_v) & kEpochMask;
+        const u32 epoch = epoch_v & kEpochMask;
         if (have_cur) {
             // ---- tile aggregate; this wave's entering state/offset relative to the tile ------
 #pragma unroll
@@ -1588,7 +1594,7 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
 
     // ---- this workgroup is done; the last one to get here completes the launch --------------------
     if (w != 0) return;
-    finish_launch<DIALECT, (DBG & 4) != 0, BATCH>(args, (u32)__builtin_amdgcn_readfirstlane((int)epoch_v) & kEpochMask, inq_in,
+    finish_launch<DIALECT, (DBG & 4) != 0, BATCH>(args, epoch_v & kEpochMask, inq_in,
                                            wg_tot, err,
                                            // the lane id again, from the execution mask: `lane` as derived from threadIdx.x
                                            // would otherwise have to survive the tile loop in a register the loop needs
