@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Icsv-simd_amd/csrc $EXTRA -S --cuda-device-only \
     csv-simd_amd/csrc/stage1_kernels.hip -o /tmp/spillcheck.s 2>/dev/null
-for k in "ILb1ELi0ELi0E" "ILb0ELi0ELi0E" "ILb1ELi0ELi1E" "ILb1ELi0ELi2E"; do
+for k in "ILb1ELi0ELi0ELb0E" "ILb0ELi0ELi0ELb0E" "ILb1ELi0ELi1ELb0E" "ILb1ELi0ELi2ELb0E" "ILb1ELi0ELi3ELb0E" "ILb1ELi0ELi0ELb1E"; do
   awk "/^_ZN7csvsimd13stage1_kernel${k}EEvNS_10KernelArgsE:/,/s_endpgm/" /tmp/spillcheck.s > /tmp/spillcheck_k.s
   first=$(grep -n "buffer_load_dwordx4.* lds" /tmp/spillcheck_k.s | head -1 | cut -d: -f1)
   last=$(grep -n "buffer_load_dwordx4.* lds" /tmp/spillcheck_k.s | tail -1 | cut -d: -f1)
