@@ -377,10 +377,11 @@ struct ColFreqEntry {  // == csvsimd_colfreq_entry
 // occupied slots -> dense entries; one output reservation per workgroup (a returning atomic on one word retires at
 // ~90 per us chip-wide)
 static constexpr u32 kCfPerThread = 8;
-__global__ __launch_bounds__(256) void colfreq_compact_kernel(const ColFreqSlot* __restrict__ table, u64 slots,
+static constexpr u32 kCfCompactThreads = 1024;  // 8192 slots per reservation: 512 of them for a 4 M-slot table (2048: 23 us of atomics alone)
+__global__ __launch_bounds__(kCfCompactThreads) void colfreq_compact_kernel(const ColFreqSlot* __restrict__ table, u64 slots,
                                                               u64 first_record, ColFreqEntry* __restrict__ out, u64 out_cap,
                                                               ColFreqStatus* __restrict__ status) {
-    __shared__ u32 s_wave[4];
+    __shared__ u32 s_wave[kCfCompactThreads / 64];
     __shared__ u64 s_base;
     const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     const u64 chunk = (u64)blockDim.x * kCfPerThread;
@@ -398,7 +399,8 @@ __global__ __launch_bounds__(256) void colfreq_compact_kernel(const ColFreqSlot*
         if (lane == 0) s_wave[w] = wave_total;
         __syncthreads();
         if (threadIdx.x == 0) {
-            const u32 tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+            u32 tot = 0;
+            for (u32 k = 0; k < kCfCompactThreads / 64; ++k) tot += s_wave[k];
             s_base = tot ? atomicAdd((unsigned long long*)&status->n_distinct, (unsigned long long)tot) : 0ull;
         }
         __syncthreads();
@@ -439,7 +441,8 @@ hipError_t launch_colfreq_insert(const void* d_col, const void* d_len, u64 n_row
 
 hipError_t launch_colfreq_compact(const void* d_table, u64 slots, u64 first_record, void* d_out, u64 out_cap,
                                   void* d_status, hipStream_t stream) {
-    hipLaunchKernelGGL(colfreq_compact_kernel, dim3(cgrid_for(slots, 256 * kCfPerThread, 4096)), dim3(256), 0, stream,
+    hipLaunchKernelGGL(colfreq_compact_kernel, dim3(cgrid_for(slots, kCfCompactThreads * kCfPerThread, 4096)),
+                       dim3(kCfCompactThreads), 0, stream,
                        (const ColFreqSlot*)d_table, slots, first_record, (ColFreqEntry*)d_out, out_cap,
                        (ColFreqStatus*)d_status);
     return hipGetLastError();
