@@ -314,7 +314,9 @@ __device__ __forceinline__ bool colfreq_global_insert(const ColView& c, ColFreqS
     return false;
 }
 
-__global__ __launch_bounds__(256) void colfreq_insert_kernel(const ColView c, ColFreqSlot* __restrict__ table, u64 mask,
+static constexpr u32 kCfInsertThreads = 1024;  // one LDS table, one flush per 8 192 records: a column of few values sends every
+                                               // workgroup to the same global slots, and accesses to one line retire one by one
+__global__ __launch_bounds__(kCfInsertThreads) void colfreq_insert_kernel(const ColView c, ColFreqSlot* __restrict__ table, u64 mask,
                                                              ColFreqStatus* __restrict__ status) {
     __shared__ u64 s_key[kCfLds];    // tag << 32 | (record - r0 of this workgroup) + 1
     __shared__ u32 s_count[kCfLds];
@@ -433,8 +435,8 @@ hipError_t launch_colfreq_insert(const void* d_col, const void* d_len, u64 n_row
                                  void* d_status, int n_cus, hipStream_t stream) {
     if (n_rows == 0) return hipSuccess;
     const ColView c = {(const uint8_t*)d_col, (const u32*)d_len, n_rows, stride};
-    const u32 grid = cgrid_for(n_rows, 2048, (u32)(n_cus > 0 ? n_cus : 256) * 8);
-    hipLaunchKernelGGL(colfreq_insert_kernel, dim3(grid), dim3(256), 0, stream, c, (ColFreqSlot*)d_table, slots - 1,
+    const u32 grid = cgrid_for(n_rows, 8 * kCfInsertThreads, (u32)(n_cus > 0 ? n_cus : 256) * 2);
+    hipLaunchKernelGGL(colfreq_insert_kernel, dim3(grid), dim3(kCfInsertThreads), 0, stream, c, (ColFreqSlot*)d_table, slots - 1,
                        (ColFreqStatus*)d_status);
     return hipGetLastError();
 }
