@@ -160,7 +160,8 @@ __device__ __forceinline__ bool global_insert(FreqSlot* table, u64 mask, u64 h, 
     return false;
 }
 
-__global__ __launch_bounds__(256) void freq_insert_kernel(const Column c, FreqSlot* __restrict__ table, u64 mask,
+static constexpr u32 kFreqInsertThreads = 1024;  // one LDS table and one flush per 8 192 rows (see colfreq_insert_kernel)
+__global__ __launch_bounds__(kFreqInsertThreads) void freq_insert_kernel(const Column c, FreqSlot* __restrict__ table, u64 mask,
                                                           FreqStatus* __restrict__ status, u64 seed) {
     __shared__ u64 s_hash[kLdsSlots];
     __shared__ u64 s_first[kLdsSlots];
@@ -479,9 +480,10 @@ hipError_t launch_freq_insert(const void* dbytes, const void* dindex, u64 first_
                               void* d_table, u64 slots, void* d_status, u64 seed, int n_cus, hipStream_t stream) {
     if (n_rows == 0) return hipSuccess;
     const Column c = make_column(dbytes, dindex, first_key, jump, n_rows, field);
-    // >= 2048 rows per workgroup so that the LDS pre-aggregation has something to aggregate
-    const u32 grid = grid_for(n_rows, 2048, (u32)(n_cus > 0 ? n_cus : 256) * 8);
-    hipLaunchKernelGGL(freq_insert_kernel, dim3(grid), dim3(256), 0, stream, c, (FreqSlot*)d_table, slots - 1,
+    // 8192 rows per workgroup: the LDS pre-aggregation has something to aggregate, and a column of few values — every
+    // workgroup flushes into the same global slots, and accesses to one line retire one by one — is flushed a quarter as often
+    const u32 grid = grid_for(n_rows, 8 * kFreqInsertThreads, (u32)(n_cus > 0 ? n_cus : 256) * 2);
+    hipLaunchKernelGGL(freq_insert_kernel, dim3(grid), dim3(kFreqInsertThreads), 0, stream, c, (FreqSlot*)d_table, slots - 1,
                        (FreqStatus*)d_status, seed);
     return hipGetLastError();
 }
