@@ -242,11 +242,12 @@ struct FreqEntry {  // == csvsimd_freq_entry: 32 bytes
 // ~90 per us chip-wide (measured: with one atomic per wave the 4 Mi-slot table of the bench took 0.8 ms, all of it
 // that word), so a workgroup reserves the room for kCompactPerThread x 256 slots with a single atomic.
 static constexpr u32 kCompactPerThread = 8;
-__global__ __launch_bounds__(256) void freq_compact_kernel(const FreqSlot* __restrict__ table, u64 slots,
+static constexpr u32 kCompactThreads = 1024;  // 8192 slots per reservation (2048: the 4 Mi-slot table's 2048 atomics alone were 23 us)
+__global__ __launch_bounds__(kCompactThreads) void freq_compact_kernel(const FreqSlot* __restrict__ table, u64 slots,
                                                            const u64* __restrict__ index, u64 jump, u32 field,
                                                            FreqEntry* __restrict__ out, u64 out_cap,
                                                            FreqStatus* __restrict__ status) {
-    __shared__ u32 s_wave[4];
+    __shared__ u32 s_wave[kCompactThreads / 64];
     __shared__ u64 s_base;
     const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     const u64 chunk = (u64)blockDim.x * kCompactPerThread;
@@ -264,7 +265,8 @@ __global__ __launch_bounds__(256) void freq_compact_kernel(const FreqSlot* __res
         if (lane == 0) s_wave[w] = wave_total;
         __syncthreads();
         if (threadIdx.x == 0) {
-            const u32 tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+            u32 tot = 0;
+            for (u32 k = 0; k < kCompactThreads / 64; ++k) tot += s_wave[k];
             s_base = tot ? atomicAdd((unsigned long long*)&status->n_distinct, (unsigned long long)tot) : 0ull;
         }
         __syncthreads();
@@ -499,7 +501,7 @@ hipError_t launch_freq_verify(const void* dbytes, const void* dindex, u64 first_
 
 hipError_t launch_freq_compact(const void* d_table, u64 slots, const void* dindex, u64 jump, u32 field, void* d_out,
                                u64 out_cap, void* d_status, hipStream_t stream) {
-    hipLaunchKernelGGL(freq_compact_kernel, dim3(grid_for(slots, 256 * kCompactPerThread, 4096)), dim3(256), 0, stream, (const FreqSlot*)d_table,
+    hipLaunchKernelGGL(freq_compact_kernel, dim3(grid_for(slots, kCompactThreads * kCompactPerThread, 4096)), dim3(kCompactThreads), 0, stream, (const FreqSlot*)d_table,
                        slots, (const u64*)dindex, jump, field, (FreqEntry*)d_out, out_cap, (FreqStatus*)d_status);
     return hipGetLastError();
 }
