@@ -439,7 +439,9 @@ def cpu_baseline_variants(oracle, host, width, budget_scale=1.0):
         return min(times), len(times), t_total
 
     try:
-        subprocess.run(["make", "-s", "-C", odir, "liboracle_native.so"], check=True, capture_output=True, timeout=120)
+        # -B: always rebuilt — the file is -march=native code, and a copy built on another machine (the repository travels
+        # with its built .so files) could hold instructions this host's CPU does not have
+        subprocess.run(["make", "-s", "-B", "-C", odir, "liboracle_native.so"], check=True, capture_output=True, timeout=120)
         nat = C.CDLL(os.path.join(odir, "liboracle_native.so"))
         nat.oracle_sse_read.restype = C.c_int
         nat.oracle_sse_read.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, u64p]
