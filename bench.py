@@ -82,7 +82,33 @@ def refuse_probe_environment(pkg):
         sys.exit("bench.py refuses a library built with -DCSVSIMD_DEV_PROBES")
 
 
+def self_launch_command(n_gpus, argv, port=None):
+    """`python bench.py --gpus N` without a launcher: the command line of the child that runs this file under
+    torch.distributed.run, one rank per GPU of this node (the same form the driver uses for N > 1)."""
+    if port is None:
+        import socket
+        with socket.socket() as s:      # a port nobody listens on right now
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_gpus)}",
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n_gpus, argv):
+    """Starts the N-rank job as a CHILD process and returns its exit code.  Called before this process has touched
+    the GPU in any way (no torch.cuda call, no library load): on this pool a process that has initialised the GPU must
+    not be replaced, and need not be — the child's rank 0 prints the JSON line on the stdout it inherits."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on these hosts
+    env.setdefault("OMP_NUM_THREADS", "1")               # what torchrun would set (and warn about) anyway
+    return subprocess.run(self_launch_command(n_gpus, argv), env=env).returncode
+
+
 PIPELINE_DEPTH = 2   # steps in flight: step i + 1 is enqueued before step i's records are read (see run_sharded)
+# sharded steps: the tail of step i (all-gather, stitch, re-emit, copy-out) runs on a second stream and completes while
+# step i + 1's stage-1 kernel drains, by which time step i + 2 must already be enqueued: three in flight
+PIPELINE_DEPTH_SHARDED = 3
 
 
 class ShardBench:
@@ -90,7 +116,7 @@ class ShardBench:
     file of world * n bytes (n = whole rows); with skew every interior cut moves `skew` bytes to the right,
     i.e. into the middle of a row ("deliberately misaligned variant")."""
 
-    def __init__(self, pkg, device, workload, shard_bytes, rank, world, skew=0, cuts=None):
+    def __init__(self, pkg, device, workload, shard_bytes, rank, world, skew=0, cuts=None, depth=PIPELINE_DEPTH):
         self.pkg, self.device, self.workload = pkg, device, workload
         cols, width, seed, q = pkg.WORKLOADS[workload]
         self.cols, self.width, self.seed, self.q = cols, width, seed, q
@@ -110,16 +136,26 @@ class ShardBench:
         self.cap = int(self.n // (width + 1) * (1.25 if q else 1.0)) + 1024
         # two tape buffers: consecutive steps alternate between them, as a caller that indexes batch after batch
         # would, so that a step can be enqueued while the previous step's tape is still being consumed
-        self.dtapes = [torch.empty(self.cap, dtype=torch.int64, device=device) for _ in range(PIPELINE_DEPTH)]
+        # (three for sharded steps, whose tails complete a step late: PIPELINE_DEPTH_SHARDED)
+        self.dtapes = [torch.empty(self.cap, dtype=torch.int64, device=device) for _ in range(depth)]
         self.dtape = self.dtapes[0]                       # what launch() writes and the verification reads
-        self.d_results = torch.zeros(PIPELINE_DEPTH, 8, dtype=torch.int64, device=device)
-        self.h_results = torch.zeros(PIPELINE_DEPTH, 8, dtype=torch.int64).pin_memory()
-        self.events = [torch.cuda.Event() for _ in range(PIPELINE_DEPTH)]
+        self.d_results = torch.zeros(depth, 8, dtype=torch.int64, device=device)
+        self.h_results = torch.zeros(depth, 8, dtype=torch.int64).pin_memory()
+        self.events = [torch.cuda.Event() for _ in range(depth)]
         self.d_result, self.h_result = self.d_results[0], self.h_results[0]
         self.h_words = self.h_results.numpy()             # the same pinned bytes, cheap to read per step
         self.ctx = pkg.Context(device.index)
         self.ctx.reserve(self.n)
+        self.ctx_tail = None    # sharded steps with an overlapped tail: the re-emit launch's own context (see reemit)
         torch.cuda.synchronize(device)
+
+    def tail_context(self):
+        """The re-emit launch of step i runs beside the first pass of step i + 1: it needs its own scratch (look-back
+        words, ticket, epoch), i.e. its own context."""
+        if self.ctx_tail is None:
+            self.ctx_tail = self.pkg.Context(self.device.index)
+            self.ctx_tail.reserve(self.n)
+        return self.ctx_tail
 
     def stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -128,6 +164,9 @@ class ShardBench:
         """Gives the device memory back (the legs of a run recycle HBM one after the other)."""
         torch.cuda.synchronize(self.device)
         self.dbuf = self.dtape = self.dtapes = None
+        if self.ctx_tail is not None:
+            self.ctx_tail.close()
+            self.ctx_tail = None
         torch.cuda.empty_cache()
 
     def launch(self, in_quote_in, d_result=None):
@@ -136,9 +175,9 @@ class ShardBench:
         self.ctx.stage1_index_device_async(self.dbuf.data_ptr(), self.n, self.lo, in_quote_in,
                                            self.dtape.data_ptr(), self.cap, d_result.data_ptr(), self.stream())
 
-    def reemit(self, d_stitch_ptr, d_result):
-        self.ctx.stage1_reemit_device_async(self.dbuf.data_ptr(), self.n, self.lo, d_stitch_ptr,
-                                            self.dtape.data_ptr(), self.cap, d_result.data_ptr(), self.stream())
+    def reemit(self, d_stitch_ptr, d_result, ctx=None):
+        (ctx or self.ctx).stage1_reemit_device_async(self.dbuf.data_ptr(), self.n, self.lo, d_stitch_ptr,
+                                                     self.dtape.data_ptr(), self.cap, d_result.data_ptr(), self.stream())
 
     def check(self, r):
         if r.error or r.count > self.cap:
@@ -762,9 +801,16 @@ def run_sharded(pkg, sb, device, dist_on, rehearsal, comm, steps, warmup):
     restores one step at a time.  (The native-RCCL entry point is one blocking C call per step: not pipelined.)"""
     from csv_simd_amd import sharded
     state = {}
-    depth = PIPELINE_DEPTH if os.environ.get("CSVSIMD_BENCH_PIPELINE", "1") != "0" and comm is None else 1
-    stepper = (sharded.ShardedStep(device, gather_via_host=rehearsal, depth=depth)
+    pipelined = os.environ.get("CSVSIMD_BENCH_PIPELINE", "1") != "0" and comm is None
+    # CSVSIMD_BENCH_TAIL_OVERLAP=0: the sharded step's tail in stream order behind its first pass, as in round 3
+    overlap = pipelined and dist_on and os.environ.get("CSVSIMD_BENCH_TAIL_OVERLAP", "1") != "0"
+    depth = min(len(sb.dtapes), PIPELINE_DEPTH_SHARDED if overlap else PIPELINE_DEPTH) if pipelined else 1
+    overlap = overlap and depth >= PIPELINE_DEPTH_SHARDED
+    stepper = (sharded.ShardedStep(device, gather_via_host=rehearsal, depth=depth, overlap_tail=overlap)
                if (dist_on and comm is None) else None)
+    ctx_re = sb.tail_context() if overlap else None
+    state["tail"] = ("all-gather, stitch kernel, re-emit launch and copy-out on a second stream (the re-emit in its own "
+                     "context): they overlap the next step's first pass" if overlap else "in stream order behind the first pass")
     # rank 0 knows how the file starts; every other rank lets the kernel choose the entering state its first eight tiles speak
     # for (CSVSIMD_ENTER_GUESS) — only a rank that chose wrong re-emits.  CSVSIMD_BENCH_NO_GUESS=1: speculate "outside"
     # everywhere, as round 1 did (then every rank that really starts inside a string re-emits).
@@ -780,7 +826,7 @@ def run_sharded(pkg, sb, device, dist_on, rehearsal, comm, steps, warmup):
             d_res = stepper.slots[slot].d_result
             sb.use_slot(slot)
             tape = sb.dtape   # bound now: the re-emit must hit the same buffer as the speculative pass
-            stepper.enqueue(lambda inq: sb.launch(inq, d_res), lambda p: sb.reemit(p, d_res), slot=slot,
+            stepper.enqueue(lambda inq: sb.launch(inq, d_res), lambda p: sb.reemit(p, d_res, ctx_re), slot=slot,
                             first_state=first_state)
             assert sb.dtape is tape
         else:
@@ -896,9 +942,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: this process becomes the launcher.  Nothing has touched the GPU yet (importing torch does not),
+        # so the ranks start as ordinary children; their rank 0 prints the line, this process relays the exit code.
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched by torch.distributed.run (one rank per GPU)")
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the product path has no CPU fallback")
@@ -937,7 +985,8 @@ def main():
     # `world` contiguous shards — N = 1 indexes the whole of BASELINE config 4 (64 GiB: 64 + 16 GiB of tape fit one
     # 288 GB GPU), N = 8 takes 8 GiB each: the same file getting faster, not more bytes.
     shard_bytes = int(args.total_gib * 2**30) // world if strong else int(args.gib_per_gpu * 2**30)
-    sb = ShardBench(pkg, device, args.workload, shard_bytes, rank, world, args.skew)
+    sb_depth = PIPELINE_DEPTH_SHARDED if (dist_on and not args.native_rccl) else PIPELINE_DEPTH
+    sb = ShardBench(pkg, device, args.workload, shard_bytes, rank, world, args.skew, depth=sb_depth)
 
     comm = None
     if dist_on and args.native_rccl:
@@ -1016,7 +1065,8 @@ def main():
                                   if strong else " (BASELINE config 4's per-GPU shard shape)"),
                    "bytes_per_gpu": sb.n, "total_bytes": total_bytes, "tape_entries": int(state["total"]),
                    "skew": args.skew,
-                   "steps_in_flight": state["pipeline_depth"],   # 2: step i+1 enqueued before step i's record is read
+                   "steps_in_flight": state["pipeline_depth"],   # step i+1 (sharded: and i+2) enqueued before step i's record is read
+                   "sharded_step_tail": state["tail"] if dist_on else None,
                    "first_pass": state["first_pass"] if world > 1 else "one rank: the file's entering state is known",
                    "rccl_world": dist.get_world_size() if (dist_on and backend == "nccl") else None,
                    "collective_world": dist.get_world_size() if dist_on else None,   # ranks the process group reports
@@ -1039,7 +1089,7 @@ def main():
     if not args.no_q10_check and args.workload == "64x31_noquote" and not args.no_verify and not strong:
         sb.release()
         cuts = mid_row_cuts(oracle, pkg, "64x31_q10", shard_bytes, world)
-        sbq = ShardBench(pkg, device, "64x31_q10", shard_bytes, rank, world, cuts=cuts)
+        sbq = ShardBench(pkg, device, "64x31_q10", shard_bytes, rank, world, cuts=cuts, depth=sb_depth)
         k = max(3, min(args.steps, 5))
         dtq, stq = run_sharded(pkg, sbq, device, dist_on, rehearsal, comm, k, 1)
         vq = verify_everything(oracle, sbq, stq, dist_on, rank, world)
@@ -1070,7 +1120,7 @@ def main():
                                                    "main leg's shards"}
         else:
             sb.release()
-            sbs = ShardBench(pkg, device, args.workload, strong_total // world, rank, world)
+            sbs = ShardBench(pkg, device, args.workload, strong_total // world, rank, world, depth=sb_depth)
             k = max(3, min(args.steps, 5))
             dts, sts = run_sharded(pkg, sbs, device, dist_on, rehearsal, comm, k, 1)
             vs = verify_everything(oracle, sbs, sts, dist_on, rank, world)

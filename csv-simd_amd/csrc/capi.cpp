@@ -50,6 +50,34 @@ int fail_hip(hipError_t e, const char* what) {
         if (_e != hipSuccess) return fail_hip(_e, #expr);     \
     } while (0)
 
+// The calling thread's current HIP device is the CALLER's state (torch.cuda.current_device() in a torch process): an
+// entry point that needs another device current — a context's — switches for its own duration only and restores the
+// caller's on every exit path.  Nothing happens when the device is already the right one (two thread-local reads).
+class ScopedDevice {
+public:
+    explicit ScopedDevice(int device) {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) cur = -1;
+        if (cur != device) {
+            err_ = hipSetDevice(device);
+            if (err_ == hipSuccess) prev_ = cur;
+        }
+    }
+    ~ScopedDevice() {
+        if (prev_ >= 0) (void)hipSetDevice(prev_);
+    }
+    ScopedDevice(const ScopedDevice&) = delete;
+    ScopedDevice& operator=(const ScopedDevice&) = delete;
+    hipError_t error() const { return err_; }
+
+private:
+    int prev_ = -1;
+    hipError_t err_ = hipSuccess;
+};
+#define WITH_DEVICE_OF(ctx_)                      \
+    ScopedDevice scoped_device_((ctx_)->device);  \
+    HIP_TRY(scoped_device_.error())
+
 // Streaming copy for the ingest pipeline's slices: 4 MiB per thread is below the size at which glibc's memcpy switches
 // to non-temporal stores, so memcpy reads the DESTINATION lines too (read-for-ownership) — a third of the memory
 // traffic of a copy whose destination nobody on the CPU is going to read (the DMA engine reads the staging slot, the
@@ -288,7 +316,8 @@ int csvsimd_ctx_create(int device, csvsimd_ctx** out) {
         return CSVSIMD_ERR_NO_DEVICE;
     }
     if (device < 0 || device >= n) return CSVSIMD_ERR_INVALID_ARG;
-    HIP_TRY(hipSetDevice(device));
+    ScopedDevice scoped_device_(device);  // the caller's current device is restored on every way out
+    HIP_TRY(scoped_device_.error());
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     std::unique_ptr<csvsimd_ctx> ctx(new (std::nothrow) csvsimd_ctx);
@@ -311,7 +340,7 @@ int csvsimd_ctx_create(int device, csvsimd_ctx** out) {
 
 void csvsimd_ctx_destroy(csvsimd_ctx* ctx) {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
+    ScopedDevice scoped_device_(ctx->device);
     (void)hipDeviceSynchronize();  // nothing of this context may still be in flight
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->d_result) (void)hipFree(ctx->d_result);
@@ -340,7 +369,7 @@ int csvsimd_ctx_reserve(csvsimd_ctx* ctx, uint64_t max_len) {
     if (!ctx) return CSVSIMD_ERR_INVALID_ARG;
     const uint64_t need = csvsimd::Stage1Launch::scratch_bytes_for(max_len);
     if (need <= ctx->scratch_bytes) return CSVSIMD_OK;
-    HIP_TRY(hipSetDevice(ctx->device));
+    WITH_DEVICE_OF(ctx);
     // every launch that may still use the old block has to finish first.  The stream of the latest launch is remembered,
     // but the caller may have destroyed it since (a dangling handle is not a guaranteed error), so this rare path
     // (a context is asked for a larger shard than ever before) waits for the whole device
@@ -399,6 +428,7 @@ static int stage1_async_impl(csvsimd_ctx* ctx, const csvsimd_dialect* dialect, c
     if (len >= (1ull << 39)) return CSVSIMD_ERR_INVALID_ARG;
     if (((uintptr_t)dtape & 7) || ((uintptr_t)d_result & 15)) return CSVSIMD_ERR_INVALID_ARG;
     if (dialect_check(dialect) != CSVSIMD_OK || in_quote_in > CSVSIMD_ENTER_GUESS) return CSVSIMD_ERR_INVALID_ARG;
+    WITH_DEVICE_OF(ctx);  // hip_stream must belong to the context's device; the caller's current device may be another
     if (csvsimd::Stage1Launch::scratch_bytes_for(len) > ctx->scratch_bytes) {
         const int rc = csvsimd_ctx_reserve(ctx, len);  // allocates + synchronises: not capturable
         if (rc != CSVSIMD_OK) return rc;
@@ -484,7 +514,7 @@ int csvsimd_stage1_index_batch_device_async(csvsimd_ctx* ctx, const csvsimd_batc
         tiles += it.len ? (t.hi + CSVSIMD_TILE_BYTES - 1) / CSVSIMD_TILE_BYTES : 0;
         if (tiles >= (1ull << 31)) return CSVSIMD_ERR_INVALID_ARG;
     }
-    HIP_TRY(hipSetDevice(ctx->device));
+    WITH_DEVICE_OF(ctx);
     // scratch: one descriptor word per tile of the whole batch (allocates + synchronises only when it has to grow)
     int rc = csvsimd_ctx_reserve(ctx, tiles * CSVSIMD_TILE_BYTES);
     if (rc != CSVSIMD_OK) return rc;
@@ -532,6 +562,7 @@ int csvsimd_stage1_index_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len
                                 uint32_t in_quote_in, void* dtape, uint64_t tape_cap,
                                 csvsimd_shard_result* result, void* hip_stream) {
     if (!ctx || !result) return CSVSIMD_ERR_INVALID_ARG;
+    WITH_DEVICE_OF(ctx);
     int rc = csvsimd_stage1_index_device_async(ctx, dbuf, len, base_off, in_quote_in, dtape, tape_cap,
                                                ctx->d_result, hip_stream);
     if (rc != CSVSIMD_OK) return rc;
@@ -618,7 +649,7 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
                                   uint64_t* tape, uint64_t tape_cap, uint64_t* tape_len, uint32_t* in_quote_out) {
     if (!ctx || (len && !buf) || (!tape && tape_cap) || !tape_len) return CSVSIMD_ERR_INVALID_ARG;
     if (dialect_check(dialect) != CSVSIMD_OK) return CSVSIMD_ERR_INVALID_ARG;
-    HIP_TRY(hipSetDevice(ctx->device));
+    WITH_DEVICE_OF(ctx);
     int rc = pipe_setup(ctx);
     if (rc != CSVSIMD_OK) return rc;
     // Chunk plan.  The slots hold up to 32 MiB.  A large file ramps up (4, 8, 16 MiB, then 32) and down (..., 16, 8):
@@ -852,7 +883,7 @@ namespace {
 // (two pinned staging slots, the context's own H2D stream), then the first stage-1 pass and its record
 int multi_feed_and_index(csvsimd_multi_shard* sh, const uint8_t* buf, uint32_t in_quote_in) {
     csvsimd_ctx* ctx = sh->ctx;
-    HIP_TRY(hipSetDevice(ctx->device));
+    WITH_DEVICE_OF(ctx);  // (shard 0 runs on the CALLER's thread: its current device is put back)
     int rc = pipe_setup(ctx);
     if (rc != CSVSIMD_OK) return rc;
     const uint64_t n = sh->end - sh->begin;
@@ -928,7 +959,7 @@ int csvsimd_stage1_index_multi(const uint8_t* buf, uint64_t len, csvsimd_multi_s
         if (rc != CSVSIMD_OK) return rc;
         if (sh.stitch.error) { g_last_error = "stage1 kernel: look-back spin bound hit"; return CSVSIMD_ERR_INTERNAL; }
         if (sh.stitch.reemit) {
-            HIP_TRY(hipSetDevice(sh.ctx->device));
+            WITH_DEVICE_OF(sh.ctx);
             rc = csvsimd_stage1_index_device(sh.ctx, sh.dbuf, sh.end - sh.begin, sh.begin, sh.stitch.in_quote_in, sh.dtape,
                                              sh.tape_cap, &sh.result, sh.ctx->pipe_stream);
             if (rc != CSVSIMD_OK && rc != CSVSIMD_ERR_TAPE_CAPACITY) return rc;
@@ -1227,6 +1258,7 @@ int csvsimd_column_frequency_device(csvsimd_ctx* ctx, const void* dbytes, const 
     int rc = tape_shape(index_len, field_cnt, new_line, &row_size, &record_cnt);
     if (rc != CSVSIMD_OK) return rc;
     if (field_idx >= field_cnt) return CSVSIMD_ERR_INVALID_ARG;
+    WITH_DEVICE_OF(ctx);
     std::vector<uint64_t> rows(n_chunks);
     for (uint32_t i = 0; i < n_chunks; ++i)
         if ((rc = chunk_rows(&chunks[i], index_len, row_size, &rows[i])) != CSVSIMD_OK) return rc;
@@ -1274,6 +1306,7 @@ int csvsimd_column_search_device(csvsimd_ctx* ctx, const void* dbytes, uint64_t 
     if (field_idx >= field_cnt || (n && (!d_bitmap || ((uintptr_t)d_bitmap & 7)))) return CSVSIMD_ERR_INVALID_ARG;
     *n_matches = 0;
     if (n == 0) return CSVSIMD_OK;
+    WITH_DEVICE_OF(ctx);
     hipStream_t s = (hipStream_t)hip_stream;
     // the needle and the match counter live in the context's small device block: [0, 8) counter, [64, 64 + 264) needle
     HIP_TRY(hipMemsetAsync(ctx->d_small, 0, 8, s));
@@ -1325,6 +1358,7 @@ int csvsimd_chunk_to_columns_device(csvsimd_ctx* ctx, const void* dbytes, uint64
     if (!fields && n_fields > field_cnt) return CSVSIMD_ERR_INVALID_ARG;
     *n_records = n;
     if (n == 0) return CSVSIMD_OK;
+    WITH_DEVICE_OF(ctx);
     hipStream_t s = (hipStream_t)hip_stream;
     void* d_fields = nullptr;
     if (fields) {
@@ -1355,6 +1389,7 @@ int csvsimd_columnar_frequency_device(csvsimd_ctx* ctx, const void* d_col, const
         n_records >= 0xffffffffull)
         return CSVSIMD_ERR_INVALID_ARG;
     static_assert(sizeof(csvsimd_colfreq_status) == 32 && sizeof(csvsimd_colfreq_entry) == 16, "layouts shared with the kernels");
+    WITH_DEVICE_OF(ctx);
     hipStream_t s = (hipStream_t)hip_stream;
     void* d_status = (char*)d_scratch + table_slots * 16;
     HIP_TRY(hipMemsetAsync(d_scratch, 0, table_slots * 16 + 64, s));
@@ -1381,6 +1416,7 @@ int csvsimd_columnar_search_device(csvsimd_ctx* ctx, const void* d_col, const vo
         return CSVSIMD_ERR_INVALID_ARG;
     *n_matches = 0;
     if (n_records == 0) return CSVSIMD_OK;
+    WITH_DEVICE_OF(ctx);
     hipStream_t s = (hipStream_t)hip_stream;
     uint64_t h[2] = {0, 0};  // matches, records longer than the stride
     HIP_TRY(hipMemsetAsync(ctx->d_small, 0, 16, s));
@@ -1405,6 +1441,7 @@ int csvsimd_trim_spans_device(const void* dbytes, void* d_begin, void* d_end, ui
 int csvsimd_utf8_validate_device_async(csvsimd_ctx* ctx, const void* dbuf, uint64_t len, void* d_result,
                                        void* hip_stream) {
     if (!ctx || !d_result || (len && !dbuf) || ((uintptr_t)d_result & 7)) return CSVSIMD_ERR_INVALID_ARG;
+    WITH_DEVICE_OF(ctx);
     HIP_TRY(csvsimd::launch_utf8_validate(dbuf, len, d_result, ctx->n_cus, (hipStream_t)hip_stream));
     return CSVSIMD_OK;
 }
@@ -1413,6 +1450,7 @@ int csvsimd_utf8_validate_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t le
                                  void* hip_stream) {
     if (!ctx || !result) return CSVSIMD_ERR_INVALID_ARG;
     static_assert(sizeof(csvsimd_utf8_result) <= sizeof(csvsimd_shard_result), "reuses the context's result slot");
+    WITH_DEVICE_OF(ctx);
     const int rc = csvsimd_utf8_validate_device_async(ctx, dbuf, len, ctx->d_result, hip_stream);
     if (rc != CSVSIMD_OK) return rc;
     HIP_TRY(hipMemcpyAsync(result, ctx->d_result, sizeof(*result), hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
@@ -1424,7 +1462,8 @@ int csvsimd_selftest_device(int device) {
     const int n = csvsimd_device_count();
     if (n <= 0) return CSVSIMD_ERR_NO_DEVICE;
     if (device < 0 || device >= n) return CSVSIMD_ERR_INVALID_ARG;
-    HIP_TRY(hipSetDevice(device));
+    ScopedDevice scoped_device_(device);
+    HIP_TRY(scoped_device_.error());
     uint32_t* d = nullptr;
     HIP_TRY(hipMalloc((void**)&d, 8));
     HIP_TRY(hipMemset(d, 0, 8));
@@ -1465,6 +1504,7 @@ int csvsimd_stage1_time_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len,
                                void* d_result, void* hip_stream, int warmup, int iters, float* avg_ms) {
     return csvsimd_guarded([&]() -> int {
     if (!ctx || !avg_ms || iters <= 0 || iters > 4096 || !d_result || !len) return CSVSIMD_ERR_INVALID_ARG;
+    WITH_DEVICE_OF(ctx);
     hipStream_t s = (hipStream_t)hip_stream;
     int rc = csvsimd_ctx_reserve(ctx, len);
     if (rc != CSVSIMD_OK) return rc;
@@ -1580,6 +1620,7 @@ int csvsimd_hbm_probe_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len, v
     if ((write_div != 0 && write_div != 4 && write_div != 25) || blocks_per_cu < 1 || blocks_per_cu > 8)
         return CSVSIMD_ERR_INVALID_ARG;
     if (!dout || ((uintptr_t)dout & 15) || len < 131072) return CSVSIMD_ERR_INVALID_ARG;
+    WITH_DEVICE_OF(ctx);
     hipStream_t s = (hipStream_t)hip_stream;
     int rc = csvsimd_ctx_reserve(ctx, 1 << 20);  // the probe's ticket pair lives in the context's control block
     ctx->last_stream = s;
@@ -1607,6 +1648,7 @@ int csvsimd_copy_probe_device(csvsimd_ctx* ctx, const void* dsrc, void* ddst, ui
     return csvsimd_guarded([&]() -> int {
     if (!ctx || !dsrc || !ddst || !avg_ms || iters <= 0 || iters > 4096 || len < 16) return CSVSIMD_ERR_INVALID_ARG;
     if (mode < 0 || mode > 2 || ((uintptr_t)dsrc & 15) || ((uintptr_t)ddst & 15)) return CSVSIMD_ERR_INVALID_ARG;
+    WITH_DEVICE_OF(ctx);
     hipStream_t s = (hipStream_t)hip_stream;
     for (int i = 0; i < warmup; ++i) HIP_TRY(csvsimd::launch_copy_probe(dsrc, ddst, len, mode, s));
     EventBatch eb;

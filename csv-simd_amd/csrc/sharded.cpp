@@ -57,6 +57,17 @@ RcclApi& rccl() {
     return api;
 }
 
+// the caller's current HIP device is put back on every way out (capi.cpp: ScopedDevice)
+struct DeviceRestore {
+    int prev = -1;
+    DeviceRestore() {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    }
+    ~DeviceRestore() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
 }  // namespace
 
 struct csvsimd_comm {
@@ -92,6 +103,7 @@ int csvsimd_comm_create(const uint8_t id[CSVSIMD_COMM_ID_BYTES], int rank, int w
     *out = nullptr;
     RcclApi& api = rccl();
     if (!api.error.empty()) return CSVSIMD_ERR_RCCL;
+    DeviceRestore restore_;
     if (hipSetDevice(device) != hipSuccess) return CSVSIMD_ERR_HIP;
     csvsimd_comm* c = new (std::nothrow) csvsimd_comm;
     if (!c) return CSVSIMD_ERR_INVALID_STATE;
@@ -119,6 +131,7 @@ int csvsimd_comm_create(const uint8_t id[CSVSIMD_COMM_ID_BYTES], int rank, int w
 
 void csvsimd_comm_destroy(csvsimd_comm* c) {
     if (!c) return;
+    DeviceRestore restore_;
     (void)hipSetDevice(c->device);
     if (c->comm) (void)rccl().CommDestroy(c->comm);
     if (c->d_mine) (void)hipFree(c->d_mine);
@@ -144,6 +157,8 @@ int csvsimd_stage1_index_sharded(csvsimd_ctx* ctx, csvsimd_comm* c, const void* 
                                  csvsimd_shard_result* result, csvsimd_stitch* stitch, void* hip_stream) {
     return csvsimd_guarded([&]() -> int {
     if (!ctx || !c || !result || !stitch) return CSVSIMD_ERR_INVALID_ARG;
+    DeviceRestore restore_;
+    if (hipSetDevice(c->device) != hipSuccess) return CSVSIMD_ERR_HIP;
     hipStream_t st = (hipStream_t)hip_stream;
     int local = csvsimd_ctx_reserve(ctx, len);  // may allocate: never inside the stream-ordered part
     if (local == CSVSIMD_OK)

@@ -17,6 +17,7 @@ absolute offsets: concatenating the shards, after the sentinel 0, is the referen
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Callable, List, Tuple
 
 import torch
@@ -83,9 +84,11 @@ class _StepSlot:
         self.d_all = self.d_block[8 + STITCH_WORDS:]
         self.h_block = torch.zeros_like(self.d_block, device="cpu")
         self.event = None
+        self.first_done = None   # overlap_tail: the first pass has been enqueued on the caller's stream up to here
         if device.type == "cuda":
             self.h_block = self.h_block.pin_memory()
             self.event = torch.cuda.Event()
+            self.first_done = torch.cuda.Event()
         self.err = None
         self.pending = False
 
@@ -105,9 +108,17 @@ class ShardedStep:
     without waiting for the host, so with depth >= 2 the next step (another file, or the next batch of this one, into
     another tape buffer) can be enqueued before the previous one's records are read — the GPU never idles between
     steps.  Every rank must enqueue and collect in the same order (the all-gather is a collective).
+
+    overlap_tail: everything behind the first pass — all-gather, stitch kernel, re-emit launch, copy-out — is enqueued
+    on a SECOND stream that waits for the first pass only.  The caller's stream is free for the next step's first pass at
+    once; the tail (tens of microseconds of latencies, no bandwidth) runs beside it: in practice when that next pass
+    drains, a persistent stage-1 grid leaving no wave slot free before.  A step then completes one step late, so the
+    caller keeps depth >= 3 steps in flight; the re-emit launch must use ANOTHER context than the first pass (its
+    scratch would be shared with the next step's first pass otherwise) — reemit() is called with that stream current.
     """
 
-    def __init__(self, device: torch.device, group=None, gather_via_host: bool = False, depth: int = 1):
+    def __init__(self, device: torch.device, group=None, gather_via_host: bool = False, depth: int = 1,
+                 overlap_tail: bool = False):
         # gather_via_host: development rehearsal on a one-GPU box (several ranks share the card, the group is
         # gloo): the records make the trip through host memory; stitch kernel and re-emit launch are the real ones
         self.gather_via_host = gather_via_host
@@ -116,6 +127,7 @@ class ShardedStep:
         self.world = dist.get_world_size(group)
         self.device = device
         self.slots = [_StepSlot(device, self.world) for _ in range(max(1, depth))]
+        self.tail = torch.cuda.Stream(device) if (overlap_tail and device.type == "cuda") else None
         # slot 0 under the names a depth-1 caller uses
         s0 = self.slots[0]
         self.d_block, self.d_result, self.d_stitch, self.d_all, self.h_block = (s0.d_block, s0.d_result, s0.d_stitch,
@@ -147,23 +159,27 @@ class ShardedStep:
             sl.err = e
             sl.d_result.zero_()
             sl.d_result[4] = 1  # error flag set: every rank will report the failure
-        if self.gather_via_host:
-            h_all = torch.empty(8 * self.world, dtype=torch.int64)
-            dist.all_gather_into_tensor(h_all, sl.d_result.cpu(), group=self.group)
-            sl.d_all.copy_(h_all)
-        else:
-            dist.all_gather_into_tensor(sl.d_all, sl.d_result, group=self.group)
-        if rehearsal:
-            self.stitch_via_host(file_in_quote_in, slot)
-        else:
-            stream = torch.cuda.current_stream(self.device).cuda_stream
-            stitch_shards_device_async(sl.d_all.data_ptr(), self.world, self.rank, file_in_quote_in,
-                                       sl.d_stitch.data_ptr(), stream)
-        if sl.err is None:
-            reemit(sl.d_stitch.data_ptr())
-        sl.h_block.copy_(sl.d_block, non_blocking=True)
-        if sl.event is not None:
-            sl.event.record(torch.cuda.current_stream(self.device))
+        if self.tail is not None:
+            sl.first_done.record(torch.cuda.current_stream(self.device))
+            self.tail.wait_event(sl.first_done)
+        with (torch.cuda.stream(self.tail) if self.tail is not None else contextlib.nullcontext()):
+            if self.gather_via_host:
+                h_all = torch.empty(8 * self.world, dtype=torch.int64)
+                dist.all_gather_into_tensor(h_all, sl.d_result.cpu(), group=self.group)
+                sl.d_all.copy_(h_all)
+            else:
+                dist.all_gather_into_tensor(sl.d_all, sl.d_result, group=self.group)
+            if rehearsal:
+                self.stitch_via_host(file_in_quote_in, slot)
+            else:
+                stream = torch.cuda.current_stream(self.device).cuda_stream
+                stitch_shards_device_async(sl.d_all.data_ptr(), self.world, self.rank, file_in_quote_in,
+                                           sl.d_stitch.data_ptr(), stream)
+            if sl.err is None:
+                reemit(sl.d_stitch.data_ptr())
+            sl.h_block.copy_(sl.d_block, non_blocking=True)
+            if sl.event is not None:
+                sl.event.record(torch.cuda.current_stream(self.device))
         sl.pending = True
 
     def collect(self, slot: int = 0) -> Tuple[Stitch, ShardResult, List[ShardResult]]:

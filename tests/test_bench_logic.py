@@ -119,3 +119,45 @@ def test_cpu_baseline_variants_time_the_same_bytes(bench, pkg, oracle):
     assert v["cpu_baseline_mt"]["cores"] == bench.cpu_threads() >= 1
     assert v["cpu_baseline_mt"]["entries"] == v["ref_sse_1t_native"]["entries"] == v["scalar_1t"]["entries"] == base["entries"]
     assert all(v[k]["value"] > 0 for k in ("cpu_baseline_mt", "ref_sse_1t_native", "scalar_1t"))
+
+
+@pytest.mark.parametrize("n", [2, 4, 8])
+def test_self_launch_command(bench, n):
+    # `python bench.py --gpus N` (no launcher, the form the driver uses at N = 1) must become the driver's own N > 1
+    # form: torch.distributed.run, one node, N ranks, rendezvous on 127.0.0.1, the same arguments
+    argv = ["--gpus", str(n), "--steps", "7", "--warmup", "2"]
+    cmd = bench.self_launch_command(n, argv, port=29123)
+    assert cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and f"--nproc-per-node={n}" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29123"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == argv                       # the script, then exactly the caller's arguments
+    assert all(not a.startswith("--gpus") for a in cmd[:i])   # --gpus belongs to bench.py, not to the launcher
+    free = bench.self_launch_command(n, argv)        # no port given: a free one is picked
+    assert 1024 < int(free[free.index("--master-port") + 1]) < 65536
+
+
+@pytest.mark.parametrize("n", [2, 4, 8])
+def test_main_without_a_launcher_starts_the_ranks_as_a_child_before_any_gpu_call(bench, monkeypatch, n):
+    import torch
+    calls = []
+
+    def no_gpu(*a, **k):
+        raise AssertionError("the launching process must not touch the GPU")
+    monkeypatch.setattr(torch.cuda, "is_available", no_gpu)
+    monkeypatch.setattr(torch.cuda, "set_device", no_gpu)
+    monkeypatch.setattr(bench.graft, "load_package", no_gpu)
+    monkeypatch.setattr(bench, "self_launch", lambda k, argv: calls.append((k, list(argv))) or 7)
+    for v in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(v, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", str(n), "--steps", "3"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7                         # the child's exit code is this process's
+    assert calls == [(n, ["--gpus", str(n), "--steps", "3"])]
+
+
+def test_self_launch_relays_the_childs_exit_code(bench, monkeypatch):
+    # the real subprocess path, with a child that is not torchrun: `python -c "exit 5"`
+    monkeypatch.setattr(bench, "self_launch_command", lambda n, argv, port=None: [sys.executable, "-c", "raise SystemExit(5)"])
+    assert bench.self_launch(2, []) == 5

@@ -44,7 +44,12 @@ def test_one_host_buffer_to_g_shards(pkg, oracle, g):
     dbufs = [torch.zeros(max(e - b, 1), dtype=torch.uint8, device="cuda:0") for b, e in ranges]
     caps = [(e - b) + 8 for b, e in ranges]
     dtapes = [torch.full((c,), -1, dtype=torch.int64, device="cuda:0") for c in caps]
+    # the call works on the contexts' private streams: dbuf / dtape must be idle when it starts (include/csvsimd.h) —
+    # the fills above run on torch's stream
+    torch.cuda.synchronize()
+    dev_before = torch.cuda.current_device()
     sh = pkg.stage1_index_multi(d, ctxs, [t.data_ptr() for t in dbufs], [t.data_ptr() for t in dtapes], caps, 0)
+    assert torch.cuda.current_device() == dev_before          # the caller's current device is the caller's
     torch.cuda.synchronize()
     parts, base, state = [np.zeros(1, dtype=np.uint64)], 1, 0
     for i in range(g):
