@@ -967,6 +967,9 @@ def main():
         else:
             if "MASTER_ADDR" not in os.environ:   # CSVSIMD_BENCH_FORCE_DIST=1 without a launcher
                 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
+            # the collective's own stream (torch keeps one per communicator) on a high-priority hardware queue as well:
+            # on a queue it shares with the stage-1 launches its wait for the tail's event would hold those up
+            os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
             dist.init_process_group("nccl", device_id=device)
         dist.barrier()
     pkg = graft.load_package()

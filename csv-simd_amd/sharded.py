@@ -127,7 +127,12 @@ class ShardedStep:
         self.world = dist.get_world_size(group)
         self.device = device
         self.slots = [_StepSlot(device, self.world) for _ in range(max(1, depth))]
-        self.tail = torch.cuda.Stream(device) if (overlap_tail and device.type == "cuda") else None
+        # A HIGH-PRIORITY stream: HIP multiplexes a process's streams onto a few hardware queues (four by default), and
+        # two streams that share one are served in submission order — the tail of step i would simply run before the
+        # first pass of step i + 1 again (seen in round 4's first kernel trace: every kernel on one queue id).  Streams
+        # of another priority live on other hardware queues than the caller's, and the tail's few small kernels are
+        # dispatched ahead of a persistent grid's workgroups whenever a slot frees up.
+        self.tail = torch.cuda.Stream(device, priority=-1) if (overlap_tail and device.type == "cuda") else None
         # slot 0 under the names a depth-1 caller uses
         s0 = self.slots[0]
         self.d_block, self.d_result, self.d_stitch, self.d_all, self.h_block = (s0.d_block, s0.d_result, s0.d_stitch,
