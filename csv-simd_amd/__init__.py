@@ -122,6 +122,17 @@ class ColFreqStatus(C.Structure):
                 ("overflow", C.c_uint64)]
 
 
+class IngestPhases(C.Structure):
+    """csvsimd_ingest_phases: where the wall time of the thread's latest csvsimd_stage1_index call went (seconds)."""
+    _fields_ = [("bytes", C.c_uint64), ("chunks", C.c_uint64), ("host_threads", C.c_uint32), ("reserved", C.c_uint32),
+                ("wall", C.c_double), ("stage_copy", C.c_double), ("stage_wait", C.c_double), ("expand_copy", C.c_double),
+                ("submit", C.c_double), ("wait_staged", C.c_double), ("wait_record", C.c_double),
+                ("wait_expanded", C.c_double)]
+
+    def as_dict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_ if f != "reserved"}
+
+
 SEARCH_EQUALS, SEARCH_STARTS_WITH, SEARCH_CONTAINS = 0, 1, 2
 ABI_VERSION = 3   # what this binding was written against: checked when the library is loaded
 
@@ -160,6 +171,8 @@ _PROTOTYPES = {
     "csvsimd_stage1_bound": (C.c_int, [C.c_uint64, _u64p]),
     "csvsimd_stage1_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, _u64p,
                                        C.POINTER(C.c_uint32)]),
+    "csvsimd_ingest_chunk_plan": (C.c_int, [C.c_uint64, _u64p, C.c_uint64, _u64p]),
+    "csvsimd_ingest_last_phases": (C.c_int, [C.POINTER(IngestPhases)]),
     "csvsimd_stage1_index_batch_device_async": (C.c_int, [C.c_void_p, C.POINTER(BatchItem), C.c_uint32, C.c_void_p,
                                                           C.c_void_p]),
     "csvsimd_multi_shard_range": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, _u64p, _u64p]),
@@ -434,6 +447,22 @@ class Comm:
         _check(lib().csvsimd_stage1_index_sharded(ctx._h, self._h, dbuf, length, base_off, file_in_quote_in,
                                                   dtape or None, tape_cap, C.byref(r), C.byref(st), stream or None))
         return r, st
+
+
+def ingest_chunk_plan(length: int):
+    """The cuts csvsimd_stage1_index streams a buffer of `length` bytes in: [0, ..., length]."""
+    n = C.c_uint64()
+    lib().csvsimd_ingest_chunk_plan(length, None, 0, C.byref(n))
+    cuts = (C.c_uint64 * n.value)()
+    _check(lib().csvsimd_ingest_chunk_plan(length, cuts, n.value, C.byref(n)))
+    return list(cuts)
+
+
+def ingest_last_phases() -> dict:
+    """Phase times of this thread's latest host-buffer call (Context.read / read_into / create)."""
+    p = IngestPhases()
+    _check(lib().csvsimd_ingest_last_phases(C.byref(p)))
+    return p.as_dict()
 
 
 def multi_shard_range(length: int, n_shards: int, i: int) -> Tuple[int, int]:

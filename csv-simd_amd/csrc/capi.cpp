@@ -127,10 +127,12 @@ static void expand_streaming(uint64_t* dst, const uint32_t* src, size_t n, uint6
 // Host-side copies of the ingest pipeline (user buffer -> pinned staging, pinned 32-bit tape -> user tape).
 // One thread moves ~10-30 GB/s, less than the PCIe link it feeds, so the copies are sliced over a few
 // persistent workers (measured on the MI355X host: 22 -> 39 GiB/s host buffer to tape, NOTEBOOK.md).
+// Several threads may call copy() / expand() at once (round 4: the pipeline's staging thread and its expanding thread
+// do): every call counts its own slices down, the workers serve whatever slice is next.
 class CopyPool {
 public:
     explicit CopyPool(int workers) {
-        jobs_.reserve(64);  // copy() must not allocate once jobs are published
+        jobs_.reserve(128);  // copy() must not allocate once jobs are published
         try {
             for (int i = 0; i < workers; ++i) threads_.emplace_back([this] { run(); });
         } catch (...) {
@@ -142,10 +144,10 @@ public:
     }
     ~CopyPool() { shutdown(); }
     // synchronous: returns when all n bytes are in place
-    void copy(void* dst, const void* src, size_t n) { run_sliced(Job{(char*)dst, (const char*)src, n, 0, false}, 1); }
+    void copy(void* dst, const void* src, size_t n) { run_sliced(Job{(char*)dst, (const char*)src, n, 0, false, nullptr}, 1); }
     // synchronous: dst[i] = base + src[i] for i < n
     void expand(uint64_t* dst, const uint32_t* src, size_t n, uint64_t base) {
-        run_sliced(Job{(char*)dst, (const char*)src, n, base, true}, 4);
+        run_sliced(Job{(char*)dst, (const char*)src, n, base, true, nullptr}, 4);
     }
 
 private:
@@ -155,6 +157,7 @@ private:
         size_t n;  // bytes (copy) or entries (expand)
         uint64_t base;
         bool widen;
+        size_t* left;  // the issuing call's count of slices still out (guarded by m_)
     };
     static void execute(const Job& j) {
         if (j.widen) expand_streaming((uint64_t*)j.dst, (const uint32_t*)j.src, j.n, j.base);
@@ -171,13 +174,14 @@ private:
         }
         const size_t slice = (((whole.n / parts) + 4095) & ~(size_t)4095);  // items; a multiple of 4096 keeps every slice aligned
         const size_t dst_unit = whole.widen ? 8 : 1, src_unit = whole.widen ? 4 : 1;
+        size_t left = 0;  // lives on this frame until every slice of this call has been executed (the wait below)
         {
             std::lock_guard<std::mutex> g(m_);
-            if (jobs_.capacity() < parts) jobs_.reserve(parts);  // before anything is published: a throw here harms nobody
+            if (jobs_.capacity() < jobs_.size() + parts) jobs_.reserve(jobs_.size() + parts);  // before anything is published
             for (size_t off = slice; off < whole.n; off += slice) {
                 jobs_.push_back(Job{whole.dst + off * dst_unit, whole.src + off * src_unit, std::min(slice, whole.n - off),
-                                    whole.base, whole.widen});
-                ++pending_;
+                                    whole.base, whole.widen, &left});
+                ++left;
             }
         }
         cv_work_.notify_all();
@@ -185,7 +189,26 @@ private:
         first.n = std::min(slice, whole.n);
         execute(first);  // the calling thread takes the first slice
         std::unique_lock<std::mutex> g(m_);
-        cv_done_.wait(g, [this] { return pending_ == 0; });
+        // ... and, rather than sleep while slices of its own call are still queued, more of them
+        while (left != 0) {
+            bool mine = false;
+            Job j{};
+            for (size_t q = jobs_.size(); q-- > 0;)
+                if (jobs_[q].left == &left) {
+                    j = jobs_[q];
+                    jobs_.erase(jobs_.begin() + (std::ptrdiff_t)q);
+                    mine = true;
+                    break;
+                }
+            if (!mine) {
+                cv_done_.wait(g, [&left] { return left == 0; });
+                break;
+            }
+            g.unlock();
+            execute(j);
+            g.lock();
+            --left;
+        }
     }
     void shutdown() {
         {
@@ -203,13 +226,13 @@ private:
                 std::unique_lock<std::mutex> g(m_);
                 cv_work_.wait(g, [this] { return stop_ || !jobs_.empty(); });
                 if (jobs_.empty()) return;  // stop requested and nothing left
-                j = jobs_.back();
-                jobs_.pop_back();
+                j = jobs_.front();          // oldest first: the call that has waited longest
+                jobs_.erase(jobs_.begin());
             }
             execute(j);
             {
                 std::lock_guard<std::mutex> g(m_);
-                if (--pending_ == 0) cv_done_.notify_all();
+                if (--*j.left == 0) cv_done_.notify_all();
             }
         }
     }
@@ -217,7 +240,6 @@ private:
     std::mutex m_;
     std::condition_variable cv_work_, cv_done_;
     std::vector<Job> jobs_;
-    size_t pending_ = 0;
     bool stop_ = false;
 };
 
@@ -249,21 +271,22 @@ struct csvsimd_ctx {
     csvsimd_shard_result* d_result = nullptr;  // for the synchronous entry points
     void* d_small = nullptr;                   // 8 KiB: [0, 16) match / truncation counters, [64, 328) search needle,
                                                // [1024, 5120) field list of csvsimd_chunk_to_columns_device
-    // host-buffer path (csvsimd_stage1_index): two-slot pipeline, allocated on first use
+    // host-buffer path (csvsimd_stage1_index): kSlots-slot pipeline; every slot is allocated when a call first needs it
     static constexpr uint64_t kChunk = 32ull << 20;  // bytes per slot
-    bool pipe_ready = false;                   // every resource below exists
+    static constexpr int kSlots = 4;
     hipStream_t pipe_stream = nullptr;         // kernels + result records
-    hipStream_t in_stream = nullptr;           // H2D of input chunks (runs one chunk ahead of the kernels)
-    hipEvent_t ev_in[2] = {nullptr, nullptr};  // chunk has landed in d_in[k]
-    void* pin_in[2] = {nullptr, nullptr};     // pinned staging of the input chunk
-    void* d_in[2] = {nullptr, nullptr};
-    uint64_t* d_tape[2] = {nullptr, nullptr};  // device tape of a chunk (grown on demand)
-    uint64_t d_tape_entries[2] = {0, 0};
-    uint32_t* pin_out[2] = {nullptr, nullptr};  // pinned slot of a chunk's tape on its way back: 32-bit chunk-relative offsets
-    uint64_t pin_out_entries[2] = {0, 0};
-    csvsimd_shard_result* d_res[2] = {nullptr, nullptr};
-    csvsimd_shard_result* h_res = nullptr;     // pinned, 2 records
-    hipEvent_t ev_rec[2] = {nullptr, nullptr}; // result record of the slot's chunk has landed in h_res[k] (and its tape in pin_out[k])
+    hipStream_t in_stream = nullptr;           // H2D of input chunks (runs ahead of the kernels)
+    hipEvent_t ev_in[kSlots] = {};             // chunk has landed in d_in[k]
+    void* pin_in[kSlots] = {};                 // pinned staging of the input chunk
+    void* d_in[kSlots] = {};
+    uint64_t* d_tape[kSlots] = {};             // device tape of a chunk (grown on demand)
+    uint64_t d_tape_entries[kSlots] = {};
+    uint32_t* pin_out[kSlots] = {};            // pinned slot of a chunk's tape on its way back: 32-bit chunk-relative offsets
+    uint64_t pin_out_entries[kSlots] = {};
+    uint64_t slot_bytes[kSlots] = {};          // size of pin_in[k] / d_in[k]
+    csvsimd_shard_result* d_res[kSlots] = {};
+    csvsimd_shard_result* h_res = nullptr;     // pinned, kSlots records
+    hipEvent_t ev_rec[kSlots] = {};            // result record of the slot's chunk has landed in h_res[k] (and its tape in pin_out[k])
     std::unique_ptr<CopyPool> copier;         // host-side slices of the staging copies
     void* d_batch = nullptr;                  // csvsimd_stage1_index_batch_device_async: the buffers' table block
     size_t d_batch_bytes = 0;
@@ -350,7 +373,7 @@ void csvsimd_ctx_destroy(csvsimd_ctx* ctx) {
         if (ctx->pin_up[k]) (void)hipHostFree(ctx->pin_up[k]);
         if (ctx->ev_up[k]) (void)hipEventDestroy(ctx->ev_up[k]);
     }
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < csvsimd_ctx::kSlots; ++k) {
         if (ctx->pin_in[k]) (void)hipHostFree(ctx->pin_in[k]);
         if (ctx->pin_out[k]) (void)hipHostFree(ctx->pin_out[k]);
         if (ctx->d_in[k]) (void)hipFree(ctx->d_in[k]);
@@ -587,22 +610,35 @@ int csvsimd_stage1_bound(uint64_t len, uint64_t* max_entries) {
 // run, chunk i+1 is staged (sliced over a few host threads) and already on its way to the device, and the tape of
 // chunk i-1 is expanded from its pinned slot into the caller's tape.  This path is PCIe bound by construction; the
 // HBM-resident entry points are the timed ones.
-static int pipe_setup(csvsimd_ctx* ctx) {
-    if (ctx->pipe_ready) return CSVSIMD_OK;
-    // a previous attempt may have failed half way (out of memory): only create what is still missing
+static int pipe_setup(csvsimd_ctx* ctx, int slots = 2, uint64_t slot_bytes = csvsimd_ctx::kChunk) {
+    // everything is created when it is first needed and kept: a previous attempt may have failed half way (out of
+    // memory), a small file needs one small slot, a large one all four at full size
+    slots = std::min(std::max(slots, 1), csvsimd_ctx::kSlots);
+    slot_bytes = std::min<uint64_t>(std::max<uint64_t>(slot_bytes, 1u << 16), csvsimd_ctx::kChunk);
     if (!ctx->copier) ctx->copier.reset(new CopyPool(ingest_workers()));
     if (!ctx->pipe_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->pipe_stream, hipStreamNonBlocking));
     if (!ctx->in_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->in_stream, hipStreamNonBlocking));
     if (!ctx->h_res)
-        HIP_TRY(hipHostMalloc((void**)&ctx->h_res, 2 * sizeof(csvsimd_shard_result), hipHostMallocDefault));
-    for (int k = 0; k < 2; ++k) {
-        if (!ctx->pin_in[k]) HIP_TRY(hipHostMalloc(&ctx->pin_in[k], csvsimd_ctx::kChunk, hipHostMallocDefault));
-        if (!ctx->d_in[k]) HIP_TRY(hipMalloc(&ctx->d_in[k], csvsimd_ctx::kChunk));
+        HIP_TRY(hipHostMalloc((void**)&ctx->h_res, csvsimd_ctx::kSlots * sizeof(csvsimd_shard_result), hipHostMallocDefault));
+    for (int k = 0; k < slots; ++k) {
+        if (ctx->slot_bytes[k] < slot_bytes) {
+            // (nothing of an earlier call is in flight: every host entry point drains its streams before it returns)
+            if (ctx->pin_in[k]) HIP_TRY(hipHostFree(ctx->pin_in[k]));
+            ctx->pin_in[k] = nullptr;
+            if (ctx->d_in[k]) HIP_TRY(hipFree(ctx->d_in[k]));
+            ctx->d_in[k] = nullptr;
+            ctx->slot_bytes[k] = 0;
+            // small slots grow geometrically: a caller that reads files of growing sizes does not re-pin for each
+            const uint64_t want = slot_bytes >= csvsimd_ctx::kChunk / 2 ? csvsimd_ctx::kChunk
+                                                                        : std::max<uint64_t>(slot_bytes, 1u << 20);
+            HIP_TRY(hipHostMalloc(&ctx->pin_in[k], want, hipHostMallocDefault));
+            HIP_TRY(hipMalloc(&ctx->d_in[k], want));
+            ctx->slot_bytes[k] = want;
+        }
         if (!ctx->d_res[k]) HIP_TRY(hipMalloc((void**)&ctx->d_res[k], sizeof(csvsimd_shard_result)));
         if (!ctx->ev_in[k]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_in[k], hipEventDisableTiming));
         if (!ctx->ev_rec[k]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_rec[k], hipEventDisableTiming));
     }
-    ctx->pipe_ready = true;
     return CSVSIMD_OK;
 }
 // a slot's device tape and its pinned way back, both for `entries` entries; everything that touches them runs on
@@ -633,10 +669,11 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
 static int stage1_index_host_impl(csvsimd_ctx* ctx, const csvsimd_dialect* dialect, const uint8_t* buf, uint64_t len,
                                   uint64_t* tape, uint64_t tape_cap, uint64_t* tape_len, uint32_t* in_quote_out) {
     const int rc = stage1_index_host_body(ctx, dialect, buf, len, tape, tape_cap, tape_len, in_quote_out);
-    if (rc != CSVSIMD_OK && rc != CSVSIMD_ERR_TAPE_CAPACITY && ctx && ctx->pipe_ready) {
+    if (rc != CSVSIMD_OK && rc != CSVSIMD_ERR_TAPE_CAPACITY && ctx && ctx->in_stream && ctx->pipe_stream) {
         // an error exit in mid-pipeline leaves copies and kernels in flight on the pinned slots: drain the
         // streams so the next call (or the caller freeing `buf` / `tape`) cannot race them
         const std::string keep = g_last_error;
+        ScopedDevice scoped_device_(ctx->device);
         (void)hipStreamSynchronize(ctx->in_stream);
         (void)hipStreamSynchronize(ctx->pipe_stream);
         (void)hipGetLastError();
@@ -645,48 +682,84 @@ static int stage1_index_host_impl(csvsimd_ctx* ctx, const csvsimd_dialect* diale
     return rc;
 }
 
-static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* dialect, const uint8_t* buf, uint64_t len,
-                                  uint64_t* tape, uint64_t tape_cap, uint64_t* tape_len, uint32_t* in_quote_out) {
-    if (!ctx || (len && !buf) || (!tape && tape_cap) || !tape_len) return CSVSIMD_ERR_INVALID_ARG;
-    if (dialect_check(dialect) != CSVSIMD_OK) return CSVSIMD_ERR_INVALID_ARG;
-    WITH_DEVICE_OF(ctx);
-    int rc = pipe_setup(ctx);
-    if (rc != CSVSIMD_OK) return rc;
-    // Chunk plan.  The slots hold up to 32 MiB.  A large file ramps up (4, 8, 16 MiB, then 32) and down (..., 16, 8):
-    // the pipeline's fill — staging + H2D of the first chunk, during which nothing else runs — and its drain — kernel,
-    // D2H and unload of the last chunk's tape — then cost a 4- / 8-MiB chunk's time instead of a 32-MiB chunk's
-    // (~0.8 + 0.3 ms of a 40 ms call on 2 GiB).  A mid-size file is cut into ~4 chunks (>= 4 MiB, a multiple of 1 MiB)
-    // so that staging, H2D, kernel and D2H of neighbouring chunks overlap inside it as well.  Every chunk costs ~100 us
-    // of host-side launches and waits, so smaller is not better: measured (scripts/probe_latency.py) 32 MiB file
-    // 25 -> 32 GiB/s with 8-MiB chunks, but a 256 MiB file 45 -> 22 GiB/s with 4-MiB chunks.
-    constexpr uint64_t kMiB = 1ull << 20, kMax = csvsimd_ctx::kChunk;
-    std::vector<uint64_t> cuts;  // chunk i = [cuts[i], cuts[i + 1])
+// The chunk plan of the ingest pipeline: chunk i = [cuts[i], cuts[i + 1]).  The slots hold up to 32 MiB.  A large file ramps
+// up (4, 8, 16 MiB, then 32) and down (..., 16, 8): the pipeline's fill — staging + H2D of the first chunk, during which
+// nothing else runs — and its drain — kernel, D2H and unload of the last chunk's tape — then cost a 4- / 8-MiB chunk's
+// time instead of a 32-MiB chunk's (~0.8 + 0.3 ms of a 40 ms call on 2 GiB).  A mid-size file is cut into ~4 chunks
+// (>= 4 MiB, a multiple of 1 MiB) so that staging, H2D, kernel and D2H of neighbouring chunks overlap inside it as well.
+// Every chunk costs ~100 us of host-side launches and waits, so smaller is not better: measured (scripts/probe_latency.py)
+// 32 MiB file 25 -> 32 GiB/s with 8-MiB chunks, but a 256 MiB file 45 -> 22 GiB/s with 4-MiB chunks.  For the same
+// reason no chunk of the ramp is shorter than 4 MiB: a remainder that would be is folded into its neighbours.
+static std::vector<uint64_t> ingest_chunk_plan(uint64_t len, uint64_t uniform_override) {
+    constexpr uint64_t kMiB = 1ull << 20, kMax = csvsimd_ctx::kChunk, kMin = 4 * kMiB;
+    std::vector<uint64_t> cuts;
     cuts.push_back(0);
-    uint64_t uniform = 0;
-    if (const char* e = getenv("CSVSIMD_INGEST_CHUNK_MIB")) {
-        const uint64_t v = (uint64_t)atoi(e) << 20;
-        if (v >= kMiB && v <= kMax) uniform = v;
-    }
+    uint64_t uniform = uniform_override;
     if (!uniform && len < 4 * kMax) {
         const uint64_t target = ((len / 4 + kMiB - 1) >> 20) << 20;
-        uniform = std::min<uint64_t>(kMax, std::max<uint64_t>(4 * kMiB, target));
+        uniform = std::min<uint64_t>(kMax, std::max<uint64_t>(kMin, target));
     }
     for (uint64_t off = 0, i = 0; off < len; ++i) {
         const uint64_t rem = len - off;
         uint64_t sz;
         if (uniform) {
             sz = std::min(uniform, rem);
+            const uint64_t least = std::min(kMin, uniform);
+            if (rem > sz && rem - sz < least)  // a stub would be left over: one chunk if the slot holds it, else two halves
+                sz = rem <= kMax ? rem : (((rem / 2) + kMiB - 1) >> 20) << 20;
         } else {
-            const uint64_t up = i < 3 ? (4 * kMiB) << i : kMax;                       // 4, 8, 16, 32, 32, ...
+            const uint64_t up = i < 3 ? kMin << i : kMax;                              // 4, 8, 16, 32, 32, ...
             if (rem > kMax + 24 * kMiB) sz = std::min(up, kMax);
-            else if (rem > 24 * kMiB) sz = std::min(up, rem - 24 * kMiB);              // ... <= 32, then 16, 8
-            else if (rem > 8 * kMiB) sz = std::min(up, rem - 8 * kMiB);
+            else if (rem > 24 * kMiB) sz = std::min(up, std::max(rem - 24 * kMiB, std::min(kMin, rem)));  // ... <= 32, then 16, 8
+            else if (rem > 8 * kMiB) sz = std::min(up, std::max(rem - 8 * kMiB, std::min(kMin, rem)));
             else sz = rem;
         }
         off += sz;
         cuts.push_back(off);
     }
+    return cuts;
+}
+
+extern "C" int csvsimd_ingest_chunk_plan(uint64_t len, uint64_t* cuts, uint64_t cap, uint64_t* n_cuts) {
+    return csvsimd_guarded([&]() -> int {
+    if (!n_cuts || (cap && !cuts)) return CSVSIMD_ERR_INVALID_ARG;
+    const std::vector<uint64_t> plan = ingest_chunk_plan(len, 0);
+    *n_cuts = plan.size();
+    if (plan.size() > cap) return CSVSIMD_ERR_TAPE_CAPACITY;
+    std::copy(plan.begin(), plan.end(), cuts);
+    return CSVSIMD_OK;
+    });
+}
+
+// Phase times of the most recent csvsimd_stage1_index call on this thread (csvsimd_ingest_last_phases): where a call's
+// wall time went, per thread of the pipeline.
+namespace {
+thread_local csvsimd_ingest_phases g_ingest_phases = {};
+}
+extern "C" int csvsimd_ingest_last_phases(csvsimd_ingest_phases* out) {
+    if (!out) return CSVSIMD_ERR_INVALID_ARG;
+    *out = g_ingest_phases;
+    return CSVSIMD_OK;
+}
+
+static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* dialect, const uint8_t* buf, uint64_t len,
+                                  uint64_t* tape, uint64_t tape_cap, uint64_t* tape_len, uint32_t* in_quote_out) {
+    if (!ctx || (len && !buf) || (!tape && tape_cap) || !tape_len) return CSVSIMD_ERR_INVALID_ARG;
+    if (dialect_check(dialect) != CSVSIMD_OK) return CSVSIMD_ERR_INVALID_ARG;
+    WITH_DEVICE_OF(ctx);
+    constexpr uint64_t kMiB = 1ull << 20, kMax = csvsimd_ctx::kChunk;
+    constexpr int S = csvsimd_ctx::kSlots;
+    uint64_t uniform = 0;
+    if (const char* e = getenv("CSVSIMD_INGEST_CHUNK_MIB")) {
+        const uint64_t v = (uint64_t)atoi(e) << 20;
+        if (v >= kMiB && v <= kMax) uniform = v;
+    }
+    const std::vector<uint64_t> cuts = ingest_chunk_plan(len, uniform);  // chunk i = [cuts[i], cuts[i + 1])
     const uint64_t nchunks = cuts.size() - 1;
+    uint64_t largest = 0;
+    for (uint64_t i = 0; i < nchunks; ++i) largest = std::max(largest, cuts[i + 1] - cuts[i]);
+    int rc = pipe_setup(ctx, (int)std::min<uint64_t>(std::max<uint64_t>(nchunks, 1), S), largest);
+    if (rc != CSVSIMD_OK) return rc;
     hipStream_t st = ctx->pipe_stream;
 
     // How a chunk's tape reaches the host: a small kernel right behind the stage-1 launch packs the chunk's entries into
@@ -695,61 +768,104 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
     // Measured on the pool's two-socket hosts (scripts/probe_ingest3.py, 2 GiB): with the tape copied back by D2H
     // copies the H2D copies of the following chunks are served one after the other with them (49 ms = 39 ms of H2D +
     // 10 ms of D2H; the count-only call: 39 ms); with the stage-1 kernel writing its u64 tape into the pinned slot
-    // itself, 42 ms; (the round-2 pipeline chose between those two by watching its waits).
-    bool zero_copy_in = false;
-#ifdef CSVSIMD_DEV_PROBES
-    if (const char* e = getenv("CSVSIMD_PROBE_ZEROCOPY_IN")) zero_copy_in = atoi(e) != 0;  // measured: 36 GiB/s, worse
-#endif
+    // itself, 42 ms.
     uint64_t n = 1;  // entries so far, sentinel included
     if (tape && tape_cap >= 1) tape[0] = 0;  // src/reader.rs:216
 
     // The loop-carried values of the reference (inside_str, array_idx: src/reader.rs:217-218) between chunks: the
     // entering state travels ON THE DEVICE — the launch of chunk i + 1 reads in_quote_out (and escape_out) from chunk i's
     // result record when it starts (KernelArgs::chain) — so chunk i + 1 is enqueued before the host has seen chunk i's
-    // record, and nothing on the GPU ever waits for the host.  The host reads the records one chunk late, only to learn
+    // record, and nothing on the GPU ever waits for the host.  The host reads the records kLag chunks late, only to learn
     // how many entries came back and where they belong in the caller's tape.
+    //
+    // Three host threads (round 4; a file of one or two chunks runs everything on the caller's):
+    //   stager     user buffer -> pinned slot, up to S - 1 chunks ahead of the H2D copies (sliced over the copy pool)
+    //   submitter  (the caller's thread) H2D copy, stage-1 launch, narrow kernel, record copy-out; reads records kLag behind
+    //   expander   pinned 32-bit offsets -> the caller's tape (sliced over the copy pool)
+    // Until round 3 the submitter did all three in turn with two slots: staging chunk i + 1 and expanding chunk i - 1 had
+    // to fit into the H2D time of chunk i, every time, or the link idled — 0.93 of the probed link rate on a quiet host,
+    // 0.88-0.90 on the driver's.  Now the link only idles when staging falls S - 1 chunks behind.
     struct Slot {
-        bool busy = false;   // a chunk's kernels are enqueued and its record not yet consumed
         uint64_t chunk = 0, cap = 0;
-        bool pend = false;   // entries waiting in pin_out[k] for the caller's tape
-        uint64_t at = 0, ncopy = 0, base = 0;
-    } slot[2];
+        uint64_t at = 0, ncopy = 0, base = 0;  // entries waiting in pin_out[k] for the caller's tape (written by the submitter
+                                               // before `finished` passes the chunk, read by the expander after)
+    } slot[S];
+    struct Shared {
+        std::mutex m;
+        std::condition_variable cv;
+        uint64_t staged = 0;    // chunks whose bytes are in their pinned slot
+        uint64_t h2d = 0;       // chunks whose H2D copy has been enqueued (ev_in recorded)
+        uint64_t finished = 0;  // chunks whose record has been read (slot[].at / ncopy / base valid)
+        uint64_t expanded = 0;  // chunks whose entries have left their pinned slot
+        bool abort = false;
+        int err = CSVSIMD_OK;
+        std::string msg;
+    } sh;
     uint32_t host_inq = 0, host_esc = dialect ? dialect->escape_in : 0;  // the state after the last chunk whose record was read
-    double t_in = 0, t_out = 0, t_sync = 0;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+    double t_stage = 0, t_stage_wait = 0, t_expand = 0, t_wait_staged = 0, t_wait_record = 0, t_wait_expanded = 0, t_submit = 0;
 #define CSVSIMD_TIMED(acc, stmt) do { const double t0_ = now(); stmt; acc += now() - t0_; } while (0)
+    auto fail = [&](int code, const std::string& msg) {
+        {
+            std::lock_guard<std::mutex> g(sh.m);
+            if (sh.err == CSVSIMD_OK) { sh.err = code; sh.msg = msg; }
+            sh.abort = true;
+        }
+        sh.cv.notify_all();
+    };
 
-    auto unload = [&](int k) -> int {  // the slot's 32-bit offsets -> the caller's tape (the record was waited for)
-        if (!slot[k].pend) return CSVSIMD_OK;
-        if (slot[k].ncopy)
-            CSVSIMD_TIMED(t_out, ctx->copier->expand(tape + slot[k].at, ctx->pin_out[k], slot[k].ncopy, slot[k].base));
-        slot[k].pend = false;
-        return CSVSIMD_OK;
+    // ---- stager: chunk j's bytes into pin_in[j % S] -----------------------------------------------------------------------
+    auto stage_one = [&](uint64_t j) -> bool {
+        const int k = (int)(j % S);
+        {
+            const double t0 = now();
+            std::unique_lock<std::mutex> g(sh.m);
+            sh.cv.wait(g, [&] { return sh.abort || j < (uint64_t)S || sh.h2d + S > j; });  // chunk j - S has been enqueued
+            t_stage_wait += now() - t0;
+            if (sh.abort) return false;
+        }
+        if (j >= (uint64_t)S) {  // ... and has left the staging slot
+            const double t0 = now();
+            const hipError_t e = hipEventSynchronize(ctx->ev_in[k]);
+            t_stage_wait += now() - t0;
+            if (e != hipSuccess) { fail(CSVSIMD_ERR_HIP, std::string("hipEventSynchronize(ev_in): ") + hipGetErrorString(e)); return false; }
+        }
+        CSVSIMD_TIMED(t_stage, ctx->copier->copy(ctx->pin_in[k], buf + cuts[j], cuts[j + 1] - cuts[j]));
+        {
+            std::lock_guard<std::mutex> g(sh.m);
+            sh.staged = j + 1;
+        }
+        sh.cv.notify_all();
+        return true;
     };
-    // stages chunk j into its slot and starts its H2D copy on the input stream
-    auto feed = [&](uint64_t j) -> int {
-        const int kj = (int)(j & 1);
-        const uint64_t offj = cuts[j], lenj = cuts[j + 1] - offj;
-        CSVSIMD_TIMED(t_in, ctx->copier->copy(ctx->pin_in[kj], buf + offj, lenj));
-        if (zero_copy_in) return CSVSIMD_OK;  // the kernel reads the pinned slot itself
-        HIP_TRY(hipMemcpyAsync(ctx->d_in[kj], ctx->pin_in[kj], lenj, hipMemcpyHostToDevice, ctx->in_stream));
-        HIP_TRY(hipEventRecord(ctx->ev_in[kj], ctx->in_stream));
-        return CSVSIMD_OK;
+    // ---- expander: chunk j's 32-bit offsets -> the caller's tape ------------------------------------------------------------
+    auto expand_one = [&](uint64_t j) -> bool {
+        const int k = (int)(j % S);
+        Slot info;
+        {
+            std::unique_lock<std::mutex> g(sh.m);
+            sh.cv.wait(g, [&] { return sh.abort || sh.finished > j; });
+            if (sh.abort) return false;
+            info = slot[k];
+        }
+        if (info.ncopy) CSVSIMD_TIMED(t_expand, ctx->copier->expand(tape + info.at, ctx->pin_out[k], info.ncopy, info.base));
+        {
+            std::lock_guard<std::mutex> g(sh.m);
+            sh.expanded = j + 1;
+        }
+        sh.cv.notify_all();
+        return true;
     };
+
     // enqueues the kernels of the chunk in slot k (stage 1, the narrow kernel) and the copy-out of its record
     auto launch = [&](int k, bool chained) -> int {
         const uint64_t i = slot[k].chunk, off = cuts[i], clen = cuts[i + 1] - off;
-        const void* in_dev = ctx->d_in[k];
-        if (zero_copy_in) {
-            void* q = nullptr;
-            HIP_TRY(hipHostGetDevicePointer(&q, ctx->pin_in[k], 0));
-            in_dev = q;
-        }
         csvsimd_dialect dia;
         if (dialect) { dia = *dialect; dia.escape_in = (uint8_t)host_esc; }
-        int rc_ = stage1_async_impl(ctx, dialect ? &dia : nullptr, in_dev, clen, off, host_inq,
+        int rc_ = stage1_async_impl(ctx, dialect ? &dia : nullptr, ctx->d_in[k], clen, off, host_inq,
                                     tape ? ctx->d_tape[k] : nullptr, slot[k].cap, ctx->d_res[k], st, nullptr,
-                                    chained ? ctx->d_res[k ^ 1] : nullptr);
+                                    chained ? ctx->d_res[(k + S - 1) % S] : nullptr);
         if (rc_ != CSVSIMD_OK) return rc_;
         if (tape) {
             void* out_dev = nullptr;
@@ -760,20 +876,20 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
         HIP_TRY(hipEventRecord(ctx->ev_rec[k], st));
         return CSVSIMD_OK;
     };
-    // reads the record of the chunk in slot k (one chunk behind the launches) and re-runs the chunk if its tape did not fit
-    auto finish = [&](int k) -> int {
-        if (!slot[k].busy) return CSVSIMD_OK;
+    // reads the record of chunk j (kLag behind the launches) and re-runs the chunk if its tape did not fit
+    auto finish = [&](uint64_t j) -> int {
+        const int k = (int)(j % S);
         {
             hipError_t e_ = hipSuccess;
-            CSVSIMD_TIMED(t_sync, e_ = hipEventSynchronize(ctx->ev_rec[k]));
+            CSVSIMD_TIMED(t_wait_record, e_ = hipEventSynchronize(ctx->ev_rec[k]));
             HIP_TRY(e_);
         }
         csvsimd_shard_result r = ctx->h_res[k];
         if (r.error) { g_last_error = "stage1 kernel: look-back spin bound hit"; return CSVSIMD_ERR_INTERNAL; }
         if (tape && r.count > slot[k].cap) {
             // denser than guessed (first guess: one entry per 4 bytes): exact capacity, run the chunk again.  Its input is
-            // still in the slot (the next chunk for this slot is fed only after this), its entering state is the host's:
-            // everything before it has been read.  The chunk enqueued behind it meanwhile chained from this chunk's first
+            // still in the slot (the slot's next chunk is S - kLag iterations away), its entering state is the host's:
+            // everything before it has been read.  The chunks enqueued behind it meanwhile chained from this chunk's first
             // record, whose in_quote_out / escape_out do not depend on the capacity — and the re-run writes the same.
             int rc_ = pipe_ensure_tape(ctx, k, r.count);  // waits for pipe_stream
             if (rc_ != CSVSIMD_OK) return rc_;
@@ -785,62 +901,147 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
             if (r.error) { g_last_error = "stage1 kernel: look-back spin bound hit"; return CSVSIMD_ERR_INTERNAL; }
             if (r.count > slot[k].cap) return CSVSIMD_ERR_INTERNAL;
         }
-        slot[k].busy = false;
-        if (tape && n < tape_cap) {
-            slot[k].ncopy = std::min<uint64_t>(tape_cap - n, r.count);
-            slot[k].at = n;
-            slot[k].base = cuts[slot[k].chunk];
-            slot[k].pend = slot[k].ncopy != 0;
+        {
+            std::lock_guard<std::mutex> g(sh.m);
+            slot[k].ncopy = 0;
+            if (tape && n < tape_cap) {
+                slot[k].ncopy = std::min<uint64_t>(tape_cap - n, r.count);
+                slot[k].at = n;
+                slot[k].base = cuts[j];
+            }
+            sh.finished = j + 1;
         }
+        sh.cv.notify_all();
         n += r.count;
         host_inq = r.in_quote_out;
         host_esc = r.escape_out;
         return CSVSIMD_OK;
     };
-
-    if (nchunks && (rc = feed(0)) != CSVSIMD_OK) return rc;
-    for (uint64_t i = 0; i < nchunks; ++i) {
-        const int k = (int)(i & 1);
+    // the submitter's share of chunk i: H2D copy, kernels, record copy-out
+    auto submit = [&](uint64_t i) -> int {
+        const int k = (int)(i % S);
         const uint64_t clen = cuts[i + 1] - cuts[i];
-        // slot k's previous chunk (i - 2): its record was consumed in the previous iteration; its offsets must have left
-        // the pinned slot before this chunk's narrow kernel may write it
-        rc = unload(k);
-        if (rc != CSVSIMD_OK) return rc;
-        if (!zero_copy_in) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_in[k], 0));
+        {
+            const double t0 = now();
+            std::unique_lock<std::mutex> g(sh.m);
+            sh.cv.wait(g, [&] { return sh.abort || sh.staged > i; });
+            t_wait_staged += now() - t0;
+            if (sh.abort) return sh.err != CSVSIMD_OK ? sh.err : CSVSIMD_ERR_INTERNAL;
+        }
+        const double t0 = now();
+        if (i >= (uint64_t)S) HIP_TRY(hipStreamWaitEvent(ctx->in_stream, ctx->ev_rec[k], 0));  // chunk i - S's kernels have read d_in[k]
+        HIP_TRY(hipMemcpyAsync(ctx->d_in[k], ctx->pin_in[k], clen, hipMemcpyHostToDevice, ctx->in_stream));
+        HIP_TRY(hipEventRecord(ctx->ev_in[k], ctx->in_stream));
+        {
+            std::lock_guard<std::mutex> g(sh.m);
+            sh.h2d = i + 1;
+        }
+        sh.cv.notify_all();
+        HIP_TRY(hipStreamWaitEvent(st, ctx->ev_in[k], 0));
+        t_submit += now() - t0;
+        if (i >= (uint64_t)S) {  // the slot's previous chunk (i - S): its offsets must have left pin_out[k]
+            const double t1 = now();
+            std::unique_lock<std::mutex> g(sh.m);
+            sh.cv.wait(g, [&] { return sh.abort || sh.expanded + S > i; });
+            t_wait_expanded += now() - t1;
+            if (sh.abort) return sh.err != CSVSIMD_OK ? sh.err : CSVSIMD_ERR_INTERNAL;
+        }
+        const double t2 = now();
         slot[k].chunk = i;
         slot[k].cap = 0;
         if (tape) {
-            rc = pipe_ensure_tape(ctx, k, std::max<uint64_t>(clen / 4, 4096));  // first guess: one entry per 4 bytes
-            if (rc != CSVSIMD_OK) return rc;
+            int rc_ = pipe_ensure_tape(ctx, k, std::max<uint64_t>(clen / 4, 4096));  // first guess: one entry per 4 bytes
+            if (rc_ != CSVSIMD_OK) return rc_;
             slot[k].cap = std::min(ctx->d_tape_entries[k], ctx->pin_out_entries[k]);
         }
-        rc = launch(k, i > 0);
-        if (rc != CSVSIMD_OK) return rc;
-        slot[k].busy = true;
-        // one chunk behind: the record of chunk i - 1 (the host blocks here until the GPU is one chunk ahead of it — the
-        // GPU itself never waits for the host)
-        rc = finish(k ^ 1);
-        if (rc != CSVSIMD_OK) return rc;
-        // stage chunk i + 1 and start its H2D copy (slot k^1: its kernels have finished, its record is read — its
-        // offsets stay in the pinned slot until the top of the next iteration) ...
-        if (i + 1 < nchunks && (rc = feed(i + 1)) != CSVSIMD_OK) return rc;
-        // ... and expand them into the caller's tape while chunk i is on the GPU
-        rc = unload(k ^ 1);
-        if (rc != CSVSIMD_OK) return rc;
+        const int rc_ = launch(k, i > 0);
+        t_submit += now() - t2;
+        return rc_;
+    };
+
+    constexpr uint64_t kLag = 2;  // records are read two chunks behind the launches: two H2D copies stay queued meanwhile
+    const bool threaded = nchunks >= 3;
+    if (threaded) {
+        std::thread stager, expander;
+        struct Joiner {  // whatever happens below (an error return, an exception), the two threads are stopped and joined
+            Shared& sh;
+            std::thread &a, &b;
+            ~Joiner() {
+                {
+                    std::lock_guard<std::mutex> g(sh.m);
+                    sh.abort = true;  // (a completed run: both loops have ended, nobody is listening)
+                }
+                sh.cv.notify_all();
+                if (a.joinable()) a.join();
+                if (b.joinable()) b.join();
+            }
+        } joiner{sh, stager, expander};
+        const int dev = ctx->device;
+        stager = std::thread([&, dev] {
+            if (hipSetDevice(dev) != hipSuccess) { fail(CSVSIMD_ERR_HIP, "hipSetDevice (stager)"); return; }
+            try {
+                for (uint64_t j = 0; j < nchunks; ++j)
+                    if (!stage_one(j)) return;
+            } catch (...) { fail(CSVSIMD_ERR_INVALID_STATE, "ingest stager: exception"); }
+        });
+        if (tape)
+            expander = std::thread([&] {
+                try {
+                    for (uint64_t j = 0; j < nchunks; ++j)
+                        if (!expand_one(j)) return;
+                } catch (...) { fail(CSVSIMD_ERR_INVALID_STATE, "ingest expander: exception"); }
+            });
+        else {
+            std::lock_guard<std::mutex> g(sh.m);
+            sh.expanded = nchunks;  // count only: nothing ever waits in a pinned slot
+        }
+        rc = CSVSIMD_OK;
+        for (uint64_t i = 0; i < nchunks && rc == CSVSIMD_OK; ++i) {
+            rc = submit(i);
+            if (rc == CSVSIMD_OK && i >= kLag) rc = finish(i - kLag);
+        }
+        for (uint64_t j = nchunks > kLag ? nchunks - kLag : 0; j < nchunks && rc == CSVSIMD_OK; ++j) rc = finish(j);
+        if (rc == CSVSIMD_OK && tape) {
+            const double t0 = now();
+            std::unique_lock<std::mutex> g(sh.m);
+            sh.cv.wait(g, [&] { return sh.abort || sh.expanded >= nchunks; });
+            t_wait_expanded += now() - t0;
+        }
+        {
+            std::lock_guard<std::mutex> g(sh.m);
+            if (sh.err != CSVSIMD_OK) {  // a worker's failure is the call's (the submitter may only have seen `abort`)
+                rc = sh.err;
+                g_last_error = sh.msg;
+            }
+        }
+        if (rc != CSVSIMD_OK) {
+            const std::string keep = g_last_error;
+            fail(rc, keep);  // stops the workers; the Joiner joins them
+            g_last_error = keep;
+            return rc;
+        }
+    } else {
+        // one or two chunks: the same steps in turn on the caller's thread (no thread is worth starting for a file that
+        // is indexed in the time it takes to start one)
+        for (uint64_t i = 0; i < nchunks; ++i) {
+            if (!stage_one(i)) return sh.err;
+            rc = submit(i);
+            if (rc != CSVSIMD_OK) return rc;
+            if (i >= 1) {
+                rc = finish(i - 1);
+                if (rc != CSVSIMD_OK) return rc;
+                if (tape && !expand_one(i - 1)) return sh.err;
+            }
+        }
+        if (nchunks) {
+            rc = finish(nchunks - 1);
+            if (rc != CSVSIMD_OK) return rc;
+            if (tape && !expand_one(nchunks - 1)) return sh.err;
+        }
     }
-    if (nchunks && (rc = finish((int)((nchunks - 1) & 1))) != CSVSIMD_OK) return rc;
-#ifdef CSVSIMD_DEV_PROBES
-    if (getenv("CSVSIMD_PROBE_INGEST_TIMES"))
-        fprintf(stderr, "ingest %.1f MiB in %llu chunks: staging copies in %.2f ms, tape expansion out %.2f ms, "
-                        "waits for records (H2D + kernels) %.2f ms\n",
-                len / 1048576.0, (unsigned long long)nchunks, t_in * 1e3, t_out * 1e3, t_sync * 1e3);
-#else
-    (void)t_in; (void)t_out; (void)t_sync;
-#endif
-    rc = unload(0);
-    if (rc != CSVSIMD_OK) return rc;
-    rc = unload(1);
-    if (rc != CSVSIMD_OK) return rc;
+#undef CSVSIMD_TIMED
+    g_ingest_phases = csvsimd_ingest_phases{len, nchunks, threaded ? 3u : 1u, 0u, now() - t_begin, t_stage, t_stage_wait, t_expand,
+                                            t_submit, t_wait_staged, t_wait_record, t_wait_expanded};
     *tape_len = n;
     if (in_quote_out) *in_quote_out = host_inq;
     if (tape && n > tape_cap) return CSVSIMD_ERR_TAPE_CAPACITY;

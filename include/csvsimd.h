@@ -153,6 +153,32 @@ int csvsimd_stage1_bound(uint64_t len, uint64_t* max_entries);
 int csvsimd_stage1_index(csvsimd_ctx* ctx, const uint8_t* buf, uint64_t len, uint64_t* tape,
                          uint64_t tape_cap, uint64_t* tape_len, uint32_t* in_quote_out);
 
+/* How csvsimd_stage1_index cuts a buffer of `len` bytes into the chunks it streams through the GPU (the host side owns
+ * the chunking; reference: csv_simd::create maps the whole file and streaming is a TODO, src/lib.rs:61-74, README.md:23):
+ * cuts[0] = 0 < cuts[1] < ... = len, chunk i = [cuts[i], cuts[i + 1]).  No chunk exceeds the 32-MiB slot, a large
+ * file ramps up (4, 8, 16 MiB) and down, and no chunk of a multi-chunk plan is shorter than 4 MiB.  *n_cuts = entries
+ * needed; CSVSIMD_ERR_TAPE_CAPACITY if cap is smaller (nothing is written). */
+int csvsimd_ingest_chunk_plan(uint64_t len, uint64_t* cuts, uint64_t cap, uint64_t* n_cuts);
+
+/* Where the wall time of the calling thread's most recent csvsimd_stage1_index[_dialect] call went, by thread of its
+ * pipeline (seconds).  A file of three or more chunks runs on three host threads — stager (user buffer -> pinned
+ * slots, ahead of the H2D copies), submitter (the caller: H2D copies, launches, records), expander (32-bit offsets in the
+ * pinned slots -> the caller's tape); a shorter one runs the same steps in turn on the caller's thread. */
+typedef struct csvsimd_ingest_phases {
+    uint64_t bytes, chunks;
+    uint32_t host_threads;       /* 3 or 1 */
+    uint32_t reserved;
+    double wall;                 /* the whole call */
+    double stage_copy;           /* stager: copying into the pinned slots ... */
+    double stage_wait;           /* ... and waiting for a slot to come free (H2D of the chunk four before) */
+    double expand_copy;          /* expander: widening offsets into the caller's tape */
+    double submit;               /* submitter: enqueueing copies, kernels, events */
+    double wait_staged;          /* submitter: waiting for the stager (the link idles meanwhile unless copies are queued) */
+    double wait_record;          /* submitter: waiting for a chunk's result record (H2D + kernels two chunks back) */
+    double wait_expanded;        /* submitter: waiting for the expander to release a pinned tape slot */
+} csvsimd_ingest_phases;
+int csvsimd_ingest_last_phases(csvsimd_ingest_phases* out);
+
 /* ---- dialect extension -------------------------------------------------
  * NOT reference behaviour: the reference hard-wires ',' and '"' (src/avx/stage1.rs:392-394);
  * its class table already knows backslash and space (src/stage1.rs:41-48) but nothing uses them

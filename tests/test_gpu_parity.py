@@ -516,6 +516,46 @@ def test_host_ingest_chained_chunks_ramped_plan_and_mid_pipeline_retry(ctx, pkg,
     assert rc == pkg.ERR_TAPE_CAPACITY and cnt == want.size and np.array_equal(small, want[:100_000])
 
 
+def test_host_ingest_three_threads_many_slot_reuses(pkg, oracle, monkeypatch):
+    """The round-4 pipeline: a stager thread (up to three chunks ahead), the submitting caller, an expander thread, four
+    slots.  Forty-odd 4-MiB chunks reuse every slot ten times; several chunks — neighbours among them, the first and the
+    last — are denser than the capacity guess and take the exact-capacity re-run while the chunks behind them are already
+    enqueued; quoted stretches cross chunk boundaries.  Then the same context reads a two-chunk file (everything on the
+    caller's thread) and a tiny one, and the phase record says which pipeline ran."""
+    monkeypatch.setenv("CSVSIMD_INGEST_CHUNK_MIB", "4")
+    rng = np.random.default_rng(31337)
+    chunk = 4 << 20
+    n = 43 * chunk + 4321
+    d = random_csvish(rng, n, 0.001)
+    for c in (0, 7, 8, 9, 21, 42):                                     # dense chunks: > 1 entry per 4 bytes
+        d[c * chunk + 100: (c + 1) * chunk - 100] = 0x2C
+        d[c * chunk + 5000] = 0x22                                     # an odd number of quotes inside: the state handed on flips
+    c = pkg.Context(0)
+    try:
+        want = oracle.scalar_read(d)
+        for rep in range(2):                                           # the second call finds every slot allocated
+            got = c.read(d)
+            assert got.size == want.size and np.array_equal(got, want), rep
+            ph = pkg.ingest_last_phases()
+            assert ph["host_threads"] == 3 and ph["chunks"] == 44 and ph["bytes"] == n
+            assert ph["wall"] > 0 and ph["stage_copy"] > 0 and ph["expand_copy"] > 0
+        rc, cnt, q = c.read_into(d, None)                              # count only: no expander
+        assert rc == 0 and cnt == want.size and q == int(np.count_nonzero(d == 0x22) & 1)
+        small = np.zeros(12345, dtype=np.uint64)
+        rc, cnt, _ = c.read_into(d, small)
+        assert rc == pkg.ERR_TAPE_CAPACITY and cnt == want.size and np.array_equal(small, want[:12345])
+        monkeypatch.delenv("CSVSIMD_INGEST_CHUNK_MIB")
+        two = d[: 2 * chunk + 17]
+        assert pkg.ingest_chunk_plan(two.size) == [0, chunk, two.size]
+        assert np.array_equal(c.read(two), oracle.scalar_read(two))
+        assert pkg.ingest_last_phases()["host_threads"] == 1
+        tiny = d[9 * chunk - 150: 9 * chunk + 150]
+        assert np.array_equal(c.read(tiny), oracle.scalar_read(tiny))
+        assert np.array_equal(c.read(d), want)                         # and the large file again after the small ones
+    finally:
+        c.close()
+
+
 def test_async_entry_point_is_graph_capturable(ctx, torch_cuda, pkg, oracle):
     # include/csvsimd.h promises: no allocation and no synchronisation inside
     # csvsimd_stage1_index_device_async once the scratch is reserved -> it can be captured into a

@@ -100,3 +100,25 @@ def test_header_quirks_are_mirrored(pkg):
     t = pkg.Tape.from_index(data, idx)
     assert t.header() == ["n", "m"] and t.new_line == "CRLF" and t.record_jump_size == 3 and t.record_cnt == 2
     assert t.seek_field(0, 1) == b"2"
+
+
+def test_ingest_chunk_plan_has_no_degenerate_chunk(pkg):
+    # the host side owns the chunking (csvsimd_stage1_index): every plan tiles [0, len) in order, no chunk exceeds the
+    # 32-MiB slot, and a multi-chunk plan holds no stub (148 MiB + 1 byte used to end in a 1-byte chunk that
+    # still paid two launches and an event wait)
+    MiB = 1 << 20
+    rng = np.random.default_rng(4)
+    lens = [0, 1, 300, 4 * MiB, 4 * MiB + 1, 12 * MiB + 1, 16 * MiB + 1, 64 * MiB + 1, 128 * MiB - 1, 128 * MiB, 128 * MiB + 1,
+            148 * MiB + 1, 152 * MiB + 1, 136 * MiB + 1, 2048 * MiB, 2048 * MiB + 777]
+    lens += [int(x) for x in rng.integers(1, 600 * MiB, 300)]
+    for n in lens:
+        cuts = pkg.ingest_chunk_plan(n)
+        assert cuts[0] == 0 and cuts[-1] == n, n
+        sizes = [b - a for a, b in zip(cuts, cuts[1:])]
+        assert all(s > 0 for s in sizes) and all(s <= 32 * MiB for s in sizes), (n, sizes)
+        if len(sizes) > 1:
+            assert min(sizes) >= 4 * MiB, (n, sizes)
+        assert len(sizes) == (0 if n == 0 else len(sizes))
+    # a large file ramps up and down around full slots
+    sizes = [b - a for a, b in zip(*(lambda c: (c, c[1:]))(pkg.ingest_chunk_plan(2048 * MiB)))]
+    assert sizes[:4] == [4 * MiB, 8 * MiB, 16 * MiB, 32 * MiB] and sizes[-2:] == [16 * MiB, 8 * MiB]
