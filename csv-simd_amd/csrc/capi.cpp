@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <condition_variable>
 #include <cstddef>
 #include <cstdio>
@@ -276,6 +277,7 @@ struct csvsimd_ctx {
     static constexpr int kSlots = 4;
     hipStream_t pipe_stream = nullptr;         // kernels + result records
     hipStream_t in_stream = nullptr;           // H2D of input chunks (runs ahead of the kernels)
+    hipStream_t in_stream2 = nullptr;          // ... of every other chunk (host-buffer pipeline; see stage1_index_host_body)
     hipEvent_t ev_in[kSlots] = {};             // chunk has landed in d_in[k]
     void* pin_in[kSlots] = {};                 // pinned staging of the input chunk
     void* d_in[kSlots] = {};
@@ -383,6 +385,7 @@ void csvsimd_ctx_destroy(csvsimd_ctx* ctx) {
         if (ctx->ev_rec[k]) (void)hipEventDestroy(ctx->ev_rec[k]);
     }
     if (ctx->in_stream) (void)hipStreamDestroy(ctx->in_stream);
+    if (ctx->in_stream2) (void)hipStreamDestroy(ctx->in_stream2);
     if (ctx->h_res) (void)hipHostFree(ctx->h_res);
     if (ctx->pipe_stream) (void)hipStreamDestroy(ctx->pipe_stream);
     delete ctx;
@@ -618,6 +621,7 @@ static int pipe_setup(csvsimd_ctx* ctx, int slots = 2, uint64_t slot_bytes = csv
     if (!ctx->copier) ctx->copier.reset(new CopyPool(ingest_workers()));
     if (!ctx->pipe_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->pipe_stream, hipStreamNonBlocking));
     if (!ctx->in_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->in_stream, hipStreamNonBlocking));
+    if (!ctx->in_stream2) HIP_TRY(hipStreamCreateWithFlags(&ctx->in_stream2, hipStreamNonBlocking));
     if (!ctx->h_res)
         HIP_TRY(hipHostMalloc((void**)&ctx->h_res, csvsimd_ctx::kSlots * sizeof(csvsimd_shard_result), hipHostMallocDefault));
     for (int k = 0; k < slots; ++k) {
@@ -675,6 +679,7 @@ static int stage1_index_host_impl(csvsimd_ctx* ctx, const csvsimd_dialect* diale
         const std::string keep = g_last_error;
         ScopedDevice scoped_device_(ctx->device);
         (void)hipStreamSynchronize(ctx->in_stream);
+        if (ctx->in_stream2) (void)hipStreamSynchronize(ctx->in_stream2);
         (void)hipStreamSynchronize(ctx->pipe_stream);
         (void)hipGetLastError();
         g_last_error = keep;
@@ -754,6 +759,13 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
         const uint64_t v = (uint64_t)atoi(e) << 20;
         if (v >= kMiB && v <= kMax) uniform = v;
     }
+    // Entries per input byte, as the latest chunk whose record was read had them (a first guess until then): sizes the grid
+    // of the kernel that writes a chunk's offsets into its pinned slot.  Those writes share the PCIe link's upstream
+    // direction with the read requests of the H2D copies; a full-width grid dumps a chunk's 4 MiB in one burst and the
+    // copies behind it stall (measured on 2 GiB of the 64-column corpus: 49.8 GiB/s with 256 workgroups, 50.4 with one,
+    // 51.5 with no tape at all).  One workgroup per 2 MiB of offsets keeps up with the link many times over.
+    double entries_per_byte = 1.0 / 32.0;
+    constexpr int h2d_streams = 2;
     const std::vector<uint64_t> cuts = ingest_chunk_plan(len, uniform);  // chunk i = [cuts[i], cuts[i + 1])
     const uint64_t nchunks = cuts.size() - 1;
     uint64_t largest = 0;
@@ -870,7 +882,9 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
         if (tape) {
             void* out_dev = nullptr;
             HIP_TRY(hipHostGetDevicePointer(&out_dev, ctx->pin_out[k], 0));
-            HIP_TRY(csvsimd::launch_narrow_tape(ctx->d_tape[k], ctx->d_res[k], slot[k].cap, off, out_dev, ctx->n_cus, st));
+            const double out_bytes = std::min<double>(entries_per_byte * (double)clen, (double)slot[k].cap) * 4.0;
+            const int wgs = (int)std::min<double>(std::max(1.0, std::ceil(out_bytes / (double)(2u << 20))), (double)ctx->n_cus);
+            HIP_TRY(csvsimd::launch_narrow_tape(ctx->d_tape[k], ctx->d_res[k], slot[k].cap, off, out_dev, wgs, st));
         }
         HIP_TRY(hipMemcpyAsync(&ctx->h_res[k], ctx->d_res[k], sizeof(csvsimd_shard_result), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipEventRecord(ctx->ev_rec[k], st));
@@ -913,6 +927,7 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
         }
         sh.cv.notify_all();
         n += r.count;
+        if (cuts[j + 1] > cuts[j]) entries_per_byte = (double)r.count / (double)(cuts[j + 1] - cuts[j]);
         host_inq = r.in_quote_out;
         host_esc = r.escape_out;
         return CSVSIMD_OK;
@@ -929,9 +944,12 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
             if (sh.abort) return sh.err != CSVSIMD_OK ? sh.err : CSVSIMD_ERR_INTERNAL;
         }
         const double t0 = now();
-        if (i >= (uint64_t)S) HIP_TRY(hipStreamWaitEvent(ctx->in_stream, ctx->ev_rec[k], 0));  // chunk i - S's kernels have read d_in[k]
-        HIP_TRY(hipMemcpyAsync(ctx->d_in[k], ctx->pin_in[k], clen, hipMemcpyHostToDevice, ctx->in_stream));
-        HIP_TRY(hipEventRecord(ctx->ev_in[k], ctx->in_stream));
+        // Two copy streams take turns: a copy's set-up and completion signalling (~30 us, measured as the difference between
+        // 68 chunked copies and one copy of the same 2 GiB) overlap the other stream's transfer instead of idling the link.
+        hipStream_t cs = (h2d_streams == 2 && (i & 1)) ? ctx->in_stream2 : ctx->in_stream;
+        if (i >= (uint64_t)S) HIP_TRY(hipStreamWaitEvent(cs, ctx->ev_rec[k], 0));  // chunk i - S's kernels have read d_in[k]
+        HIP_TRY(hipMemcpyAsync(ctx->d_in[k], ctx->pin_in[k], clen, hipMemcpyHostToDevice, cs));
+        HIP_TRY(hipEventRecord(ctx->ev_in[k], cs));
         {
             std::lock_guard<std::mutex> g(sh.m);
             sh.h2d = i + 1;

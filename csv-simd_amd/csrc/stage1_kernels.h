@@ -137,7 +137,7 @@ hipError_t launch_utf8_validate(const void* dbuf, uint64_t len, void* d_result, 
 hipError_t launch_trim_spans(const void* dbytes, void* d_begin, void* d_end, uint64_t n, uint32_t flags,
                              uint32_t quote, hipStream_t stream);
 // ingest: a chunk's tape (u64, device) -> 32-bit chunk-relative offsets in a pinned host slot; count read on the device
-hipError_t launch_narrow_tape(const void* d_tape, const void* d_result, uint64_t cap, uint64_t base, void* d_out, int n_cus,
+hipError_t launch_narrow_tape(const void* d_tape, const void* d_result, uint64_t cap, uint64_t base, void* d_out, int workgroups,
                               hipStream_t stream);
 int stage1_max_blocks_per_cu();
 

@@ -279,10 +279,11 @@ __global__ __launch_bounds__(256) void narrow_tape_kernel(const u64* __restrict_
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) out[4 * n4 + threadIdx.x] = (u32)(tape[4 * n4 + threadIdx.x] - base);
 }
 
-hipError_t launch_narrow_tape(const void* d_tape, const void* d_result, u64 cap, u64 base, void* d_out, int n_cus,
+hipError_t launch_narrow_tape(const void* d_tape, const void* d_result, u64 cap, u64 base, void* d_out, int workgroups,
                               hipStream_t stream) {
-    // 16-byte aligned tape and slot (hipMalloc / hipHostMalloc); a modest grid: the kernel is bound by the PCIe writes
-    hipLaunchKernelGGL(narrow_tape_kernel, dim3((u32)(n_cus > 0 ? n_cus : 256)), dim3(256), 0, stream, (const u64*)d_tape,
+    // 16-byte aligned tape and slot (hipMalloc / hipHostMalloc); the caller sizes the grid to the bytes it expects
+    // (capi.cpp: the writes cross PCIe against the H2D copies' read requests, and are better trickled than dumped)
+    hipLaunchKernelGGL(narrow_tape_kernel, dim3((u32)(workgroups > 0 ? workgroups : 1)), dim3(256), 0, stream, (const u64*)d_tape,
                        (const csvsimd_shard_result*)d_result, cap, base, (u32*)d_out);
     return hipGetLastError();
 }

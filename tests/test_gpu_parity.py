@@ -537,7 +537,7 @@ def test_host_ingest_three_threads_many_slot_reuses(pkg, oracle, monkeypatch):
             got = c.read(d)
             assert got.size == want.size and np.array_equal(got, want), rep
             ph = pkg.ingest_last_phases()
-            assert ph["host_threads"] == 3 and ph["chunks"] == 44 and ph["bytes"] == n
+            assert ph["host_threads"] == 3 and ph["chunks"] == 43 and ph["bytes"] == n
             assert ph["wall"] > 0 and ph["stage_copy"] > 0 and ph["expand_copy"] > 0
         rc, cnt, q = c.read_into(d, None)                              # count only: no expander
         assert rc == 0 and cnt == want.size and q == int(np.count_nonzero(d == 0x22) & 1)
