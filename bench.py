@@ -554,6 +554,57 @@ def ingest_leg(pkg, device, host, width, closed_form):
                     "slot -> caller's tape (an expander thread); PCIe-inclusive, never part of `value`"}
 
 
+def latency_leg(pkg, oracle, device):
+    """The drop-in on SMALL inputs (the reference's only real inputs are 96-623 bytes: res/*.csv, src/lib.rs:52-74):
+    end-to-end wall time of csvsimd_stage1_index — host bytes in, host tape out — with ONE context kept across calls
+    (rust/reader_hip.rs holds it per thread), next to ref_sse_1t (the oracle's restatement of reader::read, one thread,
+    growing Vec) on the same bytes on this host, and the size where the GPU path starts to win.  Up to 1 MiB the call is
+    one launch over pinned, GPU-mapped memory (no copy engine); above, the chunked pipeline."""
+    t0 = time.perf_counter()
+    ctx = pkg.Context(device.index)
+    create_ms = (time.perf_counter() - t0) * 1e3
+    fixture = os.path.join(ROOT, "tests", "golden", "sample.csv")       # the reference's res/sample.csv (300 bytes)
+    cols, width, seed, q = pkg.WORKLOADS["16x32_q10"]
+    cases = [("res/sample.csv", np.frombuffer(open(fixture, "rb").read(), dtype=np.uint8))]
+    for nbytes in (4 << 10, 64 << 10, 256 << 10, 1 << 20, 4 << 20, 32 << 20):
+        cases.append((f"16x32_q10 {nbytes >> 10} KiB", oracle.synth(0, nbytes, cols, width, seed, q)))
+    rows, ok, first_us = [], True, None
+    for name, data in cases:
+        host = oracle.aligned_copy(data)
+        tape = np.zeros(host.size // 8 + 64, dtype=np.uint64)
+        t0 = time.perf_counter()
+        rc, tl, _ = ctx.read_into(host, tape)                             # first call at this size: allocations included
+        first = (time.perf_counter() - t0) * 1e6
+        first_us = first if first_us is None else first_us
+        want = oracle.sse_read(host)
+        ok = ok and rc == 0 and tl == want.size and bool(np.array_equal(tape[:tl], want))
+        reps = 300 if host.size <= (1 << 20) else 30
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            rc, tl, _ = ctx.read_into(host, tape)
+            ts.append(time.perf_counter() - t0)
+            ok = ok and rc == 0
+        cs = []
+        for _ in range(min(reps, 100)):
+            _, dt = oracle.sse_read_growing_timed(host)
+            cs.append(dt)
+        g_best, g_med, c_best = min(ts) * 1e6, sorted(ts)[len(ts) // 2] * 1e6, min(cs) * 1e6
+        rows.append({"input": name, "bytes": int(host.size), "gpu_us_best": round(g_best, 1), "gpu_us_median": round(g_med, 1),
+                     "first_call_us": round(first, 1), "cpu_ref_sse_1t_us_best": round(c_best, 1),
+                     "gpu_over_cpu": round(g_best / c_best, 2)})
+    ctx.close()
+    cross = next((r for r in rows if r["gpu_us_best"] < r["cpu_ref_sse_1t_us_best"]), None)
+    below = [r for r in rows if cross and r["bytes"] < cross["bytes"]]
+    return {"context_create_ms": round(create_ms, 2), "first_read_us": round(first_us, 1), "sizes": rows,
+            "crossover": (f"the GPU path is faster from {cross['bytes']} bytes up" +
+                          (f" (slower at {below[-1]['bytes']} bytes and below)" if below else "")) if cross
+                         else "the CPU path is faster at every size measured",
+            "verified": bool(ok),
+            "note": "wall time of csvsimd_stage1_index (pageable host bytes -> host tape) with a context kept across calls; "
+                    "cpu = the oracle's ref_sse_1t on the same bytes, same host, one thread like the reference"}
+
+
 def consumer_traffic(key):
     """HBM bytes per launch of a consumer kernel from the committed PMC profile (separate --pmc passes over
     `bench.py --only-consumers`, scripts/collect_profiles_consumers.sh), or None."""
@@ -933,6 +984,7 @@ def main():
                     help="do the sharded step inside the C ABI (csvsimd_stage1_index_sharded: ncclAllGather "
                          "from C++) instead of torch.distributed.all_gather_into_tensor")
     ap.add_argument("--only-batch", action="store_true", help="development: run the `batch_many_files` leg alone")
+    ap.add_argument("--only-latency", action="store_true", help="development: run the `latency` leg alone")
     ap.add_argument("--only-consumers", action="store_true",
                     help="development / profiling: run the `consumers` leg alone and print its record (not the "
                          "contract line)")
@@ -983,6 +1035,9 @@ def main():
         return
     if args.only_batch:
         print(json.dumps({"batch_many_files": batch_leg(pkg, device)}))
+        return
+    if args.only_latency:
+        print(json.dumps({"latency": latency_leg(pkg, oracle or graft.load_oracle(), device)}))
         return
 
     strong = args.scaling == "strong"
@@ -1167,6 +1222,8 @@ def main():
             out["consumers"] = consumers_leg(pkg, oracle, device)
             failed = failed or not out["consumers"]["verified"]
         if not args.no_ingest:
+            out["latency"] = latency_leg(pkg, oracle, device)
+            failed = failed or not out["latency"]["verified"]
             out["ingest"] = ingest_leg(pkg, device, sample, main_width, closed_form=(not main_q and main_lo == 0))
             failed = failed or not out["ingest"]["verified"]
     # ---- the CPU beside it, same bytes, same run, at EVERY N (rank 0's host cores) -------------------------------

@@ -289,6 +289,12 @@ struct csvsimd_ctx {
     csvsimd_shard_result* d_res[kSlots] = {};
     csvsimd_shard_result* h_res = nullptr;     // pinned, kSlots records
     hipEvent_t ev_rec[kSlots] = {};            // result record of the slot's chunk has landed in h_res[k] (and its tape in pin_out[k])
+    // small files (<= kSmallBytes) through the host-buffer entry point: ONE launch that reads the bytes from a pinned block
+    // and writes tape and record into another, both mapped into the GPU's address space — no copy engine, no second stream
+    static constexpr uint64_t kSmallBytes = 1ull << 20;
+    void* pin_small_in = nullptr;             // kSmallBytes + 64
+    void* pin_small_out = nullptr;            // [0, 64): the launch's result record; [64, ...): its tape (u64)
+    uint64_t pin_small_out_entries = 0;
     std::unique_ptr<CopyPool> copier;         // host-side slices of the staging copies
     void* d_batch = nullptr;                  // csvsimd_stage1_index_batch_device_async: the buffers' table block
     size_t d_batch_bytes = 0;
@@ -384,6 +390,8 @@ void csvsimd_ctx_destroy(csvsimd_ctx* ctx) {
         if (ctx->ev_in[k]) (void)hipEventDestroy(ctx->ev_in[k]);
         if (ctx->ev_rec[k]) (void)hipEventDestroy(ctx->ev_rec[k]);
     }
+    if (ctx->pin_small_in) (void)hipHostFree(ctx->pin_small_in);
+    if (ctx->pin_small_out) (void)hipHostFree(ctx->pin_small_out);
     if (ctx->in_stream) (void)hipStreamDestroy(ctx->in_stream);
     if (ctx->in_stream2) (void)hipStreamDestroy(ctx->in_stream2);
     if (ctx->h_res) (void)hipHostFree(ctx->h_res);
@@ -673,12 +681,12 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
 static int stage1_index_host_impl(csvsimd_ctx* ctx, const csvsimd_dialect* dialect, const uint8_t* buf, uint64_t len,
                                   uint64_t* tape, uint64_t tape_cap, uint64_t* tape_len, uint32_t* in_quote_out) {
     const int rc = stage1_index_host_body(ctx, dialect, buf, len, tape, tape_cap, tape_len, in_quote_out);
-    if (rc != CSVSIMD_OK && rc != CSVSIMD_ERR_TAPE_CAPACITY && ctx && ctx->in_stream && ctx->pipe_stream) {
+    if (rc != CSVSIMD_OK && rc != CSVSIMD_ERR_TAPE_CAPACITY && ctx && ctx->pipe_stream) {
         // an error exit in mid-pipeline leaves copies and kernels in flight on the pinned slots: drain the
         // streams so the next call (or the caller freeing `buf` / `tape`) cannot race them
         const std::string keep = g_last_error;
         ScopedDevice scoped_device_(ctx->device);
-        (void)hipStreamSynchronize(ctx->in_stream);
+        if (ctx->in_stream) (void)hipStreamSynchronize(ctx->in_stream);
         if (ctx->in_stream2) (void)hipStreamSynchronize(ctx->in_stream2);
         (void)hipStreamSynchronize(ctx->pipe_stream);
         (void)hipGetLastError();
@@ -747,11 +755,70 @@ extern "C" int csvsimd_ingest_last_phases(csvsimd_ingest_phases* out) {
     return CSVSIMD_OK;
 }
 
+// A file of at most kSmallBytes (the reference's own inputs are 96 to 623 bytes, res/*.csv): the pipeline above would
+// spend its time in set-up.  Here: memcpy into a pinned block, ONE stage-1 launch whose input, tape and result record
+// all live in pinned host memory that the GPU addresses directly, one wait, memcpy of the entries.  Nothing is copied
+// by an engine, nothing crosses streams.  (PCIe reads at ~36 GiB/s: from a megabyte up the staged pipeline wins.)
+static int stage1_index_host_small(csvsimd_ctx* ctx, const csvsimd_dialect* dialect, const uint8_t* buf, uint64_t len,
+                                   uint64_t* tape, uint64_t tape_cap, uint64_t* tape_len, uint32_t* in_quote_out) {
+    const double t_begin = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    if (!ctx->pipe_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->pipe_stream, hipStreamNonBlocking));
+    if (!ctx->pin_small_in) HIP_TRY(hipHostMalloc(&ctx->pin_small_in, csvsimd_ctx::kSmallBytes + 64, hipHostMallocDefault));
+    auto ensure_out = [&](uint64_t entries) -> int {
+        if (ctx->pin_small_out && ctx->pin_small_out_entries >= entries) return CSVSIMD_OK;
+        if (ctx->pin_small_out) HIP_TRY(hipHostFree(ctx->pin_small_out));
+        ctx->pin_small_out = nullptr;
+        ctx->pin_small_out_entries = 0;
+        const uint64_t want = std::max<uint64_t>(entries, 8192);
+        HIP_TRY(hipHostMalloc(&ctx->pin_small_out, 64 + want * 8, hipHostMallocDefault));
+        ctx->pin_small_out_entries = want;
+        return CSVSIMD_OK;
+    };
+    // first guess: an entry per 4 bytes (what fits is kept for the next call: a caller that reads many small files
+    // allocates once)
+    int rc = ensure_out(tape ? std::max<uint64_t>(len / 4, 64) : 0);
+    if (rc != CSVSIMD_OK) return rc;
+    if (len) memcpy(ctx->pin_small_in, buf, len);
+    csvsimd_shard_result r;
+    for (int attempt = 0;; ++attempt) {
+        void *d_in = nullptr, *d_out = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&d_in, ctx->pin_small_in, 0));
+        HIP_TRY(hipHostGetDevicePointer(&d_out, ctx->pin_small_out, 0));
+        const uint64_t cap = tape ? ctx->pin_small_out_entries : 0;
+        rc = stage1_async_impl(ctx, dialect, d_in, len, 0, 0, tape ? (char*)d_out + 64 : nullptr, cap, d_out, ctx->pipe_stream);
+        if (rc != CSVSIMD_OK) return rc;
+        HIP_TRY(hipStreamSynchronize(ctx->pipe_stream));
+        r = *reinterpret_cast<const csvsimd_shard_result*>(ctx->pin_small_out);
+        if (r.error) { g_last_error = "stage1 kernel: look-back spin bound hit"; return CSVSIMD_ERR_INTERNAL; }
+        if (!tape || r.count <= cap) break;
+        if (attempt) return CSVSIMD_ERR_INTERNAL;
+        rc = ensure_out(r.count);  // denser than one entry per 4 bytes: exact capacity, once more
+        if (rc != CSVSIMD_OK) return rc;
+    }
+    const uint64_t n = 1 + r.count;
+    if (tape && tape_cap >= 1) {
+        tape[0] = 0;  // src/reader.rs:216
+        const uint64_t ncopy = std::min<uint64_t>(tape_cap - 1, r.count);
+        if (ncopy) memcpy(tape + 1, (const char*)ctx->pin_small_out + 64, ncopy * 8);
+    }
+    g_ingest_phases = csvsimd_ingest_phases{};
+    g_ingest_phases.bytes = len;
+    g_ingest_phases.chunks = len ? 1 : 0;
+    g_ingest_phases.host_threads = 1;
+    g_ingest_phases.wall = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_begin;
+    *tape_len = n;
+    if (in_quote_out) *in_quote_out = r.in_quote_out;
+    if (tape && n > tape_cap) return CSVSIMD_ERR_TAPE_CAPACITY;
+    return CSVSIMD_OK;
+}
+
 static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* dialect, const uint8_t* buf, uint64_t len,
                                   uint64_t* tape, uint64_t tape_cap, uint64_t* tape_len, uint32_t* in_quote_out) {
     if (!ctx || (len && !buf) || (!tape && tape_cap) || !tape_len) return CSVSIMD_ERR_INVALID_ARG;
     if (dialect_check(dialect) != CSVSIMD_OK) return CSVSIMD_ERR_INVALID_ARG;
     WITH_DEVICE_OF(ctx);
+    if (len <= csvsimd_ctx::kSmallBytes && !getenv("CSVSIMD_INGEST_CHUNK_MIB"))
+        return stage1_index_host_small(ctx, dialect, buf, len, tape, tape_cap, tape_len, in_quote_out);
     constexpr uint64_t kMiB = 1ull << 20, kMax = csvsimd_ctx::kChunk;
     constexpr int S = csvsimd_ctx::kSlots;
     uint64_t uniform = 0;
@@ -908,6 +975,7 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
             int rc_ = pipe_ensure_tape(ctx, k, r.count);  // waits for pipe_stream
             if (rc_ != CSVSIMD_OK) return rc_;
             slot[k].cap = std::min(ctx->d_tape_entries[k], ctx->pin_out_entries[k]);
+            entries_per_byte = (double)r.count / (double)std::max<uint64_t>(1, cuts[j + 1] - cuts[j]);  // now known exactly
             rc_ = launch(k, false);
             if (rc_ != CSVSIMD_OK) return rc_;
             HIP_TRY(hipEventSynchronize(ctx->ev_rec[k]));

@@ -12,9 +12,11 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "csv_simd.hpp"
@@ -183,6 +185,25 @@ void create_sample_rx(csvsimd_ctx* ctx, const std::string& dir) {  // BOM + CRLF
     CHECK(saw_quoted_comma);
 }
 
+// A host that reads file after file keeps ONE context (rust/reader_hip.rs holds it per thread): what a read of the
+// reference's own 300-byte fixture costs once the context exists.  (The figure is reported by bench.py's latency leg;
+// the bound here only catches a context rebuilt per call: hipMalloc + pinned allocations cost milliseconds.)
+void repeated_reads_one_context(csvsimd_ctx* ctx, const std::string& dir) {
+    Mmap memmap;
+    CHECK(memmap.open(dir + "/sample.csv"));
+    std::vector<std::uint64_t> first, again;
+    CHECK(reader_read(ctx, memmap, first) && first.size() == 46);
+    double best = 1e9;
+    for (int rep = 0; rep < 20; ++rep) {
+        const auto t0 = std::chrono::steady_clock::now();
+        CHECK(reader_read(ctx, memmap, again));
+        best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+        CHECK(again == first);
+    }
+    std::printf("  second read() of sample.csv (300 B), same context: %.1f us (best of 20)\n", best);
+    CHECK(best < 1000.0);
+}
+
 }  // namespace
 
 // in-process entry (tests/test_native_cpp.py loads libreference_tests.so with ctypes for the GPU part:
@@ -209,6 +230,8 @@ extern "C" int run_reference_tests(int gpu, const char* golden_dir) {
         create_sample(ctx, dir);
         std::printf("test create(sample_rx.csv)\n");
         create_sample_rx(ctx, dir);
+        std::printf("test repeated reads, one context\n");
+        repeated_reads_one_context(ctx, dir);
         csvsimd_ctx_destroy(ctx);
     } else {
         // no GPU: the library must refuse loudly, never fall back
