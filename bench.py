@@ -681,44 +681,71 @@ def consumers_leg(pkg, oracle, device):
                          "note": "row-major file + tape read once (rows staged through LDS), every column written with "
                                  "1-KiB wave stores; ms = device time per call (events around 10 back-to-back asynchronous "
                                  "calls)"}
-    # ---- frequency count of one column (all values distinct: the table's worst case) -------------------------------
-    slots = 1 << 22
-    scratch = torch.empty(pkg.columnar_frequency_scratch_bytes(slots), dtype=torch.uint8, device=device)
+    # ---- frequency count of one column (all values distinct: the worst case) ----------------------------------------
+    need = pkg.columnar_frequency_scratch_bytes(nrec)
+    scratch = torch.empty(need, dtype=torch.uint8, device=device)
     ent = torch.empty((nrec + 8, 2), dtype=torch.int64, device=device)
+    d_status = torch.zeros(4, dtype=torch.int64, device=device)
     col_ptr, len_ptr = ccols[field].data_ptr(), clens[field].data_ptr()
-    t, st = best(lambda: pkg.columnar_frequency_device(ctx, col_ptr, len_ptr, nrec, stride, 0, scratch.data_ptr(), slots,
-                                                       ent.data_ptr(), ent.shape[0]))
-    ok = ok and st.n_records == nrec and st.truncated == 0 and int(ent[: st.n_distinct, 1].sum()) == nrec
+
+    def device_time(fn, reps=10):
+        """the call is asynchronous (two launches): events on the launch stream around `reps` back-to-back calls"""
+        t_ = None
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            e1.synchronize()
+            dt_ = e0.elapsed_time(e1) * 1e-3 / reps
+            t_ = dt_ if t_ is None else min(t_, dt_)
+        return t_
+
+    s_ = torch.cuda.current_stream(device).cuda_stream
+    t_wall, st = best(lambda: pkg.columnar_frequency_device(ctx, col_ptr, len_ptr, nrec, stride, 0, scratch.data_ptr(), need,
+                                                            ent.data_ptr(), ent.shape[0]))
+    t = device_time(lambda: pkg.columnar_frequency_device_async(ctx, col_ptr, len_ptr, nrec, stride, 0, scratch.data_ptr(), need,
+                                                                ent.data_ptr(), ent.shape[0], d_status.data_ptr(), s_))
+    ok = ok and st.n_records == nrec and st.truncated == 0 and st.overflow == 0 and int(ent[: st.n_distinct, 1].sum()) == nrec
+    ok = ok and d_status.cpu().tolist() == [nrec, st.n_distinct, 0, 0]
     # the CPU definition on a bounded sample: first 50 k records
     host = dbytes[: 50001 * cols * (width + 1)].cpu().numpy().tobytes()
     hidx = dindex[: 50001 * cols + 1].cpu().numpy().view(np.uint64)
     sample = (0, cols, 50001 * cols, 50000)
     want = oracle.column_frequency(host, hidx, cols, False, [sample], field)
-    st_s = pkg.columnar_frequency_device(ctx, col_ptr, len_ptr, 50000, stride, 0, scratch.data_ptr(), slots, ent.data_ptr(),
+    st_s = pkg.columnar_frequency_device(ctx, col_ptr, len_ptr, 50000, stride, 0, scratch.data_ptr(), need, ent.data_ptr(),
                                          ent.shape[0])
     got = {oracle.seek_field(host, hidx, cols, False, f_, field): c for f_, c in ent[: st_s.n_distinct].cpu().tolist()}
     ok = ok and got == dict(want)
-    alg_f = nrec * (stride + 4) + nrec * 16
-    res["frequency_count"] = {"ms": round(t * 1e3, 3), "distinct": int(st.n_distinct),
+    alg_f = nrec * (stride + 4) + int(st.n_distinct) * 16
+    tr_f = consumer_traffic("colfreq")
+    res["frequency_count"] = {"ms": round(t * 1e3, 4), "wall_ms_one_call_plus_sync": round(t_wall * 1e3, 3),
+                              "distinct": int(st.n_distinct),
                               "algorithmic_bytes": alg_f, "GBps_algorithmic": round(alg_f / t / 1e9, 1),
-                              "hbm_traffic_bytes_profiled": consumer_traffic("colfreq"),
-                              "hbm_traffic_bytes_table_memset": slots * 16,
-                              "note": "on the column: memset of the table, insert (one returning atomic per new value; slots "
-                                      "point at a representative record and compare bytes: exact, no verification pass), "
-                                      "compact; algorithmic bytes = the column + its lengths read, 16 B per distinct value "
-                                      "written"}
-    # ... and of a column of FEW distinct values (100 of them over the same 2.03 M records): the workgroup-local LDS stage
-    # keeps the hot values off the global table (all 2 M records would otherwise hammer 100 slots)
+                              "hbm_traffic_bytes_profiled": tr_f,
+                              "traffic_over_algorithmic": round(tr_f / alg_f, 3) if tr_f else None,
+                              "scratch_bytes": need,
+                              "note": "on the column, two launches, no table in device memory and nothing cleared per call: slabs "
+                                      "of 8 192 records aggregate in LDS and leave (first record, count, hash) tuples partitioned "
+                                      "by hash, partitions merge in LDS (bytes compared: exact) and write their entries; ms = "
+                                      "device time per call (events around 10 back-to-back asynchronous calls); algorithmic "
+                                      "bytes = the column + its lengths read, 16 B per distinct value written"}
+    # ... and of a column of FEW distinct values (100 of them over the same 2.03 M records): the slabs' LDS tables collapse
+    # them to ~100 tuples per workgroup
     vocab = ccols[field][:100].clone()
     pick = torch.randint(0, 100, (nrec,), device=device)
     few = vocab[pick].contiguous()
-    t_few, st_few = best(lambda: pkg.columnar_frequency_device(ctx, few.data_ptr(), 0, nrec, stride, 0, scratch.data_ptr(), slots,
-                                                           ent.data_ptr(), ent.shape[0]))
+    t_few_wall, st_few = best(lambda: pkg.columnar_frequency_device(ctx, few.data_ptr(), 0, nrec, stride, 0, scratch.data_ptr(), need,
+                                                                    ent.data_ptr(), ent.shape[0]))
+    t_few = device_time(lambda: pkg.columnar_frequency_device_async(ctx, few.data_ptr(), 0, nrec, stride, 0, scratch.data_ptr(),
+                                                                    need, ent.data_ptr(), ent.shape[0], d_status.data_ptr(), s_))
     cnt_few = torch.bincount(pick, minlength=100)
     got_few = ent[: st_few.n_distinct].cpu()
     ok = ok and st_few.n_distinct == 100 and int(got_few[:, 1].sum()) == nrec
     ok = ok and sorted(got_few[:, 1].tolist()) == sorted(cnt_few.cpu().tolist())
-    res["frequency_count"]["few_distinct_values"] = {"ms": round(t_few * 1e3, 3), "distinct": int(st_few.n_distinct)}
+    res["frequency_count"]["few_distinct_values"] = {"ms": round(t_few * 1e3, 4), "wall_ms_one_call_plus_sync": round(t_few_wall * 1e3, 3),
+                                                     "distinct": int(st_few.n_distinct)}
     del few, pick
     # ---- search -----------------------------------------------------------------------------------------------------
     needle = host[int(hidx[1000 * cols + field]) + 4: int(hidx[1000 * cols + field]) + 10]
@@ -742,32 +769,36 @@ def consumers_leg(pkg, oracle, device):
         pkg.gather_fields_device(args[0], n, b.data_ptr(), e.data_ptr(), nrec, dst.data_ptr(), 32)
     t_g, _ = best(spans_gather)
     ok = ok and torch.equal(dst.view(nrec, 32), ccols[field])
-    slots_o = 1 << 22
-    scratch_o = torch.empty(pkg.column_frequency_scratch_bytes(slots_o), dtype=torch.uint8, device=device)
+    need_o = pkg.column_frequency_scratch_bytes(nrec, 1, width)
+    scratch_o = torch.empty(need_o, dtype=torch.uint8, device=device)
     ent_o = torch.empty((nrec + 8, 4), dtype=torch.int64, device=device)
-    t_f, st_o = best(lambda: pkg.column_frequency_device(ctx, *args, [whole], field, scratch_o.data_ptr(), slots_o,
+    t_f, st_o = best(lambda: pkg.column_frequency_device(ctx, *args, [whole], field, scratch_o.data_ptr(), need_o,
                                                          ent_o.data_ptr(), ent_o.shape[0]))
-    ok = ok and st_o.n_distinct == st.n_distinct
+    ok = ok and st_o.n_distinct == st.n_distinct and st_o.max_field_bytes == width and int(ent_o[: st_o.n_distinct, 3].sum()) == nrec
     t_s, hits_o = best(lambda: pkg.column_search_device(ctx, args[0], n, *args[1:], whole, field, needle, pkg.SEARCH_CONTAINS,
                                                         bm.data_ptr()))
     ok = ok and hits_o == hits
     res["per_column_on_row_major_file"] = {"spans_plus_gather_ms": round(t_g * 1e3, 3), "frequency_count_ms": round(t_f * 1e3, 3),
                                            "search_contains_ms": round(t_s * 1e3, 3),
                                            "note": "one column per call straight from the row-major file (a 32-byte field of a "
-                                                   "528-byte row costs 1-2 sectors + a slice of tape per record)"}
+                                                   "528-byte row costs 1-2 sectors + a slice of tape per record); the frequency "
+                                                   "count = spans + gather + the columnar count above (one implementation), two "
+                                                   "synchronisations"}
     res["verified"] = bool(ok)
     ctx.close()
     return res
 
 
-def batch_leg(pkg, device):
-    """Many files: 8 buffers of 128 MiB (the 16x32 corpus, whole rows each) indexed by EIGHT launches back to back and by
+def batch_leg(pkg, device, k=8):
+    """Many files: k buffers of 128 MiB (the 16x32 corpus, whole rows each) indexed by k launches back to back and by
     ONE batched launch (csvsimd_stage1_index_batch_device_async: the tiles of all buffers share one ticket, a look-back
-    stops at its buffer's first tile).  A launch's fixed cost (fill + drain, ~20 us) is paid once instead of eight times.
+    stops at its buffer's first tile).  A launch's fixed cost (fill + drain, ~20 us) is paid once instead of k times.
+    k = 8 is 1 GiB per launch: the one fixed cost still weighs 9 % there, exactly as for ONE 1-GiB buffer; k = 64 is
+    8 GiB per launch, where the batch runs at the rate of a single 8-GiB buffer.
     Times = torch events on the launch stream around 20 repetitions after a settle; every tape checked against the closed form."""
     name = "16x32_noquote"
     cols, width, seed, q = pkg.WORKLOADS[name]
-    k, per = 8, pkg.workload_len(name, 128 << 20)
+    per = pkg.workload_len(name, 128 << 20)
     pitch = width + 1
     dbuf = torch.empty(k * per, dtype=torch.uint8, device=device)
     pkg.synth_fill_device(dbuf.data_ptr(), 0, k * per, cols, width, seed, q)
@@ -815,8 +846,9 @@ def batch_leg(pkg, device):
     ok = ok and verify()
     ctx.close()
     frac = lambda ms: round(k * per / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
-    return {"workload": f"{k} buffers x {per / 2**20:.0f} MiB of the {name} corpus",
-            "eight_launches_ms": round(ms_sep, 4), "eight_launches_hbm_read_frac": frac(ms_sep),
+    word = {8: "eight", 64: "sixty_four"}.get(k, str(k))
+    return {"workload": f"{k} buffers x {per / 2**20:.0f} MiB of the {name} corpus ({k * per / 2**30:.2f} GiB per batch)",
+            f"{word}_launches_ms": round(ms_sep, 4), f"{word}_launches_hbm_read_frac": frac(ms_sep),
             "one_batched_launch_ms": round(ms_bat, 4), "one_batched_launch_hbm_read_frac": frac(ms_bat),
             "verified": ok}
 
@@ -1034,7 +1066,7 @@ def main():
         print(json.dumps({"consumers": consumers_leg(pkg, oracle or graft.load_oracle(), device)}))
         return
     if args.only_batch:
-        print(json.dumps({"batch_many_files": batch_leg(pkg, device)}))
+        print(json.dumps({"batch_many_files": batch_leg(pkg, device), "at_8_GiB_per_batch": batch_leg(pkg, device, k=64)}))
         return
     if args.only_latency:
         print(json.dumps({"latency": latency_leg(pkg, oracle or graft.load_oracle(), device)}))
@@ -1218,7 +1250,8 @@ def main():
                 del del_sb
             out["other_workloads"] = extra
             out["batch_many_files"] = batch_leg(pkg, device)
-            failed = failed or not out["batch_many_files"]["verified"]
+            out["batch_many_files"]["at_8_GiB_per_batch"] = batch_leg(pkg, device, k=64)
+            failed = failed or not (out["batch_many_files"]["verified"] and out["batch_many_files"]["at_8_GiB_per_batch"]["verified"])
             out["consumers"] = consumers_leg(pkg, oracle, device)
             failed = failed or not out["consumers"]["verified"]
         if not args.no_ingest:

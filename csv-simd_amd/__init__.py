@@ -113,7 +113,7 @@ class _Chunk(C.Structure):
 
 
 class FreqStatus(C.Structure):
-    _fields_ = [("n_records", C.c_uint64), ("n_distinct", C.c_uint64), ("collisions", C.c_uint64),
+    _fields_ = [("n_records", C.c_uint64), ("n_distinct", C.c_uint64), ("max_field_bytes", C.c_uint64),
                 ("overflow", C.c_uint64)]
 
 
@@ -134,7 +134,7 @@ class IngestPhases(C.Structure):
 
 
 SEARCH_EQUALS, SEARCH_STARTS_WITH, SEARCH_CONTAINS = 0, 1, 2
-ABI_VERSION = 3   # what this binding was written against: checked when the library is loaded
+ABI_VERSION = 4   # what this binding was written against: checked when the library is loaded
 
 # every symbol include/csvsimd.h declares: (restype, argtypes)
 _u64p = C.POINTER(C.c_uint64)
@@ -212,7 +212,7 @@ _PROTOTYPES = {
                                                C.c_uint32, C.c_void_p, C.c_void_p]),
     "csvsimd_chunk_field_spans_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(_Chunk),
                                                    C.c_uint32, C.c_void_p, C.c_void_p, _u64p, C.c_void_p]),
-    "csvsimd_column_frequency_scratch_bytes": (C.c_uint64, [C.c_uint64]),
+    "csvsimd_column_frequency_scratch_bytes": (C.c_uint64, [C.c_uint64, C.c_uint32, C.c_uint64]),
     "csvsimd_column_frequency_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int,
                                                   C.POINTER(_Chunk), C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64,
                                                   C.c_void_p, C.c_uint64, C.POINTER(FreqStatus), C.c_void_p]),
@@ -226,6 +226,9 @@ _PROTOTYPES = {
     "csvsimd_columnar_frequency_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
                                                     C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                                     C.POINTER(ColFreqStatus), C.c_void_p]),
+    "csvsimd_columnar_frequency_device_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
+                                                          C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                                          C.c_void_p, C.c_void_p]),
     "csvsimd_columnar_search_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_char_p,
                                                  C.c_uint32, C.c_int, C.c_void_p, _u64p, C.c_void_p]),
     "csvsimd_bitmap_select_scratch_bytes": (C.c_uint64, [C.c_uint64]),
@@ -658,21 +661,25 @@ def chunk_field_spans_device(dindex: int, index_len: int, field_cnt: int, new_li
     return n.value
 
 
-def column_frequency_scratch_bytes(table_slots: int) -> int:
-    return lib().csvsimd_column_frequency_scratch_bytes(table_slots)
+def column_frequency_scratch_bytes(n_records: int, n_chunks: int = 1, max_field_bytes: int = 32) -> int:
+    return lib().csvsimd_column_frequency_scratch_bytes(n_records, n_chunks, max_field_bytes)
 
 
 def column_frequency_device(ctx: "Context", dbytes: int, dindex: int, index_len: int, field_cnt: int, new_line: str,
-                            chunks, field_idx: int, d_scratch: int, table_slots: int, d_entries: int,
-                            entries_cap: int, stream: int = 0) -> FreqStatus:
-    """Exact frequency count of a column over the given chunks; entries (first_record, begin, end, count as
-    4 x uint64) land in d_entries, status.n_distinct of them."""
+                            chunks, field_idx: int, d_scratch: int, scratch_bytes: int, d_entries: int,
+                            entries_cap: int, stream: int = 0, allow_capacity: bool = False) -> FreqStatus:
+    """Exact frequency count of a column of the row-major file over the given chunks; entries (first_record, begin, end,
+    count as 4 x uint64) land in d_entries, status.n_distinct of them.  scratch_bytes: column_frequency_scratch_bytes(
+    records, chunks, longest field) — a scratch too small for the longest field is reported (ERR_TAPE_CAPACITY) with
+    status.max_field_bytes set."""
     arr = (_Chunk * len(chunks))(*[_chunk(c) for c in chunks])
     st = FreqStatus()
-    _check(lib().csvsimd_column_frequency_device(ctx._h, dbytes, dindex, index_len, field_cnt,
-                                                 NEWLINE_CRLF if new_line == "CRLF" else NEWLINE_LF, arr, len(chunks),
-                                                 field_idx, d_scratch, table_slots, d_entries or None, entries_cap,
-                                                 C.byref(st), stream or None))
+    rc = lib().csvsimd_column_frequency_device(ctx._h, dbytes, dindex, index_len, field_cnt,
+                                               NEWLINE_CRLF if new_line == "CRLF" else NEWLINE_LF, arr, len(chunks),
+                                               field_idx, d_scratch, scratch_bytes, d_entries or None, entries_cap,
+                                               C.byref(st), stream or None)
+    if not (rc == ERR_TAPE_CAPACITY and allow_capacity):
+        _check(rc)
     return st
 
 
@@ -708,22 +715,32 @@ def chunk_to_columns_device(ctx: "Context", dbytes: int, bytes_len: int, dindex:
     return n.value
 
 
-def columnar_frequency_scratch_bytes(table_slots: int) -> int:
-    return lib().csvsimd_columnar_frequency_scratch_bytes(table_slots)
+def columnar_frequency_scratch_bytes(n_records: int) -> int:
+    return lib().csvsimd_columnar_frequency_scratch_bytes(n_records)
 
 
 def columnar_frequency_device(ctx: "Context", d_col: int, d_len: int, n_records: int, stride: int, first_record: int,
-                              d_scratch: int, table_slots: int, d_entries: int, entries_cap: int, stream: int = 0,
+                              d_scratch: int, scratch_bytes: int, d_entries: int, entries_cap: int, stream: int = 0,
                               allow_capacity: bool = False) -> ColFreqStatus:
     """Exact frequency count of one column of a columnar copy; entries (first_record, count as 2 x uint64) land in
-    d_entries, status.n_distinct of them."""
+    d_entries, status.n_distinct of them.  Synchronous (the status comes back)."""
     st = ColFreqStatus()
     rc = lib().csvsimd_columnar_frequency_device(ctx._h, d_col or None, d_len or None, n_records, stride, first_record,
-                                                 d_scratch, table_slots, d_entries or None, entries_cap, C.byref(st),
+                                                 d_scratch, scratch_bytes, d_entries or None, entries_cap, C.byref(st),
                                                  stream or None)
     if not (rc == ERR_TAPE_CAPACITY and allow_capacity):
         _check(rc)
     return st
+
+
+def columnar_frequency_device_async(ctx: "Context", d_col: int, d_len: int, n_records: int, stride: int, first_record: int,
+                                    d_scratch: int, scratch_bytes: int, d_entries: int, entries_cap: int, d_status: int,
+                                    stream: int = 0) -> None:
+    """The same as two launches on `stream` and nothing else: the 32-byte status record (n_records, n_distinct, truncated,
+    overflow as 4 x uint64) is written to DEVICE memory at d_status; capturable into a graph."""
+    _check(lib().csvsimd_columnar_frequency_device_async(ctx._h, d_col or None, d_len or None, n_records, stride,
+                                                         first_record, d_scratch, scratch_bytes, d_entries or None,
+                                                         entries_cap, d_status, stream or None))
 
 
 def columnar_search_device(ctx: "Context", d_col: int, d_len: int, n_records: int, stride: int, needle: bytes, mode: int,

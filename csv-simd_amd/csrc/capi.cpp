@@ -334,7 +334,7 @@ int csvsimd_device_count(void) {
     return n;
 }
 
-uint32_t csvsimd_abi_version(void) { return 3; }
+uint32_t csvsimd_abi_version(void) { return 4; }
 uint32_t csvsimd_tile_bytes(void) { return CSVSIMD_TILE_BYTES; }
 
 int csvsimd_ctx_create(int device, csvsimd_ctx** out) {
@@ -1530,51 +1530,92 @@ int csvsimd_gather_fields_device(const void* dbytes, uint64_t bytes_len, const v
     return CSVSIMD_OK;
 }
 
-uint64_t csvsimd_column_frequency_scratch_bytes(uint64_t table_slots) { return table_slots * 32 + 64; }
+// scratch of csvsimd_column_frequency_device: [64 B: max field length, last tape entry | chunk map | begin[n] | end[n] |
+// column n x stride | lengths n x 4 | the count's own scratch | its (row, count) entries n x 16 | its status 64 B]
+namespace {
+struct FreqLayout {
+    uint64_t off_map, off_begin, off_end, off_col, off_len, off_cf, off_ent, off_status, total;
+};
+FreqLayout freq_layout(uint64_t n, uint32_t n_chunks, uint64_t stride) {
+    auto up = [](uint64_t v) { return (v + 255) & ~(uint64_t)255; };
+    FreqLayout L;
+    L.off_map = 64;
+    L.off_begin = up(L.off_map + (uint64_t)n_chunks * 16);
+    L.off_end = up(L.off_begin + n * 8);
+    L.off_col = up(L.off_end + n * 8);
+    L.off_len = up(L.off_col + n * stride);
+    L.off_cf = up(L.off_len + n * 4);
+    L.off_ent = up(L.off_cf + csvsimd::colfreq_scratch_bytes(n));
+    L.off_status = up(L.off_ent + n * 16);
+    L.total = L.off_status + 64;
+    return L;
+}
+uint64_t stride_for(uint64_t max_field_bytes) { return std::max<uint64_t>(16, (max_field_bytes + 15) & ~(uint64_t)15); }
+}  // namespace
+
+uint64_t csvsimd_column_frequency_scratch_bytes(uint64_t n_records, uint32_t n_chunks, uint64_t max_field_bytes) {
+    return freq_layout(n_records, n_chunks ? n_chunks : 1, stride_for(max_field_bytes)).total;
+}
 
 int csvsimd_column_frequency_device(csvsimd_ctx* ctx, const void* dbytes, const void* dindex, uint64_t index_len,
                                     uint32_t field_cnt, int new_line, const csvsimd_chunk* chunks, uint32_t n_chunks,
-                                    uint32_t field_idx, void* d_scratch, uint64_t table_slots, void* d_entries,
+                                    uint32_t field_idx, void* d_scratch, uint64_t scratch_bytes, void* d_entries,
                                     uint64_t entries_cap, csvsimd_freq_status* status, void* hip_stream) {
     return csvsimd_guarded([&]() -> int {
     if (!ctx || !dbytes || !dindex || !chunks || !n_chunks || !d_scratch || !status || (entries_cap && !d_entries))
         return CSVSIMD_ERR_INVALID_ARG;
-    if (table_slots < 64 || (table_slots & (table_slots - 1)) || ((uintptr_t)d_scratch & 15) || ((uintptr_t)d_entries & 7))
-        return CSVSIMD_ERR_INVALID_ARG;
+    if (((uintptr_t)d_scratch & 255) || ((uintptr_t)d_entries & 7)) return CSVSIMD_ERR_INVALID_ARG;
     uint64_t row_size = 0, record_cnt = 0;
     int rc = tape_shape(index_len, field_cnt, new_line, &row_size, &record_cnt);
     if (rc != CSVSIMD_OK) return rc;
     if (field_idx >= field_cnt) return CSVSIMD_ERR_INVALID_ARG;
     WITH_DEVICE_OF(ctx);
     std::vector<uint64_t> rows(n_chunks);
-    for (uint32_t i = 0; i < n_chunks; ++i)
+    struct RowMap { uint64_t row0, first_record; };
+    std::vector<RowMap> map(n_chunks);
+    uint64_t n = 0;
+    for (uint32_t i = 0; i < n_chunks; ++i) {
         if ((rc = chunk_rows(&chunks[i], index_len, row_size, &rows[i])) != CSVSIMD_OK) return rc;
-    hipStream_t s = (hipStream_t)hip_stream;
-    void* d_status = (char*)d_scratch + table_slots * 32;
+        map[i] = RowMap{n, chunks[i].start / row_size - 1};  // seek_field numbering: the header row is not a record
+        n += rows[i];
+    }
+    if (n >= 0xffffffffull) return CSVSIMD_ERR_INVALID_ARG;  // record ids are 32-bit (Tape.record_cnt, src/tape.rs:76)
     static_assert(sizeof(csvsimd_freq_status) == 32 && sizeof(csvsimd_freq_entry) == 32, "layouts shared with the kernels");
-    // a 64-bit hash collision between two different values is detected by the verification pass, never merged:
-    // the count is then repeated with another seed (three tries; 2^-64-ish per pair of distinct values each)
-    for (uint64_t attempt = 0; attempt < 3; ++attempt) {
-        const uint64_t seed = 0x243F6A8885A308D3ull + attempt * 0x9E3779B97F4A7C15ull;
-        HIP_TRY(hipMemsetAsync(d_scratch, 0, table_slots * 32 + 64, s));
-        for (uint32_t i = 0; i < n_chunks; ++i)
-            HIP_TRY(csvsimd::launch_freq_insert(dbytes, dindex, chunks[i].start, row_size, rows[i], field_idx, d_scratch,
-                                                table_slots, d_status, seed, ctx->n_cus, s));
-        for (uint32_t i = 0; i < n_chunks; ++i)
-            HIP_TRY(csvsimd::launch_freq_verify(dbytes, dindex, chunks[i].start, row_size, rows[i], field_idx, d_scratch,
-                                                table_slots, d_status, seed, s));
-        HIP_TRY(csvsimd::launch_freq_compact(d_scratch, table_slots, dindex, row_size, field_idx, d_entries, entries_cap,
-                                             d_status, s));
-        HIP_TRY(hipMemcpyAsync(status, d_status, sizeof(*status), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        if (status->overflow) return CSVSIMD_ERR_TAPE_CAPACITY;  // the table is full: call again with more slots
-        if (status->collisions == 0) break;
-    }
-    if (status->collisions) {
-        g_last_error = "column frequency: hash collisions persisted over three seeds";
-        return CSVSIMD_ERR_INTERNAL;
-    }
-    if (status->n_distinct > entries_cap) return CSVSIMD_ERR_TAPE_CAPACITY;  // status->n_distinct = the size needed
+    *status = csvsimd_freq_status{n, 0, 0, 0};
+    if (n == 0) return CSVSIMD_OK;
+    hipStream_t s = (hipStream_t)hip_stream;
+    // the part of the layout that does not depend on the stride: spans, then the longest field decides the rest
+    FreqLayout L = freq_layout(n, n_chunks, 16);
+    if (scratch_bytes < L.total) return CSVSIMD_ERR_TAPE_CAPACITY;  // (status->max_field_bytes 0: not even the spans fit)
+    char* const base = (char*)d_scratch;
+    HIP_TRY(hipMemsetAsync(base, 0, 64, s));
+    rc = ctx_upload(ctx, base + L.off_map, map.data(), map.size() * sizeof(RowMap), s);
+    if (rc != CSVSIMD_OK) return rc;
+    for (uint32_t i = 0; i < n_chunks; ++i)
+        HIP_TRY(csvsimd::launch_chunk_spans(dindex, chunks[i].start, row_size, field_idx, 1, rows[i],
+                                            base + L.off_begin + map[i].row0 * 8, base + L.off_end + map[i].row0 * 8, s));
+    HIP_TRY(csvsimd::launch_span_stats(base + L.off_begin, base + L.off_end, n, dindex, index_len, base, s));
+    uint64_t stats[2] = {0, 0};  // longest field; the tape's last entry (the file is at least that long + 1)
+    HIP_TRY(hipMemcpyAsync(stats, base, 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    status->max_field_bytes = stats[0];
+    const uint64_t stride = stride_for(stats[0]);
+    if (stride > 0xfffffff0ull) return CSVSIMD_ERR_INVALID_ARG;
+    L = freq_layout(n, n_chunks, stride);
+    if (scratch_bytes < L.total) return CSVSIMD_ERR_TAPE_CAPACITY;  // csvsimd_column_frequency_scratch_bytes(n, n_chunks, status->max_field_bytes)
+    HIP_TRY(csvsimd::launch_gather_fields(dbytes, stats[1] + 1, base + L.off_begin, base + L.off_end, n, base + L.off_col,
+                                          (uint32_t)stride, base + L.off_len, s));
+    HIP_TRY(csvsimd::launch_colfreq(base + L.off_col, base + L.off_len, n, (uint32_t)stride, 0, base + L.off_cf, base + L.off_ent, n,
+                                    base + L.off_status, ctx->n_cus, s));
+    HIP_TRY(csvsimd::launch_freq_entries(base + L.off_ent, base + L.off_status, base + L.off_begin, base + L.off_end,
+                                         base + L.off_map, n_chunks, d_entries, entries_cap, n, s));
+    csvsimd_colfreq_status cs;
+    HIP_TRY(hipMemcpyAsync(&cs, base + L.off_status, sizeof cs, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    status->n_distinct = cs.n_distinct;
+    status->overflow = cs.overflow;
+    if (cs.overflow) return CSVSIMD_ERR_TAPE_CAPACITY;
+    if (cs.n_distinct > entries_cap) return CSVSIMD_ERR_TAPE_CAPACITY;  // status->n_distinct = the size needed
     return CSVSIMD_OK;
     });
 }
@@ -1662,29 +1703,42 @@ int csvsimd_chunk_to_columns_device(csvsimd_ctx* ctx, const void* dbytes, uint64
     });
 }
 
-uint64_t csvsimd_columnar_frequency_scratch_bytes(uint64_t table_slots) { return table_slots * 16 + 64; }
+uint64_t csvsimd_columnar_frequency_scratch_bytes(uint64_t n_records) { return csvsimd::colfreq_scratch_bytes(n_records); }
 
-int csvsimd_columnar_frequency_device(csvsimd_ctx* ctx, const void* d_col, const void* d_len, uint64_t n_records,
-                                      uint32_t stride, uint64_t first_record, void* d_scratch, uint64_t table_slots,
-                                      void* d_entries, uint64_t entries_cap, csvsimd_colfreq_status* status,
-                                      void* hip_stream) {
+int csvsimd_columnar_frequency_device_async(csvsimd_ctx* ctx, const void* d_col, const void* d_len, uint64_t n_records,
+                                            uint32_t stride, uint64_t first_record, void* d_scratch, uint64_t scratch_bytes,
+                                            void* d_entries, uint64_t entries_cap, void* d_status, void* hip_stream) {
     return csvsimd_guarded([&]() -> int {
-    if (!ctx || !d_scratch || !status || (n_records && !d_col) || (entries_cap && !d_entries)) return CSVSIMD_ERR_INVALID_ARG;
-    if (table_slots < 64 || (table_slots & (table_slots - 1)) || ((uintptr_t)d_scratch & 15) || ((uintptr_t)d_entries & 7))
-        return CSVSIMD_ERR_INVALID_ARG;
+    if (!ctx || !d_scratch || !d_status || (n_records && !d_col) || (entries_cap && !d_entries)) return CSVSIMD_ERR_INVALID_ARG;
+    if (((uintptr_t)d_scratch & 15) || ((uintptr_t)d_entries & 7) || ((uintptr_t)d_status & 7)) return CSVSIMD_ERR_INVALID_ARG;
     if (stride == 0 || (stride & 15u) || stride > 4096 || ((uintptr_t)d_col & 15) || ((uintptr_t)d_len & 3) ||
         n_records >= 0xffffffffull)
         return CSVSIMD_ERR_INVALID_ARG;
+    if (scratch_bytes < csvsimd::colfreq_scratch_bytes(n_records)) return CSVSIMD_ERR_TAPE_CAPACITY;
     static_assert(sizeof(csvsimd_colfreq_status) == 32 && sizeof(csvsimd_colfreq_entry) == 16, "layouts shared with the kernels");
     WITH_DEVICE_OF(ctx);
+    HIP_TRY(csvsimd::launch_colfreq(d_col, d_len, n_records, stride, first_record, d_scratch, d_entries, entries_cap, d_status,
+                                    ctx->n_cus, (hipStream_t)hip_stream));
+    return CSVSIMD_OK;
+    });
+}
+
+int csvsimd_columnar_frequency_device(csvsimd_ctx* ctx, const void* d_col, const void* d_len, uint64_t n_records,
+                                      uint32_t stride, uint64_t first_record, void* d_scratch, uint64_t scratch_bytes,
+                                      void* d_entries, uint64_t entries_cap, csvsimd_colfreq_status* status,
+                                      void* hip_stream) {
+    return csvsimd_guarded([&]() -> int {
+    if (!ctx || !status) return CSVSIMD_ERR_INVALID_ARG;
+    // the status record of the synchronous form lives in the context's small device block ([512, 544): nothing else uses it)
+    void* const d_status = (char*)ctx->d_small + 512;
+    const int rc = csvsimd_columnar_frequency_device_async(ctx, d_col, d_len, n_records, stride, first_record, d_scratch,
+                                                           scratch_bytes, d_entries, entries_cap, d_status, hip_stream);
+    if (rc != CSVSIMD_OK) return rc;
+    WITH_DEVICE_OF(ctx);
     hipStream_t s = (hipStream_t)hip_stream;
-    void* d_status = (char*)d_scratch + table_slots * 16;
-    HIP_TRY(hipMemsetAsync(d_scratch, 0, table_slots * 16 + 64, s));
-    HIP_TRY(csvsimd::launch_colfreq_insert(d_col, d_len, n_records, stride, d_scratch, table_slots, d_status, ctx->n_cus, s));
-    HIP_TRY(csvsimd::launch_colfreq_compact(d_scratch, table_slots, first_record, d_entries, entries_cap, d_status, s));
     HIP_TRY(hipMemcpyAsync(status, d_status, sizeof(*status), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    if (status->overflow) return CSVSIMD_ERR_TAPE_CAPACITY;   // the table is full: call again with more slots
+    if (status->overflow) return CSVSIMD_ERR_TAPE_CAPACITY;   // more values with equal hash bits than a partition's table holds
     if (status->truncated) return CSVSIMD_ERR_TAPE_CAPACITY;  // values longer than the stride: counts would merge them
     if (status->n_distinct > entries_cap) return CSVSIMD_ERR_TAPE_CAPACITY;
     return CSVSIMD_OK;

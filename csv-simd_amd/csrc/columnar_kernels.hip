@@ -274,154 +274,302 @@ __device__ __forceinline__ bool rows_equal(const ColView& c, u64 i, u64 j, u32 l
 }
 
 // ---------------------------------------------------------------------------------------------
-// exact frequency count on a column.  Table slot (16 bytes):
-//   key    : tag (upper 32 bits of the hash) << 32 | representative record + 1        0 = empty
-//   extra  : records holding the value beyond the one that claimed the slot
-//   first  : ~(smallest record id among the records that found the slot taken), 0 = none
-// A record looks at a taken slot's representative only if the tags agree, and the slot is its value's only if the
-// bytes are equal: two values with the same hash simply occupy two slots.  One returning atomic (the claim) per new
-// value; a workgroup first aggregates in LDS so that a column of few distinct values does not hammer a handful of
-// global slots.
+// exact frequency count on a column, in two passes and WITHOUT a global hash table (round 4).
+//
+// Rounds 2-3 inserted every value into an open-addressing table in device memory: a 64-MiB table cleared on every
+// call, one returning atomic per new value on a random 16-byte slot (each a whole line through the memory-side
+// atomic path: 3.8-6.1 x the algorithmic bytes, profiles/r03_pmc_consumers.json), a scan of all 4 Mi slots to find
+// the 100 that were used.  Here no record ever touches a shared word in device memory:
+//
+//   pass 1 (colfreq_partition_kernel)  a workgroup owns a slab of 8 192 consecutive records.  It hashes every record,
+//       aggregates repeated values in an LDS table (a column of few distinct values collapses to a handful of tuples
+//       per workgroup), and writes one TUPLE (first record, count, 32 hash bits) per surviving value into its own block
+//       of the scratch, sorted by PARTITION (hash bits 40..) — a counting sort in LDS, so the block is written once,
+//       in place, and the per-partition offsets go to a small table.
+//   pass 2 (colfreq_reduce_kernel)     a workgroup owns a partition: it gathers that partition's run from every block
+//       (the offsets table says where), merges the tuples in an LDS table that is big enough for all of them (values are
+//       equal only if hash bits AND bytes are: a representative record is compared) and writes the partition's entries
+//       (first record, count) straight to the output, reserving its range with ONE atomic per workgroup.
+//
+// Nothing is cleared per call (the status words are written, not accumulated, or zeroed by pass 1), nothing is scanned
+// that was not written, and the call is two launches on the caller's stream: asynchronous and capturable.
+// Algorithmic bytes: the column and its lengths read once, 16 bytes per distinct value written; the tuples add 12 bytes
+// written + read per value that survives pass 1's aggregation.
 // ---------------------------------------------------------------------------------------------
-struct ColFreqSlot {
-    u64 key;
-    u32 extra;
-    u32 first_inv;
-};
 struct ColFreqStatus {  // == csvsimd_colfreq_status
     u64 n_records, n_distinct, truncated, overflow;
 };
-static constexpr u32 kCfLds = 1024;
+struct ColFreqEntry {  // == csvsimd_colfreq_entry
+    u64 first_record, count;
+};
+static constexpr u32 kCfSlab = 8192;         // records per pass-1 workgroup
+static constexpr u32 kCfThreads1 = 1024;
+static constexpr u32 kCfPerThread = kCfSlab / kCfThreads1;
+static constexpr u32 kCfLds = 1024;          // pass-1 LDS table slots
+static constexpr u32 kCfMaxParts = 4096;
+static constexpr u32 kCfCap2 = 8192;         // pass-2 LDS table slots
+static constexpr u32 kCfRound2 = 6144;       // tuples a pass-2 round may be asked to hold (distinct values <= tuples)
+static constexpr u32 kCfThreads2 = 1024;
+static constexpr u32 kCfTupleWords = 3;      // {first record, count, low 32 hash bits}
 
-__device__ __forceinline__ bool colfreq_global_insert(const ColView& c, ColFreqSlot* table, u64 mask, u64 h, u32 rep,
-                                                      u32 len_rep, u32 count, u32 first) {
-    const u64 mine = (h & 0xffffffff00000000ull) | ((u64)rep + 1);
-    u64 s = cmix64(h) & mask;
-    for (u64 probes = 0; probes <= mask; ++probes, s = (s + 1) & mask) {
-        u64 old = __hip_atomic_load(&table[s].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == 0) old = atomicCAS((unsigned long long*)&table[s].key, 0ull, (unsigned long long)mine);
-        if (old == 0) {  // claimed: this record represents the value
-            if (count > 1) atomicAdd(&table[s].extra, count - 1);
-            if (first != rep) atomicMax(&table[s].first_inv, ~first);
-            return true;
-        }
-        if ((old >> 32) == (mine >> 32) && rows_equal(c, rep, (u32)old - 1u, len_rep)) {
-            atomicAdd(&table[s].extra, count);
-            atomicMax(&table[s].first_inv, ~first);
-            return true;
-        }
-    }
-    return false;
+struct ColFreqGeom {
+    u32 slabs;       // W: pass-1 workgroups = tuple blocks
+    u32 parts;       // P: partitions (a power of two)
+    u64 offs_bytes;  // u16 offs[P + 2][W]: row p = where partition p starts in every block, row P = the block's tuple
+                     // count, row P + 1 = records of the slab longer than the stride
+    u64 bytes;       // the whole scratch: [offs | tuples: W blocks of kCfSlab x 12 bytes]
+};
+static ColFreqGeom colfreq_geom(u64 n_rows) {
+    ColFreqGeom g;
+    g.slabs = (u32)((n_rows + kCfSlab - 1) / kCfSlab);
+    if (g.slabs == 0) g.slabs = 1;
+    u64 want = (n_rows + 4095) / 4096;  // ~4 096 records per partition: a pass-2 table is half full when all are distinct
+    u32 p = 1;
+    while (p < want && p < kCfMaxParts) p <<= 1;
+    g.parts = p;
+    g.offs_bytes = (((u64)(g.parts + 2) * g.slabs * 2) + 255) & ~255ull;
+    g.bytes = g.offs_bytes + (u64)g.slabs * kCfSlab * kCfTupleWords * 4 + 256;
+    return g;
 }
+u64 colfreq_scratch_bytes(u64 n_rows) { return colfreq_geom(n_rows).bytes; }
 
-static constexpr u32 kCfInsertThreads = 1024;  // one LDS table, one flush per 8 192 records: a column of few values sends every
-                                               // workgroup to the same global slots, and accesses to one line retire one by one
-__global__ __launch_bounds__(kCfInsertThreads) void colfreq_insert_kernel(const ColView c, ColFreqSlot* __restrict__ table, u64 mask,
-                                                             ColFreqStatus* __restrict__ status) {
-    __shared__ u64 s_key[kCfLds];    // tag << 32 | (record - r0 of this workgroup) + 1
+__device__ __forceinline__ u32 cf_part(u64 h, u32 parts) { return (u32)(h >> 40) & (parts - 1u); }
+
+__global__ __launch_bounds__(kCfThreads1) void colfreq_partition_kernel(const ColView c, unsigned short* __restrict__ offs,
+                                                                       u32* __restrict__ tuples, u32 parts, u32 slabs,
+                                                                       ColFreqStatus* __restrict__ status) {
+    __shared__ u64 s_key[kCfLds];    // hash bits 32..63 << 32 | (record - r0) + 1; 0 = empty
     __shared__ u32 s_count[kCfLds];
-    __shared__ u32 s_first[kCfLds];
-    __shared__ u32 s_fill;
-    for (u32 k = threadIdx.x; k < kCfLds; k += blockDim.x) {
+    __shared__ u32 s_first[kCfLds];  // smallest (record - r0) holding the slot's value
+    __shared__ u32 s_hlo[kCfLds];    // hash bits 0..31 of the slot's value (written by the claimer, read after the barrier)
+    __shared__ u32 s_hmid[kCfLds];   // hash bits 32..63 again, for the partition (cheaper than unpacking the key)
+    __shared__ u32 s_hist[kCfMaxParts];
+    __shared__ u32 s_scan[kCfThreads1];
+    __shared__ u32 s_fill, s_trunc;
+    const u32 t = threadIdx.x, w = blockIdx.x;
+    for (u32 k = t; k < kCfLds; k += kCfThreads1) {
         s_key[k] = 0;
         s_count[k] = 0;
         s_first[k] = 0xffffffffu;
     }
-    if (threadIdx.x == 0) s_fill = 0;
+    for (u32 k = t; k < parts; k += kCfThreads1) s_hist[k] = 0;
+    if (t == 0) {
+        s_fill = 0;
+        s_trunc = 0;
+        if (w == 0) {  // pass 2 (the next launch on this stream) adds to the one and may set the other
+            status->n_distinct = 0;
+            status->overflow = 0;
+        }
+    }
     __syncthreads();
-    u32 overflow = 0, truncated = 0;
-    const u64 per = (c.n_rows + gridDim.x - 1) / gridDim.x;  // contiguous slab of records per workgroup
-    const u64 r0 = (u64)blockIdx.x * per, r1 = r0 + per < c.n_rows ? r0 + per : c.n_rows;
-    for (u64 i = r0 + threadIdx.x; i < r1; i += blockDim.x) {
+    const u64 r0 = (u64)w * kCfSlab;
+    const u32 nrec = (u32)(c.n_rows - r0 < kCfSlab ? c.n_rows - r0 : kCfSlab);
+    // ---- phase A: hash every record; repeated values meet in the LDS table -----------------------------------------
+    u64 hs[kCfPerThread];
+    u32 single = 0, trunc = 0;  // bit j: record j of this thread goes out as its own tuple
+#pragma unroll
+    for (u32 j = 0; j < kCfPerThread; ++j) {
+        const u32 li = j * kCfThreads1 + t;  // consecutive lanes, consecutive records: coalesced loads
+        hs[j] = 0;
+        if (li >= nrec) continue;
+        const u64 i = r0 + li;
         const u32 len = c.len ? c.len[i] : c.stride;
-        if (len > c.stride) ++truncated;
+        if (len > c.stride) ++trunc;
         const u64 h = hash_row(c, i, len);
-        const u64 mine = (h & 0xffffffff00000000ull) | (u64)((u32)(i - r0) + 1u);
+        hs[j] = h;
+        const u64 mine = (h & 0xffffffff00000000ull) | (u64)(li + 1u);
         bool done = false;
-        // a column of many distinct values fills the LDS table with its first rows; from then on new values only find
-        // full probe sequences there, so the probing is limited to a look at the home slot
+        // a column of many distinct values fills the table with its first rows; from then on new values only find full
+        // probe sequences, so the probing is limited to a look at the home slot
         const int max_probes = s_fill < kCfLds * 3 / 4 ? 8 : 1;
         u32 s = (u32)h & (kCfLds - 1);
         for (int p = 0; p < max_probes && !done; ++p, s = (s + 1) & (kCfLds - 1)) {
             u64 old = s_key[s];
             if (old == 0) old = atomicCAS((unsigned long long*)&s_key[s], 0ull, (unsigned long long)mine);
             if (old == 0) {
+                s_hlo[s] = (u32)h;
+                s_hmid[s] = (u32)(h >> 32);
                 atomicAdd(&s_fill, 1u);
                 atomicAdd(&s_count[s], 1u);
-                atomicMin(&s_first[s], (u32)i);
+                atomicMin(&s_first[s], li);
                 done = true;
             } else if ((old >> 32) == (mine >> 32) && rows_equal(c, i, r0 + ((u32)old - 1u), len)) {
                 atomicAdd(&s_count[s], 1u);
-                atomicMin(&s_first[s], (u32)i);
+                atomicMin(&s_first[s], li);
                 done = true;
             }
         }
-        if (!done && !colfreq_global_insert(c, table, mask, h, (u32)i, len, 1u, (u32)i)) ++overflow;
+        if (!done) single |= 1u << j;
+    }
+    if (trunc) atomicAdd(&s_trunc, trunc);
+    __syncthreads();
+    // ---- phase B: counting sort of this workgroup's tuples by partition ----------------------------------------------
+    // every tuple takes a rank within its partition (one returning LDS atomic), the histogram is scanned, and the tuple
+    // goes to block[prefix[partition] + rank]: the block is written once, nothing is staged
+    u32 rank[kCfPerThread + 1], part[kCfPerThread + 1];
+#pragma unroll
+    for (u32 j = 0; j < kCfPerThread; ++j) {
+        part[j] = 0;
+        rank[j] = 0;
+        if ((single >> j) & 1u) {
+            part[j] = cf_part(hs[j], parts);
+            rank[j] = atomicAdd(&s_hist[part[j]], 1u);
+        }
+    }
+    const bool own_slot = t < kCfLds && s_key[t] != 0;  // (kCfLds == kCfThreads1: one table slot per thread)
+    part[kCfPerThread] = rank[kCfPerThread] = 0;
+    if (own_slot) {
+        part[kCfPerThread] = cf_part((u64)s_hmid[t] << 32, parts);
+        rank[kCfPerThread] = atomicAdd(&s_hist[part[kCfPerThread]], 1u);
     }
     __syncthreads();
-    for (u32 k = threadIdx.x; k < kCfLds; k += blockDim.x) {
-        const u64 key = s_key[k];
-        if (!key) continue;
-        const u32 rep = (u32)(r0 + ((u32)key - 1u));
-        const u32 len = c.len ? c.len[rep] : c.stride;
-        // the tag is the upper half of the hash, the global slot comes from the whole hash: recompute it
-        const u64 h = hash_row(c, rep, len);
-        if (!colfreq_global_insert(c, table, mask, h, rep, len, s_count[k], s_first[k])) ++overflow;
+    // exclusive scan of s_hist[0, parts): thread t owns bins [t * per, (t + 1) * per)
+    const u32 per = (parts + kCfThreads1 - 1) / kCfThreads1;  // <= 4
+    u32 local = 0;
+    for (u32 k = 0; k < per; ++k) {
+        const u32 bin = t * per + k;
+        if (bin < parts) local += s_hist[bin];
     }
-    if (overflow) atomicAdd((unsigned long long*)&status->overflow, (unsigned long long)overflow);
-    if (truncated) atomicAdd((unsigned long long*)&status->truncated, (unsigned long long)truncated);
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd((unsigned long long*)&status->n_records, (unsigned long long)c.n_rows);
+    s_scan[t] = local;
+    __syncthreads();
+    for (u32 d = 1; d < kCfThreads1; d <<= 1) {  // Hillis-Steele over 1 024 partial sums
+        const u32 v = t >= d ? s_scan[t - d] : 0u;
+        __syncthreads();
+        s_scan[t] += v;
+        __syncthreads();
+    }
+    u32 run = s_scan[t] - local;  // exclusive prefix of this thread's first bin
+    for (u32 k = 0; k < per; ++k) {
+        const u32 bin = t * per + k;
+        if (bin < parts) {
+            const u32 cnt = s_hist[bin];
+            s_hist[bin] = run;  // the bin's start within the block
+            offs[(u64)bin * slabs + w] = (unsigned short)run;
+            run += cnt;
+        }
+    }
+    if (t == kCfThreads1 - 1) {
+        offs[(u64)parts * slabs + w] = (unsigned short)s_scan[t];          // tuples in this block (<= 8 192)
+        offs[(u64)(parts + 1) * slabs + w] = (unsigned short)s_trunc;      // (<= 8 192 as well)
+    }
+    __syncthreads();
+    u32* const block = tuples + (u64)w * kCfSlab * kCfTupleWords;
+#pragma unroll
+    for (u32 j = 0; j < kCfPerThread; ++j) {
+        if ((single >> j) & 1u) {
+            u32* const q = block + (u64)(s_hist[part[j]] + rank[j]) * kCfTupleWords;
+            const u32 rec = (u32)r0 + j * kCfThreads1 + t;
+            q[0] = rec;
+            q[1] = 1u;
+            q[2] = (u32)hs[j];
+        }
+    }
+    if (own_slot) {
+        u32* const q = block + (u64)(s_hist[part[kCfPerThread]] + rank[kCfPerThread]) * kCfTupleWords;
+        q[0] = (u32)r0 + s_first[t];  // the smallest record holding the value stands for it from here on
+        q[1] = s_count[t];
+        q[2] = s_hlo[t];
+    }
 }
 
-struct ColFreqEntry {  // == csvsimd_colfreq_entry
-    u64 first_record, count;
-};
-// occupied slots -> dense entries; one output reservation per workgroup (a returning atomic on one word retires at
-// ~90 per us chip-wide)
-static constexpr u32 kCfPerThread = 8;
-static constexpr u32 kCfCompactThreads = 1024;  // 8192 slots per reservation: 512 of them for a 4 M-slot table (2048: 23 us of atomics alone)
-__global__ __launch_bounds__(kCfCompactThreads) void colfreq_compact_kernel(const ColFreqSlot* __restrict__ table, u64 slots,
-                                                              u64 first_record, ColFreqEntry* __restrict__ out, u64 out_cap,
-                                                              ColFreqStatus* __restrict__ status) {
-    __shared__ u32 s_wave[kCfCompactThreads / 64];
+__global__ __launch_bounds__(kCfThreads2) void colfreq_reduce_kernel(const ColView c, const unsigned short* __restrict__ offs,
+                                                                    const u32* __restrict__ tuples, u32 parts, u32 slabs,
+                                                                    u64 first_record, ColFreqEntry* __restrict__ out, u64 out_cap,
+                                                                    ColFreqStatus* __restrict__ status) {
+    __shared__ u64 s_key[kCfCap2];    // low 32 hash bits << 32 | representative record + 1; 0 = empty
+    __shared__ u32 s_count[kCfCap2];
+    __shared__ u32 s_first[kCfCap2];
+    __shared__ u32 s_wave[kCfThreads2 / 64];
+    __shared__ u32 s_total, s_overflow;
     __shared__ u64 s_base;
-    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    const u64 chunk = (u64)blockDim.x * kCfPerThread;
-    for (u64 c0 = (u64)blockIdx.x * chunk; c0 < slots; c0 += (u64)gridDim.x * chunk) {
-        u64 masks[kCfPerThread];
-        u32 mine = 0, wave_total = 0;
-#pragma unroll
-        for (u32 j = 0; j < kCfPerThread; ++j) {
-            const u64 sl = c0 + (u64)j * blockDim.x + threadIdx.x;
-            const bool used = sl < slots && table[sl].key != 0;
-            masks[j] = __ballot(used);
-            mine |= (used ? 1u : 0u) << j;
-            wave_total += (u32)__builtin_popcountll(masks[j]);
-        }
-        if (lane == 0) s_wave[w] = wave_total;
+    const u32 t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+    for (u32 p = blockIdx.x; p < parts; p += gridDim.x) {
+        // tuples of this partition over all blocks (a block's run for partition p ends where its run for p + 1 starts;
+        // the last partition's ends at the block's tuple count — row `parts` of the table)
+        if (t == 0) { s_total = 0; s_overflow = 0; }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            u32 tot = 0;
-            for (u32 k = 0; k < kCfCompactThreads / 64; ++k) tot += s_wave[k];
-            s_base = tot ? atomicAdd((unsigned long long*)&status->n_distinct, (unsigned long long)tot) : 0ull;
-        }
+        u32 mine = 0;
+        for (u32 w = t; w < slabs; w += kCfThreads2)
+            mine += (u32)offs[(u64)(p + 1) * slabs + w] - (u32)offs[(u64)p * slabs + w];
+        if (mine) atomicAdd(&s_total, mine);
         __syncthreads();
-        u64 at = s_base;
-        for (u32 k = 0; k < w; ++k) at += s_wave[k];
-#pragma unroll
-        for (u32 j = 0; j < kCfPerThread; ++j) {
-            if ((mine >> j) & 1u) {
-                const u64 o = at + (u64)__builtin_popcountll(masks[j] & ((1ull << lane) - 1ull));
-                if (o < out_cap) {
-                    const ColFreqSlot sl = table[c0 + (u64)j * blockDim.x + threadIdx.x];
-                    u32 first = (u32)sl.key - 1u;
-                    if (sl.first_inv && ~sl.first_inv < first) first = ~sl.first_inv;
-                    out[o] = ColFreqEntry{first_record + first, (u64)sl.extra + 1};
+        const u32 total = s_total;
+        const u32 rounds = total ? (total + kCfRound2 - 1) / kCfRound2 : 0;  // a skewed or huge partition: several passes over its tuples
+        for (u32 r = 0; r < rounds; ++r) {
+            for (u32 k = t; k < kCfCap2; k += kCfThreads2) {
+                s_key[k] = 0;
+                s_count[k] = 0;
+                s_first[k] = 0xffffffffu;
+            }
+            __syncthreads();
+            // 16 lanes per block run: a run is ~16 tuples when all values are distinct, a few when they are not
+            for (u32 w = t >> 4; w < slabs; w += kCfThreads2 >> 4) {
+                const u32 b = offs[(u64)p * slabs + w], e = offs[(u64)(p + 1) * slabs + w];
+                const u32* const block = tuples + (u64)w * kCfSlab * kCfTupleWords;
+                for (u32 i = b + (t & 15u); i < e; i += 16) {
+                    const u32 rec = block[(u64)i * kCfTupleWords], cnt = block[(u64)i * kCfTupleWords + 1],
+                              h32 = block[(u64)i * kCfTupleWords + 2];
+                    if (rounds > 1 && ((h32 >> 13) % rounds) != r) continue;
+                    const u64 key = ((u64)h32 << 32) | ((u64)rec + 1);
+                    const u32 len = c.len ? c.len[rec] : c.stride;
+                    u32 s = h32 & (kCfCap2 - 1);
+                    bool done = false;
+                    for (u32 probes = 0; probes < kCfCap2 && !done; ++probes, s = (s + 1) & (kCfCap2 - 1)) {
+                        u64 old = s_key[s];
+                        if (old == 0) old = atomicCAS((unsigned long long*)&s_key[s], 0ull, (unsigned long long)key);
+                        if (old == 0 || ((old >> 32) == h32 && rows_equal(c, rec, (u32)old - 1u, len))) {
+                            atomicAdd(&s_count[s], cnt);
+                            atomicMin(&s_first[s], rec);
+                            done = true;
+                        }
+                    }
+                    if (!done) s_overflow = 1;  // more distinct values with these hash bits than a table holds
                 }
             }
-            at += (u64)__builtin_popcountll(masks[j]);
+            __syncthreads();
+            // occupied slots -> entries; ONE reservation per workgroup and round
+            u32 used[kCfCap2 / kCfThreads2], wave_total = 0;
+#pragma unroll
+            for (u32 j = 0; j < kCfCap2 / kCfThreads2; ++j) {
+                used[j] = s_key[j * kCfThreads2 + t] != 0 ? 1u : 0u;
+                wave_total += (u32)__builtin_popcountll(__ballot(used[j] != 0));
+            }
+            if (lane == 0) s_wave[wv] = wave_total;
+            __syncthreads();
+            if (t == 0) {
+                u32 tot = 0;
+                for (u32 k = 0; k < kCfThreads2 / 64; ++k) tot += s_wave[k];
+                s_base = tot ? atomicAdd((unsigned long long*)&status->n_distinct, (unsigned long long)tot) : 0ull;
+            }
+            __syncthreads();
+            u64 at = s_base;
+            for (u32 k = 0; k < wv; ++k) at += s_wave[k];
+#pragma unroll
+            for (u32 j = 0; j < kCfCap2 / kCfThreads2; ++j) {
+                const u64 m = __ballot(used[j] != 0);
+                if (used[j]) {
+                    const u64 o = at + (u64)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+                    const u32 slot = j * kCfThreads2 + t;
+                    if (o < out_cap) out[o] = ColFreqEntry{first_record + s_first[slot], (u64)s_count[slot]};
+                }
+                at += (u64)__builtin_popcountll(m);
+            }
+            __syncthreads();
         }
+        if (t == 0 && s_overflow) status->overflow = 1;
+    }
+    if (blockIdx.x == 0) {
+        // the call's totals: records, and how many of them were longer than the stride (pass 1 left a count per block)
+        if (t == 0) s_total = 0;
         __syncthreads();
+        u32 mine = 0;
+        for (u32 w = t; w < slabs; w += kCfThreads2) mine += offs[(u64)(parts + 1) * slabs + w];
+        if (mine) atomicAdd(&s_total, mine);
+        __syncthreads();
+        if (t == 0) {
+            status->n_records = c.n_rows;
+            status->truncated = s_total;
+        }
     }
 }
 
@@ -431,22 +579,21 @@ static u32 cgrid_for(u64 items, u32 per_block, u32 cap) {
     return (u32)(blocks > cap ? cap : blocks);
 }
 
-hipError_t launch_colfreq_insert(const void* d_col, const void* d_len, u64 n_rows, u32 stride, void* d_table, u64 slots,
-                                 void* d_status, int n_cus, hipStream_t stream) {
-    if (n_rows == 0) return hipSuccess;
+hipError_t launch_colfreq(const void* d_col, const void* d_len, u64 n_rows, u32 stride, u64 first_record, void* d_scratch,
+                          void* d_entries, u64 entries_cap, void* d_status, int n_cus, hipStream_t stream) {
+    ColFreqStatus* const status = (ColFreqStatus*)d_status;
+    if (n_rows == 0) return hipMemsetAsync(status, 0, sizeof(ColFreqStatus), stream);
+    const ColFreqGeom g = colfreq_geom(n_rows);
     const ColView c = {(const uint8_t*)d_col, (const u32*)d_len, n_rows, stride};
-    const u32 grid = cgrid_for(n_rows, 8 * kCfInsertThreads, (u32)(n_cus > 0 ? n_cus : 256) * 2);
-    hipLaunchKernelGGL(colfreq_insert_kernel, dim3(grid), dim3(kCfInsertThreads), 0, stream, c, (ColFreqSlot*)d_table, slots - 1,
-                       (ColFreqStatus*)d_status);
-    return hipGetLastError();
-}
-
-hipError_t launch_colfreq_compact(const void* d_table, u64 slots, u64 first_record, void* d_out, u64 out_cap,
-                                  void* d_status, hipStream_t stream) {
-    hipLaunchKernelGGL(colfreq_compact_kernel, dim3(cgrid_for(slots, kCfCompactThreads * kCfPerThread, 4096)),
-                       dim3(kCfCompactThreads), 0, stream,
-                       (const ColFreqSlot*)d_table, slots, first_record, (ColFreqEntry*)d_out, out_cap,
-                       (ColFreqStatus*)d_status);
+    unsigned short* const offs = (unsigned short*)d_scratch;
+    u32* const tuples = (u32*)((char*)d_scratch + g.offs_bytes);
+    hipLaunchKernelGGL(colfreq_partition_kernel, dim3(g.slabs), dim3(kCfThreads1), 0, stream, c, offs, tuples, g.parts, g.slabs,
+                       status);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const u32 cap = (u32)(n_cus > 0 ? n_cus : 256);  // one 144-KiB workgroup per CU
+    hipLaunchKernelGGL(colfreq_reduce_kernel, dim3(g.parts < cap ? g.parts : cap), dim3(kCfThreads2), 0, stream, c, offs, tuples,
+                       g.parts, g.slabs, first_record, (ColFreqEntry*)d_entries, entries_cap, status);
     return hipGetLastError();
 }
 

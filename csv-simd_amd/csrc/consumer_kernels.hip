@@ -103,189 +103,48 @@ __global__ void gather_fields_kernel(const uint8_t* __restrict__ bytes, u64 byte
 }
 
 // ---------------------------------------------------------------------------------------------
-// hashing of a field's bytes: 8 bytes per step (unaligned loads), splitmix-style finish; never 0 (0 = empty slot)
+// frequency count of a column of the ROW-MAJOR file (csvsimd_column_frequency_device).  Rounds 1-3 kept a second
+// counting algorithm here (64-bit hashes in a 32-byte-slot device table + a verification pass over every record:
+// 11-22 x the column's bytes in traffic).  Now the column is gathered once into fixed-stride rows (the two kernels
+// above) and counted by the ONE implementation of columnar_kernels.hip; what is left here is the glue:
+//   span_stats_kernel    the longest field of the column (the gather's stride) and the tape's last entry (how far the
+//                        gather may read)
+//   freq_entries_kernel  the count's (row, count) entries -> csvsimd_freq_entry {record id, text span, count}
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ u64 mix64(u64 z) {
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-__device__ __forceinline__ u64 hash_bytes(const uint8_t* p, u64 n, u64 seed) {
-    u64 h = seed ^ (n * 0x9E3779B97F4A7C15ull);
-    u64 k = 0;
-    for (; k + 8 <= n; k += 8) h = mix64(h ^ *reinterpret_cast<const u64u*>(p + k)) + 0x9E3779B97F4A7C15ull;
-    u64 tail = 0;
-    for (u32 j = 0; k + j < n; ++j) tail |= (u64)p[k + j] << (8 * j);
-    h = mix64(h ^ tail ^ 0xA5A5A5A5A5A5A5A5ull);
-    return h ? h : 1ull;
-}
-__device__ __forceinline__ bool bytes_equal(const uint8_t* a, const uint8_t* b, u64 n) {
-    u64 k = 0;
-    for (; k + 8 <= n; k += 8)
-        if (*reinterpret_cast<const u64u*>(a + k) != *reinterpret_cast<const u64u*>(b + k)) return false;
-    for (; k < n; ++k)
-        if (a[k] != b[k]) return false;
-    return true;
+__global__ __launch_bounds__(256) void span_stats_kernel(const u64* __restrict__ begin, const u64* __restrict__ end, u64 n,
+                                                         const u64* __restrict__ index, u64 index_len, u64* __restrict__ out) {
+    u64 m = 0;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u64 len = end[i] - begin[i];
+        m = len > m ? len : m;
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        const u64 o = ((u64)(u32)__shfl_xor((int)(u32)(m >> 32), d) << 32) | (u32)__shfl_xor((int)(u32)m, d);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63u) == 0 && m) atomicMax((unsigned long long*)&out[0], (unsigned long long)m);
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[1] = index[index_len - 1];
 }
 
-// ---------------------------------------------------------------------------------------------
-// frequency count of a column.  Global open-addressing table of csvsimd_freq_slot {hash, first_row, count}:
-//   insert  : every record hashes its field; a workgroup first aggregates in an LDS table (a column of few
-//             distinct values would otherwise hammer a handful of global counters), then merges its LDS slots
-//             into the global table (CAS on the hash word, atomicAdd count, atomicMin first row);
-//   verify  : every record compares its bytes with the bytes of its slot's first row — two different values
-//             with the same 64-bit hash are DETECTED (counted in `collisions`; the host then repeats with another
-//             seed), never silently merged: the counts are exact, not probabilistic;
-//   compact : occupied slots -> dense csvsimd_freq_entry array (first row, span of its text, count).
-// ---------------------------------------------------------------------------------------------
-static constexpr u32 kLdsSlots = 1024;  // per workgroup (power of two)
-
-struct FreqSlot {  // 32 bytes; the table is cleared with one memset, so the "first row" is kept as the MAXIMUM of
-    u64 hash, first_inv, count, pad;  // ~row (0 = none yet): first row = ~first_inv
+struct FreqRowMap {  // one per chunk: rows [row0, row0 + rows) of the gathered column are records first_record + ...
+    u64 row0, first_record;
 };
-struct FreqStatus {  // == csvsimd_freq_status
-    u64 n_records, n_distinct, collisions, overflow;
-};
-
-__device__ __forceinline__ bool global_insert(FreqSlot* table, u64 mask, u64 h, u64 first_row, u64 count) {
-    u64 s = h & mask;
-    for (u64 probes = 0; probes <= mask; ++probes, s = (s + 1) & mask) {
-        const u64 old = atomicCAS((unsigned long long*)&table[s].hash, 0ull, (unsigned long long)h);
-        if (old == 0 || old == h) {
-            atomicAdd((unsigned long long*)&table[s].count, (unsigned long long)count);
-            atomicMax((unsigned long long*)&table[s].first_inv, (unsigned long long)~first_row);
-            return true;
-        }
-    }
-    return false;
-}
-
-static constexpr u32 kFreqInsertThreads = 1024;  // one LDS table and one flush per 8 192 rows (see colfreq_insert_kernel)
-__global__ __launch_bounds__(kFreqInsertThreads) void freq_insert_kernel(const Column c, FreqSlot* __restrict__ table, u64 mask,
-                                                          FreqStatus* __restrict__ status, u64 seed) {
-    __shared__ u64 s_hash[kLdsSlots];
-    __shared__ u64 s_first[kLdsSlots];
-    __shared__ u32 s_count[kLdsSlots];
-    __shared__ u32 s_fill;  // slots of the LDS table taken so far
-    for (u32 k = threadIdx.x; k < kLdsSlots; k += blockDim.x) {
-        s_hash[k] = 0;
-        s_first[k] = ~0ull;
-        s_count[k] = 0;
-    }
-    if (threadIdx.x == 0) s_fill = 0;
-    __syncthreads();
-    bool overflow = false;
-    // contiguous slab of rows per workgroup: neighbouring lanes read neighbouring rows
-    const u64 per = (c.n_rows + gridDim.x - 1) / gridDim.x;
-    const u64 r0 = (u64)blockIdx.x * per, r1 = r0 + per < c.n_rows ? r0 + per : c.n_rows;
-    for (u64 i = r0 + threadIdx.x; i < r1; i += blockDim.x) {
-        u64 b, e;
-        field_span(c, i, b, e);
-        const u64 h = hash_bytes(c.bytes + b, e - b, seed);
-        const u64 row = c.first_row + i;
-        // LDS first: at most 8 probes, then straight to the global table (a column of many distinct values)
-        u32 s = (u32)(h >> 32) & (kLdsSlots - 1);
-        bool done = false;
-        // a column of many distinct values fills the LDS table with its first thousand rows; from then on new values
-        // only find full probe sequences there, so the probing is limited to a look at the home slot
-        const int max_probes = s_fill < kLdsSlots * 3 / 4 ? 8 : 1;
-        for (int p = 0; p < max_probes && !done; ++p, s = (s + 1) & (kLdsSlots - 1)) {
-            const u64 old = atomicCAS((unsigned long long*)&s_hash[s], 0ull, (unsigned long long)h);
-            if (old == 0 || old == h) {
-                if (old == 0) atomicAdd(&s_fill, 1u);
-                atomicAdd(&s_count[s], 1u);
-                atomicMin((unsigned long long*)&s_first[s], (unsigned long long)row);
-                done = true;
-            }
-        }
-        if (!done && !global_insert(table, mask, h, row, 1)) overflow = true;
-    }
-    __syncthreads();
-    for (u32 k = threadIdx.x; k < kLdsSlots; k += blockDim.x)
-        if (s_hash[k] && !global_insert(table, mask, s_hash[k], s_first[k], s_count[k])) overflow = true;
-    if (overflow) atomicAdd((unsigned long long*)&status->overflow, 1ull);
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd((unsigned long long*)&status->n_records, (unsigned long long)c.n_rows);
-}
-
-__global__ __launch_bounds__(256) void freq_verify_kernel(const Column c, const FreqSlot* __restrict__ table, u64 mask,
-                                                          FreqStatus* __restrict__ status, u64 seed, u64 table_jump,
-                                                          u32 table_field) {
-    u32 bad = 0;
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < c.n_rows; i += (u64)gridDim.x * blockDim.x) {
-        u64 b, e;
-        field_span(c, i, b, e);
-        const u64 h = hash_bytes(c.bytes + b, e - b, seed);
-        u64 s = h & mask;
-        bool found = false;
-        for (u64 probes = 0; probes <= mask; ++probes, s = (s + 1) & mask) {
-            const u64 th = table[s].hash;
-            if (th == h) { found = true; break; }
-            if (th == 0) break;
-        }
-        if (!found) { ++bad; continue; }
-        // the representative: field `table_field` of row first_row (any chunk of the same tape); a record that is its
-        // own representative (every record of an all-distinct column) has nothing to compare — and skips three
-        // dependent random reads
-        const u64 rep = ~table[s].first_inv;
-        if (rep == c.first_row + i) continue;
-        const u64 k = rep * table_jump + table_field;
-        const u64 rb = c.index[k] + 1, re = c.index[k + 1];
-        if (re - rb != e - b || !bytes_equal(c.bytes + rb, c.bytes + b, e - b)) ++bad;
-    }
-    if (bad) atomicAdd((unsigned long long*)&status->collisions, (unsigned long long)bad);
-}
-
 struct FreqEntry {  // == csvsimd_freq_entry: 32 bytes
     u64 first_record, begin, end, count;
 };
-// Occupied slots -> dense entries.  The output cursor is ONE word: a returning atomic on one address retires at
-// ~90 per us chip-wide (measured: with one atomic per wave the 4 Mi-slot table of the bench took 0.8 ms, all of it
-// that word), so a workgroup reserves the room for kCompactPerThread x 256 slots with a single atomic.
-static constexpr u32 kCompactPerThread = 8;
-static constexpr u32 kCompactThreads = 1024;  // 8192 slots per reservation (2048: the 4 Mi-slot table's 2048 atomics alone were 23 us)
-__global__ __launch_bounds__(kCompactThreads) void freq_compact_kernel(const FreqSlot* __restrict__ table, u64 slots,
-                                                           const u64* __restrict__ index, u64 jump, u32 field,
-                                                           FreqEntry* __restrict__ out, u64 out_cap,
-                                                           FreqStatus* __restrict__ status) {
-    __shared__ u32 s_wave[kCompactThreads / 64];
-    __shared__ u64 s_base;
-    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    const u64 chunk = (u64)blockDim.x * kCompactPerThread;
-    for (u64 c0 = (u64)blockIdx.x * chunk; c0 < slots; c0 += (u64)gridDim.x * chunk) {   // uniform per workgroup
-        u64 masks[kCompactPerThread];
-        u32 mine = 0, wave_total = 0;
-#pragma unroll
-        for (u32 j = 0; j < kCompactPerThread; ++j) {
-            const u64 sl = c0 + (u64)j * blockDim.x + threadIdx.x;
-            const bool used = sl < slots && table[sl].hash != 0;
-            masks[j] = __ballot(used);
-            mine |= (used ? 1u : 0u) << j;
-            wave_total += (u32)__builtin_popcountll(masks[j]);
+__global__ __launch_bounds__(256) void freq_entries_kernel(const u64* __restrict__ ent16, const u64* __restrict__ cf_status,
+                                                           const u64* __restrict__ begin, const u64* __restrict__ end,
+                                                           const FreqRowMap* __restrict__ map, u32 n_chunks,
+                                                           FreqEntry* __restrict__ out, u64 out_cap) {
+    const u64 n = cf_status[1] < out_cap ? cf_status[1] : out_cap;  // n_distinct
+    for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (u64)gridDim.x * blockDim.x) {
+        const u64 row = ent16[2 * k], cnt = ent16[2 * k + 1];
+        u32 lo = 0, hi = n_chunks;  // the last chunk whose row0 <= row
+        while (hi - lo > 1) {
+            const u32 mid = (lo + hi) >> 1;
+            if (map[mid].row0 <= row) lo = mid; else hi = mid;
         }
-        if (lane == 0) s_wave[w] = wave_total;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            u32 tot = 0;
-            for (u32 k = 0; k < kCompactThreads / 64; ++k) tot += s_wave[k];
-            s_base = tot ? atomicAdd((unsigned long long*)&status->n_distinct, (unsigned long long)tot) : 0ull;
-        }
-        __syncthreads();
-        u64 at = s_base;
-        for (u32 k = 0; k < w; ++k) at += s_wave[k];
-#pragma unroll
-        for (u32 j = 0; j < kCompactPerThread; ++j) {
-            if ((mine >> j) & 1u) {
-                const u64 o = at + (u64)__builtin_popcountll(masks[j] & ((1ull << lane) - 1ull));
-                if (o < out_cap) {
-                    const u64 sl = c0 + (u64)j * blockDim.x + threadIdx.x;
-                    const u64 row = ~table[sl].first_inv;
-                    const u64 k = row * jump + field;
-                    out[o] = FreqEntry{row - 1, index[k] + 1, index[k + 1], table[sl].count};  // record id as seek_field counts
-                }
-            }
-            at += (u64)__builtin_popcountll(masks[j]);
-        }
-        __syncthreads();  // s_wave / s_base are rewritten by the next chunk
+        out[k] = FreqEntry{map[lo].first_record + (row - map[lo].row0), begin[row], end[row], cnt};
     }
 }
 
@@ -478,31 +337,19 @@ static Column make_column(const void* dbytes, const void* dindex, u64 first_key,
     return c;
 }
 
-hipError_t launch_freq_insert(const void* dbytes, const void* dindex, u64 first_key, u64 jump, u64 n_rows, u32 field,
-                              void* d_table, u64 slots, void* d_status, u64 seed, int n_cus, hipStream_t stream) {
-    if (n_rows == 0) return hipSuccess;
-    const Column c = make_column(dbytes, dindex, first_key, jump, n_rows, field);
-    // 8192 rows per workgroup: the LDS pre-aggregation has something to aggregate, and a column of few values — every
-    // workgroup flushes into the same global slots, and accesses to one line retire one by one — is flushed a quarter as often
-    const u32 grid = grid_for(n_rows, 8 * kFreqInsertThreads, (u32)(n_cus > 0 ? n_cus : 256) * 2);
-    hipLaunchKernelGGL(freq_insert_kernel, dim3(grid), dim3(kFreqInsertThreads), 0, stream, c, (FreqSlot*)d_table, slots - 1,
-                       (FreqStatus*)d_status, seed);
+hipError_t launch_span_stats(const void* d_begin, const void* d_end, u64 n, const void* dindex, u64 index_len, void* d_out,
+                             hipStream_t stream) {
+    hipLaunchKernelGGL(span_stats_kernel, dim3(grid_for(n, 256 * 8, 2048)), dim3(256), 0, stream, (const u64*)d_begin,
+                       (const u64*)d_end, n, (const u64*)dindex, index_len, (u64*)d_out);
     return hipGetLastError();
 }
 
-hipError_t launch_freq_verify(const void* dbytes, const void* dindex, u64 first_key, u64 jump, u64 n_rows, u32 field,
-                              const void* d_table, u64 slots, void* d_status, u64 seed, hipStream_t stream) {
-    if (n_rows == 0) return hipSuccess;
-    const Column c = make_column(dbytes, dindex, first_key, jump, n_rows, field);
-    hipLaunchKernelGGL(freq_verify_kernel, dim3(grid_for(n_rows, 256, 8192)), dim3(256), 0, stream, c,
-                       (const FreqSlot*)d_table, slots - 1, (FreqStatus*)d_status, seed, jump, field);
-    return hipGetLastError();
-}
-
-hipError_t launch_freq_compact(const void* d_table, u64 slots, const void* dindex, u64 jump, u32 field, void* d_out,
-                               u64 out_cap, void* d_status, hipStream_t stream) {
-    hipLaunchKernelGGL(freq_compact_kernel, dim3(grid_for(slots, kCompactThreads * kCompactPerThread, 4096)), dim3(kCompactThreads), 0, stream, (const FreqSlot*)d_table,
-                       slots, (const u64*)dindex, jump, field, (FreqEntry*)d_out, out_cap, (FreqStatus*)d_status);
+hipError_t launch_freq_entries(const void* d_ent16, const void* d_cf_status, const void* d_begin, const void* d_end,
+                               const void* d_map, u32 n_chunks, void* d_out, u64 out_cap, u64 n_max, hipStream_t stream) {
+    if (n_max == 0 || out_cap == 0) return hipSuccess;
+    hipLaunchKernelGGL(freq_entries_kernel, dim3(grid_for(n_max < out_cap ? n_max : out_cap, 256, 4096)), dim3(256), 0, stream,
+                       (const u64*)d_ent16, (const u64*)d_cf_status, (const u64*)d_begin, (const u64*)d_end,
+                       (const FreqRowMap*)d_map, n_chunks, (FreqEntry*)d_out, out_cap);
     return hipGetLastError();
 }
 

@@ -107,14 +107,11 @@ hipError_t launch_chunk_spans(const void* dindex, uint64_t first_key, uint64_t j
                               uint64_t n_rows, void* d_begin, void* d_end, hipStream_t stream);
 hipError_t launch_gather_fields(const void* dbytes, uint64_t bytes_len, const void* d_begin, const void* d_end,
                                 uint64_t n_records, void* d_dst, uint32_t stride, void* d_len, hipStream_t stream);
-hipError_t launch_freq_insert(const void* dbytes, const void* dindex, uint64_t first_key, uint64_t jump, uint64_t n_rows,
-                              uint32_t field, void* d_table, uint64_t slots, void* d_status, uint64_t seed, int n_cus,
-                              hipStream_t stream);
-hipError_t launch_freq_verify(const void* dbytes, const void* dindex, uint64_t first_key, uint64_t jump, uint64_t n_rows,
-                              uint32_t field, const void* d_table, uint64_t slots, void* d_status, uint64_t seed,
-                              hipStream_t stream);
-hipError_t launch_freq_compact(const void* d_table, uint64_t slots, const void* dindex, uint64_t jump, uint32_t field,
-                               void* d_out, uint64_t out_cap, void* d_status, hipStream_t stream);
+hipError_t launch_span_stats(const void* d_begin, const void* d_end, uint64_t n, const void* dindex, uint64_t index_len,
+                             void* d_out, hipStream_t stream);
+hipError_t launch_freq_entries(const void* d_ent16, const void* d_cf_status, const void* d_begin, const void* d_end,
+                               const void* d_map, uint32_t n_chunks, void* d_out, uint64_t out_cap, uint64_t n_max,
+                               hipStream_t stream);
 hipError_t launch_search(const void* dbytes, uint64_t bytes_len, const void* dindex, uint64_t first_key, uint64_t jump, uint64_t n_rows,
                          uint32_t field, const void* d_needle, uint32_t needle_len, int mode, void* d_bitmap, void* d_count,
                          hipStream_t stream);
@@ -125,10 +122,10 @@ hipError_t launch_to_columns(const void* dbytes, uint64_t bytes_len, const void*
                              uint64_t n_rows, const void* d_fields, uint32_t n_fields, void* d_cols, uint32_t stride,
                              void* d_lens, uint32_t rows_per_block, int n_cus, hipStream_t stream);
 uint32_t to_columns_window_bytes();
-hipError_t launch_colfreq_insert(const void* d_col, const void* d_len, uint64_t n_rows, uint32_t stride, void* d_table,
-                                 uint64_t slots, void* d_status, int n_cus, hipStream_t stream);
-hipError_t launch_colfreq_compact(const void* d_table, uint64_t slots, uint64_t first_record, void* d_out, uint64_t out_cap,
-                                  void* d_status, hipStream_t stream);
+// exact frequency count on a column: two launches, no device-memory table (columnar_kernels.hip)
+uint64_t colfreq_scratch_bytes(uint64_t n_rows);
+hipError_t launch_colfreq(const void* d_col, const void* d_len, uint64_t n_rows, uint32_t stride, uint64_t first_record,
+                          void* d_scratch, void* d_entries, uint64_t entries_cap, void* d_status, int n_cus, hipStream_t stream);
 hipError_t launch_colsearch(const void* d_col, const void* d_len, uint64_t n_rows, uint32_t stride, const void* d_needle,
                             uint32_t needle_len, int mode, void* d_bitmap, void* d_count, void* d_truncated,
                             hipStream_t stream);

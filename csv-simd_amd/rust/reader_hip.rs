@@ -36,7 +36,7 @@ extern "C" {
 const CSVSIMD_ERR_TAPE_CAPACITY: c_int = -11;
 /// The C ABI this file was written against (include/csvsimd.h): entry points changed their argument lists between
 /// versions, so a library of another version is refused instead of called.
-const CSVSIMD_ABI_VERSION: u32 = 3;
+const CSVSIMD_ABI_VERSION: u32 = 4;
 
 /// One context per thread, created on the first `read` and kept: a context owns device scratch and pinned staging
 /// (hipMalloc / hipHostMalloc: milliseconds), a read of a small file costs tens of microseconds.  A context serves one

@@ -47,7 +47,7 @@ extern "C" {
 const char* csvsimd_strerror(int code);
 const char* csvsimd_last_error(void); /* thread-local text of the last HIP failure */
 int csvsimd_device_count(void);       /* number of HIP devices visible, 0 if none */
-uint32_t csvsimd_abi_version(void); /* 3: + columnar consumers, copy yardstick (2: csvsimd_stitch grew an error field;
+uint32_t csvsimd_abi_version(void); /* 4: frequency counts take n_records / scratch_bytes, + _async, ingest plan / phases (3: + columnar consumers, copy yardstick; 2: csvsimd_stitch grew an error field;
                                        device-side stitch / re-emit).  Bindings should check it when they load the library */
 /* bytes one workgroup indexes per look-back step (informational: tests probe sizes around it) */
 uint32_t csvsimd_tile_bytes(void);
@@ -371,27 +371,30 @@ int csvsimd_gather_fields_device(const void* dbytes, uint64_t bytes_len, const v
                                  void* hip_stream);
 
 /* Frequency count of column field_idx over the given chunks (all of csvsimd_tape_chunks' output = the whole
- * file): one entry per DISTINCT field text with the number of records that hold it.  EXACT: values are
- * grouped by a 64-bit hash in a device hash table, then a verification pass compares every record's bytes with
- * its group's first record — a hash collision between two different values is detected (and the count repeated
- * with another seed), never merged.  Definition checked against: collections.Counter over seek_field.
- *   d_scratch   : csvsimd_column_frequency_scratch_bytes(table_slots) bytes, 16-byte aligned; table_slots a power
- *                 of two >= 64, at least ~2x the number of distinct values (CSVSIMD_ERR_TAPE_CAPACITY if it fills)
+ * file): one entry per DISTINCT field text with the number of records that hold it.  EXACT (bytes are compared, see
+ * csvsimd_columnar_frequency_device below: this call gathers the column into fixed-stride rows — spans, then
+ * csvsimd_gather_fields_device at the stride of its longest field — and counts it with that ONE implementation).
+ * Definition checked against: collections.Counter over seek_field.
+ *   d_scratch   : scratch_bytes >= csvsimd_column_frequency_scratch_bytes(n_records, n_chunks, max_field_bytes), 256-byte
+ *                 aligned; n_records = the chunks' records together.  The longest field is only known once the call
+ *                 has looked: if the scratch is too small for it the call returns CSVSIMD_ERR_TAPE_CAPACITY with
+ *                 status->max_field_bytes set — size the scratch from that and call again
  *   d_entries   : entries_cap csvsimd_freq_entry, unordered (sort by first_record for a deterministic order);
  *                 status->n_distinct of them are valid (CSVSIMD_ERR_TAPE_CAPACITY if more exist than fit)
- * Synchronous on hip_stream. */
+ * Synchronous on hip_stream (it waits twice: for the longest field, and at the end).  The slow path next to the
+ * columnar one: it touches one or two 64-byte sectors of the file plus a slice of tape per record. */
 typedef struct csvsimd_freq_entry {
     uint64_t first_record; /* first record (seek_field numbering) that holds this value */
     uint64_t begin, end;   /* bytes[begin..end) = the value's text (of that record)      */
     uint64_t count;        /* records holding it                                         */
 } csvsimd_freq_entry;
 typedef struct csvsimd_freq_status {
-    uint64_t n_records, n_distinct, collisions /* of the last attempt: 0 on success */, overflow;
+    uint64_t n_records, n_distinct, max_field_bytes, overflow;
 } csvsimd_freq_status;
-uint64_t csvsimd_column_frequency_scratch_bytes(uint64_t table_slots);
+uint64_t csvsimd_column_frequency_scratch_bytes(uint64_t n_records, uint32_t n_chunks, uint64_t max_field_bytes);
 int csvsimd_column_frequency_device(csvsimd_ctx* ctx, const void* dbytes, const void* dindex, uint64_t index_len,
                                     uint32_t field_cnt, int new_line, const csvsimd_chunk* chunks,
-                                    uint32_t n_chunks, uint32_t field_idx, void* d_scratch, uint64_t table_slots,
+                                    uint32_t n_chunks, uint32_t field_idx, void* d_scratch, uint64_t scratch_bytes,
                                     void* d_entries, uint64_t entries_cap, csvsimd_freq_status* status,
                                     void* hip_stream);
 
@@ -432,23 +435,35 @@ int csvsimd_chunk_to_columns_device(csvsimd_ctx* ctx, const void* dbytes, uint64
 /* Frequency count of one column of such a copy (d_col = n_records x stride bytes, d_len = its lengths or NULL for
  * fixed-width keys): one entry per DISTINCT value (length + bytes) with the number of records that hold it and the FIRST
  * record that does (first_record + its position in the column; the value's text is that row of the column).  EXACT by
- * construction: a table slot points at a representative record and is a value's only if the bytes are equal, so a hash
- * collision costs a probe, never a wrong count — no verification pass, no retry.  design_notes_1.md:1-4; definition
- * checked against collections.Counter over seek_field.
- *   d_scratch : csvsimd_columnar_frequency_scratch_bytes(table_slots) bytes, 16-byte aligned; table_slots a power of two
- *               >= 64, ~2x the number of distinct values (CSVSIMD_ERR_TAPE_CAPACITY if it fills: status->overflow)
- *   d_entries : entries_cap csvsimd_colfreq_entry, unordered; status->n_distinct are valid
- * CSVSIMD_ERR_TAPE_CAPACITY also if status->truncated records are longer than the stride (their counts would merge
- * values that differ past it: transpose with a larger stride).  Synchronous on hip_stream. */
+ * construction: two records count as one value only if their bytes are equal (hash bits choose where values meet, a
+ * representative record is compared), so a hash collision costs a comparison, never a wrong count — no verification
+ * pass, no retry.  design_notes_1.md:1-4; definition checked against collections.Counter over seek_field.
+ * Two launches, no table in device memory, nothing cleared per call (round 4): pass 1 aggregates each slab of 8 192
+ * records in LDS and writes its surviving (first record, count, hash) tuples partitioned by hash into d_scratch; pass 2
+ * merges each partition in LDS and writes its entries.
+ *   d_scratch : csvsimd_columnar_frequency_scratch_bytes(n_records) bytes (~12 per record), 16-byte aligned; no need
+ *               to clear it
+ *   d_entries : entries_cap csvsimd_colfreq_entry, unordered; n_distinct of the status are valid (the first entries_cap
+ *               are written if there are more)
+ *   d_status  : (_async) one csvsimd_colfreq_status in DEVICE memory, 8-byte aligned, written by the launches
+ * csvsimd_columnar_frequency_device_async enqueues the two launches on hip_stream and returns: nothing is waited for,
+ * allocated or copied — capturable into a hipGraph; the caller reads d_status when it needs it.
+ * csvsimd_columnar_frequency_device = the same + the status copied to the host + one synchronisation; it returns
+ * CSVSIMD_ERR_TAPE_CAPACITY if status->n_distinct > entries_cap, if status->truncated records are longer than the stride
+ * (their counts would merge values that differ past it: transpose with a larger stride), or if status->overflow (more
+ * than 8 192 distinct values share 21 hash bits: not a property of real data). */
 typedef struct csvsimd_colfreq_entry {
     uint64_t first_record, count;
 } csvsimd_colfreq_entry;
 typedef struct csvsimd_colfreq_status {
     uint64_t n_records, n_distinct, truncated, overflow;
 } csvsimd_colfreq_status;
-uint64_t csvsimd_columnar_frequency_scratch_bytes(uint64_t table_slots);
+uint64_t csvsimd_columnar_frequency_scratch_bytes(uint64_t n_records);
+int csvsimd_columnar_frequency_device_async(csvsimd_ctx* ctx, const void* d_col, const void* d_len, uint64_t n_records,
+                                            uint32_t stride, uint64_t first_record, void* d_scratch, uint64_t scratch_bytes,
+                                            void* d_entries, uint64_t entries_cap, void* d_status, void* hip_stream);
 int csvsimd_columnar_frequency_device(csvsimd_ctx* ctx, const void* d_col, const void* d_len, uint64_t n_records,
-                                      uint32_t stride, uint64_t first_record, void* d_scratch, uint64_t table_slots,
+                                      uint32_t stride, uint64_t first_record, void* d_scratch, uint64_t scratch_bytes,
                                       void* d_entries, uint64_t entries_cap, csvsimd_colfreq_status* status,
                                       void* hip_stream);
 /* csvsimd_column_search_device on a column of the columnar copy: bit i of d_bitmap = record i matches; same modes and

@@ -108,12 +108,13 @@ def test_columnar_frequency_is_counter(ctx, pkg, oracle, torch_cuda):
     stride = 48   # every field of make_csv is <= 40 bytes
     cols, lens = transpose(ctx, pkg, torch, dt, ch, None, stride)
     first_record = ch[1] // dt.tape.record_jump_size - 1
-    for f, slots in ((1, 64), (2, 16384), (3, 256), (0, 16384)):
+    need = pkg.columnar_frequency_scratch_bytes(n)
+    scratch = torch.full((need,), 0xA5, dtype=torch.uint8, device="cuda:0")   # never cleared by anybody: the call must not care
+    for f in (1, 2, 3, 0):
         want = oracle.column_frequency(dt.data, dt.index, dt.field_cnt, dt.crlf, [ch], f)
-        scratch = torch.empty(pkg.columnar_frequency_scratch_bytes(slots), dtype=torch.uint8, device="cuda:0")
         ent = torch.zeros((len(want) + 3, 2), dtype=torch.int64, device="cuda:0")
         st = pkg.columnar_frequency_device(ctx, cols[f].data_ptr(), lens[f].data_ptr(), n, stride, first_record,
-                                           scratch.data_ptr(), slots, ent.data_ptr(), ent.shape[0])
+                                           scratch.data_ptr(), need, ent.data_ptr(), ent.shape[0])
         assert (st.n_records, st.n_distinct, st.truncated, st.overflow) == (n, len(want), 0, 0)
         got = {}
         for first, cnt in ent[: st.n_distinct].cpu().tolist():
@@ -123,23 +124,74 @@ def test_columnar_frequency_is_counter(ctx, pkg, oracle, torch_cuda):
             # the entry names the FIRST record holding the value
             assert all(oracle.seek_field(dt.data, dt.index, dt.field_cnt, dt.crlf, r, f) != text for r in range(first))
         assert got == dict(want)
-    # capacity protocol: a table smaller than the number of distinct values fills up, loudly
-    scratch = torch.empty(pkg.columnar_frequency_scratch_bytes(1024), dtype=torch.uint8, device="cuda:0")
+    # capacity protocol: a scratch smaller than the call needs is refused before anything runs
     ent = torch.zeros((8, 2), dtype=torch.int64, device="cuda:0")
     with pytest.raises(pkg.StructureError) as e:
-        pkg.columnar_frequency_device(ctx, cols[2].data_ptr(), lens[2].data_ptr(), n, stride, 0, scratch.data_ptr(), 1024,
+        pkg.columnar_frequency_device(ctx, cols[2].data_ptr(), lens[2].data_ptr(), n, stride, 0, scratch.data_ptr(), need - 1,
                                       ent.data_ptr(), 8)
     assert e.value.code == pkg.ERR_TAPE_CAPACITY
     # too few output entries: the status says how many are needed
-    scratch = torch.empty(pkg.columnar_frequency_scratch_bytes(16384), dtype=torch.uint8, device="cuda:0")
-    st = pkg.columnar_frequency_device(ctx, cols[1].data_ptr(), lens[1].data_ptr(), n, stride, 0, scratch.data_ptr(), 16384,
+    st = pkg.columnar_frequency_device(ctx, cols[1].data_ptr(), lens[1].data_ptr(), n, stride, 0, scratch.data_ptr(), need,
                                        ent.data_ptr(), 2, allow_capacity=True)
     assert st.n_distinct == len(oracle.column_frequency(dt.data, dt.index, dt.field_cnt, dt.crlf, [ch], 1)) > 2
     # a stride shorter than some values: the count would merge values that differ past it -> refused, and counted
     short, slens = transpose(ctx, pkg, torch, dt, ch, [2], 16)
-    st = pkg.columnar_frequency_device(ctx, short[0].data_ptr(), slens[0].data_ptr(), n, 16, 0, scratch.data_ptr(), 16384,
+    st = pkg.columnar_frequency_device(ctx, short[0].data_ptr(), slens[0].data_ptr(), n, 16, 0, scratch.data_ptr(), need,
                                        ent.data_ptr(), 8, allow_capacity=True)
     assert st.truncated == int((slens[0] > 16).sum())  and st.truncated > 0
+
+
+def test_columnar_frequency_async_is_two_launches_and_graph_capturable(ctx, pkg, torch_cuda):
+    """The asynchronous form: nothing waited for, allocated or copied — so it can be captured and replayed on new data; the
+    status record is read from device memory by the caller.  Sizes around the slab (8 192 records) and partition geometry,
+    all-distinct and few-valued columns, an empty column."""
+    torch = torch_cuda
+    rng = np.random.default_rng(77)
+    stride = 32
+    for n in (1, 63, 8191, 8192, 8193, 100_000, 1_000_003):
+        need = pkg.columnar_frequency_scratch_bytes(n)
+        scratch = torch.empty(need, dtype=torch.uint8, device="cuda:0")
+        col = torch.zeros((n, stride), dtype=torch.uint8, device="cuda:0")
+        ent = torch.zeros((n + 4, 2), dtype=torch.int64, device="cuda:0")
+        d_status = torch.full((4,), -1, dtype=torch.int64, device="cuda:0")
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            pkg.columnar_frequency_device_async(ctx, col.data_ptr(), 0, n, stride, 5, scratch.data_ptr(), need, ent.data_ptr(),
+                                                ent.shape[0], d_status.data_ptr(), side.cuda_stream)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            pkg.columnar_frequency_device_async(ctx, col.data_ptr(), 0, n, stride, 5, scratch.data_ptr(), need, ent.data_ptr(),
+                                                ent.shape[0], d_status.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        for kind in ("distinct", "few", "one"):
+            if kind == "distinct":
+                keys = np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+            elif kind == "few":
+                keys = rng.integers(0, 37, size=n).astype(np.uint64)
+            else:
+                keys = np.zeros(n, dtype=np.uint64)
+            host = np.zeros((n, stride), dtype=np.uint8)
+            host[:, :8] = keys.view(np.uint8).reshape(n, 8)
+            host[:, 24] = 7
+            col.copy_(torch.from_numpy(host))
+            ent.fill_(-1)
+            d_status.fill_(-1)
+            g.replay()
+            torch.cuda.synchronize()
+            uniq, first, counts = np.unique(keys, return_index=True, return_counts=True)
+            st = d_status.cpu().tolist()
+            assert st == [n, uniq.size, 0, 0], (n, kind, st)
+            got = {int(f) - 5: int(c) for f, c in ent[: uniq.size].cpu().tolist()}
+            assert got == {int(f): int(c) for f, c in zip(first, counts)}, (n, kind)
+            assert bool((ent[uniq.size:] == -1).all())
+        del g
+    # no records: the status is still written
+    d_status = torch.full((4,), -1, dtype=torch.int64, device="cuda:0")
+    pkg.columnar_frequency_device_async(ctx, 0, 0, 0, stride, 0, scratch.data_ptr(), need, 0, 0, d_status.data_ptr())
+    torch.cuda.synchronize()
+    assert d_status.cpu().tolist() == [0, 0, 0, 0]
 
 
 def test_columnar_frequency_same_hash_tag_never_merges(ctx, pkg, torch_cuda):
@@ -152,9 +204,10 @@ def test_columnar_frequency_same_hash_tag_never_merges(ctx, pkg, torch_cuda):
     vocab[150:, 31] ^= 1                      # pairs that differ in the last byte only
     pick = rng.integers(0, 300, size=n)
     col = torch.from_numpy(vocab[pick]).cuda()
-    scratch = torch.empty(pkg.columnar_frequency_scratch_bytes(1024), dtype=torch.uint8, device="cuda:0")
+    need = pkg.columnar_frequency_scratch_bytes(n)
+    scratch = torch.empty(need, dtype=torch.uint8, device="cuda:0")
     ent = torch.zeros((400, 2), dtype=torch.int64, device="cuda:0")
-    st = pkg.columnar_frequency_device(ctx, col.data_ptr(), 0, n, stride, 1000, scratch.data_ptr(), 1024, ent.data_ptr(), 400)
+    st = pkg.columnar_frequency_device(ctx, col.data_ptr(), 0, n, stride, 1000, scratch.data_ptr(), need, ent.data_ptr(), 400)
     want = np.bincount(pick, minlength=300)
     first = {v: int(np.flatnonzero(pick == v)[0]) for v in range(300)}
     assert st.n_distinct == int((want > 0).sum()) and st.n_records == n

@@ -69,13 +69,15 @@ def test_chunk_spans_frequency_and_search(ctx, pkg, oracle, torch_cuda, line_end
                 for k, rec in enumerate(oracle.chunk_record_ids(ch, field_cnt, dt.crlf)):
                     assert dt.data[bh[k]: eh[k]] == oracle.seek_field(dt.data, dt.index, field_cnt, dt.crlf, rec, f)
         # ---- frequency count over all chunks == Counter ------------------------------------------------
-        for f, slots in ((1, 64), (2, 16384), (3, 256)):
+        for f in (1, 2, 3):
             want = oracle.column_frequency(dt.data, dt.index, field_cnt, dt.crlf, chunks, f)
-            scratch = torch.empty(pkg.column_frequency_scratch_bytes(slots), dtype=torch.uint8, device="cuda:0")
+            longest = max(len(v) for v in want)
+            need = pkg.column_frequency_scratch_bytes(nrec, len(chunks), longest)
+            scratch = torch.empty(need, dtype=torch.uint8, device="cuda:0")
             ent = torch.zeros((len(want) + 3, 4), dtype=torch.int64, device="cuda:0")
             st = pkg.column_frequency_device(ctx, dbytes, dindex, index_len, field_cnt, new_line, chunks, f,
-                                             scratch.data_ptr(), slots, ent.data_ptr(), ent.shape[0])
-            assert (st.n_records, st.n_distinct, st.collisions, st.overflow) == (nrec, len(want), 0, 0)
+                                             scratch.data_ptr(), need, ent.data_ptr(), ent.shape[0])
+            assert (st.n_records, st.n_distinct, st.max_field_bytes, st.overflow) == (nrec, len(want), longest, 0)
             got = {}
             for first, b_, e_, cnt in ent[: st.n_distinct].cpu().tolist():
                 text = dt.data[b_: e_]
@@ -112,29 +114,37 @@ def test_frequency_capacity_protocol_and_argument_checks(ctx, pkg, oracle, torch
     dt = DeviceTape(ctx, pkg, torch, make_csv(rng, 3000, b"\n"))
     dbytes, dindex, index_len, field_cnt, new_line = dt.args()
     chunks = dt.tape.chunks(2)
+    nrec = sum(c[3] for c in chunks)
     want = oracle.column_frequency(dt.data, dt.index, field_cnt, False, chunks, 2)   # ~3000 distinct codes
-    # a table with fewer slots than distinct values fills up: CSVSIMD_ERR_TAPE_CAPACITY, nothing silently dropped
-    scratch = torch.empty(pkg.column_frequency_scratch_bytes(1024), dtype=torch.uint8, device="cuda:0")
+    longest = max(len(v) for v in want)
     ent = torch.zeros((8, 4), dtype=torch.int64, device="cuda:0")
+    # a scratch sized for shorter fields than the column holds: refused, and the status says how long the longest one is
+    small = pkg.column_frequency_scratch_bytes(nrec, len(chunks), 1)
+    assert small < pkg.column_frequency_scratch_bytes(nrec, len(chunks), longest)
+    scratch = torch.empty(small, dtype=torch.uint8, device="cuda:0")
+    st = pkg.column_frequency_device(ctx, dbytes, dindex, index_len, field_cnt, new_line, chunks, 2, scratch.data_ptr(), small,
+                                     ent.data_ptr(), 8, allow_capacity=True)
+    assert st.max_field_bytes == longest and st.n_distinct == 0
+    # ... sized from that answer it fits; too few output entries: the status says how many are needed, the first 8 are written
+    need = pkg.column_frequency_scratch_bytes(nrec, len(chunks), st.max_field_bytes)
+    scratch = torch.empty(need, dtype=torch.uint8, device="cuda:0")
     with pytest.raises(pkg.StructureError) as e:
-        pkg.column_frequency_device(ctx, dbytes, dindex, index_len, field_cnt, new_line, chunks, 2, scratch.data_ptr(), 1024,
+        pkg.column_frequency_device(ctx, dbytes, dindex, index_len, field_cnt, new_line, chunks, 2, scratch.data_ptr(), need,
                                     ent.data_ptr(), 8)
     assert e.value.code == pkg.ERR_TAPE_CAPACITY
-    # enough slots but too few output entries: the status says how many are needed
-    scratch = torch.empty(pkg.column_frequency_scratch_bytes(8192), dtype=torch.uint8, device="cuda:0")
-    with pytest.raises(pkg.StructureError) as e:
-        pkg.column_frequency_device(ctx, dbytes, dindex, index_len, field_cnt, new_line, chunks, 2, scratch.data_ptr(), 8192,
-                                    ent.data_ptr(), 8)
-    assert e.value.code == pkg.ERR_TAPE_CAPACITY
-    # a chunk that is not whole rows of this tape, a field that does not exist, a table size that is no power of two
+    st = pkg.column_frequency_device(ctx, dbytes, dindex, index_len, field_cnt, new_line, chunks, 2, scratch.data_ptr(), need,
+                                     ent.data_ptr(), 8, allow_capacity=True)
+    assert st.n_distinct == len(want) > 1024
+    for first, b_, e_, cnt in ent.cpu().tolist():
+        assert want[dt.data[b_: e_]] == cnt and oracle.seek_field(dt.data, dt.index, field_cnt, False, first, 2) == dt.data[b_: e_]
+    # a chunk that is not whole rows of this tape, a field that does not exist, a scratch that is not even aligned
     bad = (0, chunks[0][1] + 1, chunks[0][2], chunks[0][3])
-    for kwargs in (dict(chunks=[bad]), dict(field=field_cnt), dict(slots=1000)):
+    for kwargs in (dict(chunks=[bad]), dict(field=field_cnt), dict(misalign=8)):
         with pytest.raises(pkg.StructureError) as e:
             pkg.column_frequency_device(ctx, dbytes, dindex, index_len, field_cnt, new_line, kwargs.get("chunks", chunks),
-                                        kwargs.get("field", 1), scratch.data_ptr(), kwargs.get("slots", 8192),
+                                        kwargs.get("field", 1), scratch.data_ptr() + kwargs.get("misalign", 0), need - 256,
                                         ent.data_ptr(), 8)
         assert e.value.code == pkg.ERR_INVALID_ARG
-    assert len(want) > 1024
 
 
 def test_gather_wide_every_alignment(ctx, pkg, oracle, torch_cuda):
@@ -180,12 +190,12 @@ def test_consumers_on_the_synthetic_corpus_at_scale(ctx, pkg, oracle, torch_cuda
     jump = cols
     chunks = [(i, max(1, i * (rows // 4)) * jump, (rows if i == 3 else (i + 1) * (rows // 4)) * jump, 0) for i in range(4)]
     nrec = rows - 1
-    slots = 1 << 19
-    scratch = torch.empty(pkg.column_frequency_scratch_bytes(slots), dtype=torch.uint8, device="cuda:0")
+    need = pkg.column_frequency_scratch_bytes(nrec, len(chunks), width)
+    scratch = torch.empty(need, dtype=torch.uint8, device="cuda:0")
     ent = torch.zeros((nrec + 8, 4), dtype=torch.int64, device="cuda:0")
     st = pkg.column_frequency_device(ctx, dbytes.data_ptr(), dindex.data_ptr(), index_len, cols, "LF", chunks, 5,
-                                     scratch.data_ptr(), slots, ent.data_ptr(), ent.shape[0])
-    assert (st.n_records, st.collisions, st.overflow) == (nrec, 0, 0)
+                                     scratch.data_ptr(), need, ent.data_ptr(), ent.shape[0])
+    assert (st.n_records, st.max_field_bytes, st.overflow) == (nrec, width, 0)
     e = ent[: st.n_distinct]
     assert int(e[:, 3].sum()) == nrec and bool((e[:, 2] - e[:, 1] == width).all())
     host = dbytes.cpu().numpy().tobytes()
