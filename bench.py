@@ -720,6 +720,8 @@ def consumers_leg(pkg, oracle, device):
     ok = ok and got == dict(want)
     alg_f = nrec * (stride + 4) + int(st.n_distinct) * 16
     tr_f = consumer_traffic("colfreq")
+    if isinstance(tr_f, dict):   # (a record of the round-3 kernels: two readings of the counters; the conservative one)
+        tr_f = tr_f.get("fetch_x2_plus_write")
     res["frequency_count"] = {"ms": round(t * 1e3, 4), "wall_ms_one_call_plus_sync": round(t_wall * 1e3, 3),
                               "distinct": int(st.n_distinct),
                               "algorithmic_bytes": alg_f, "GBps_algorithmic": round(alg_f / t / 1e9, 1),

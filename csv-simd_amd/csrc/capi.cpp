@@ -1540,7 +1540,7 @@ FreqLayout freq_layout(uint64_t n, uint32_t n_chunks, uint64_t stride) {
     auto up = [](uint64_t v) { return (v + 255) & ~(uint64_t)255; };
     FreqLayout L;
     L.off_map = 64;
-    L.off_begin = up(L.off_map + (uint64_t)n_chunks * 16);
+    L.off_begin = up(L.off_map + (uint64_t)n_chunks * 24);
     L.off_end = up(L.off_begin + n * 8);
     L.off_col = up(L.off_end + n * 8);
     L.off_len = up(L.off_col + n * stride);
@@ -1571,12 +1571,12 @@ int csvsimd_column_frequency_device(csvsimd_ctx* ctx, const void* dbytes, const 
     if (field_idx >= field_cnt) return CSVSIMD_ERR_INVALID_ARG;
     WITH_DEVICE_OF(ctx);
     std::vector<uint64_t> rows(n_chunks);
-    struct RowMap { uint64_t row0, first_record; };
+    struct RowMap { uint64_t row0, first_record, first_key; };
     std::vector<RowMap> map(n_chunks);
     uint64_t n = 0;
     for (uint32_t i = 0; i < n_chunks; ++i) {
         if ((rc = chunk_rows(&chunks[i], index_len, row_size, &rows[i])) != CSVSIMD_OK) return rc;
-        map[i] = RowMap{n, chunks[i].start / row_size - 1};  // seek_field numbering: the header row is not a record
+        map[i] = RowMap{n, chunks[i].start / row_size - 1, chunks[i].start};  // seek_field numbering: the header row is not a record
         n += rows[i];
     }
     if (n >= 0xffffffffull) return CSVSIMD_ERR_INVALID_ARG;  // record ids are 32-bit (Tape.record_cnt, src/tape.rs:76)
@@ -1593,10 +1593,10 @@ int csvsimd_column_frequency_device(csvsimd_ctx* ctx, const void* dbytes, const 
     if (rc != CSVSIMD_OK) return rc;
     for (uint32_t i = 0; i < n_chunks; ++i)
         HIP_TRY(csvsimd::launch_chunk_spans(dindex, chunks[i].start, row_size, field_idx, 1, rows[i],
-                                            base + L.off_begin + map[i].row0 * 8, base + L.off_end + map[i].row0 * 8, s));
-    HIP_TRY(csvsimd::launch_span_stats(base + L.off_begin, base + L.off_end, n, dindex, index_len, base, s));
+                                            base + L.off_begin + map[i].row0 * 8, base + L.off_end + map[i].row0 * 8, s, base));
     uint64_t stats[2] = {0, 0};  // longest field; the tape's last entry (the file is at least that long + 1)
-    HIP_TRY(hipMemcpyAsync(stats, base, 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&stats[0], base, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&stats[1], (const char*)dindex + (index_len - 1) * 8, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     status->max_field_bytes = stats[0];
     const uint64_t stride = stride_for(stats[0]);
@@ -1607,8 +1607,8 @@ int csvsimd_column_frequency_device(csvsimd_ctx* ctx, const void* dbytes, const 
                                           (uint32_t)stride, base + L.off_len, s));
     HIP_TRY(csvsimd::launch_colfreq(base + L.off_col, base + L.off_len, n, (uint32_t)stride, 0, base + L.off_cf, base + L.off_ent, n,
                                     base + L.off_status, ctx->n_cus, s));
-    HIP_TRY(csvsimd::launch_freq_entries(base + L.off_ent, base + L.off_status, base + L.off_begin, base + L.off_end,
-                                         base + L.off_map, n_chunks, d_entries, entries_cap, n, s));
+    HIP_TRY(csvsimd::launch_freq_entries(base + L.off_ent, base + L.off_status, dindex, row_size, field_idx, base + L.off_map,
+                                         n_chunks, d_entries, entries_cap, n, s));
     csvsimd_colfreq_status cs;
     HIP_TRY(hipMemcpyAsync(&cs, base + L.off_status, sizeof cs, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));

@@ -307,7 +307,8 @@ static constexpr u32 kCfThreads1 = 1024;
 static constexpr u32 kCfPerThread = kCfSlab / kCfThreads1;
 static constexpr u32 kCfLds = 1024;          // pass-1 LDS table slots
 static constexpr u32 kCfMaxParts = 4096;
-static constexpr u32 kCfCap2 = 8192;         // pass-2 LDS table slots
+static constexpr u32 kCfCap2 = 8192;         // pass-2 LDS table slots.  (4 096 slots and twice the partitions, two workgroups per
+                                             // CU instead of one: 20-25 % slower on every cardinality measured)
 static constexpr u32 kCfRound2 = 6144;       // tuples a pass-2 round may be asked to hold (distinct values <= tuples)
 static constexpr u32 kCfThreads2 = 1024;
 static constexpr u32 kCfTupleWords = 3;      // {first record, count, low 32 hash bits}
@@ -333,8 +334,25 @@ static ColFreqGeom colfreq_geom(u64 n_rows) {
 }
 u64 colfreq_scratch_bytes(u64 n_rows) { return colfreq_geom(n_rows).bytes; }
 
+__device__ __forceinline__ u32 wave_incl_scan_u32(u32 v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 o = (u32)__shfl_up((int)v, d);
+        if ((threadIdx.x & 63u) >= (u32)d) v += o;
+    }
+    return v;
+}
+__device__ __forceinline__ u32 wave_sum_u32(u32 v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += (u32)__shfl_xor((int)v, d);
+    return v;
+}
 __device__ __forceinline__ u32 cf_part(u64 h, u32 parts) { return (u32)(h >> 40) & (parts - 1u); }
 
+// ROWS_IN_LDS (strides up to 32 bytes): the table keeps a copy of every slot's representative row.  A record that meets
+// its value in the table compares against LDS instead of gathering the representative's row from memory — on a column
+// of few values that gather (64 lanes, ~64 different lines per load) was 12 of the kernel's 34 us (ablation, round 4).
+template <bool ROWS_IN_LDS>
 __global__ __launch_bounds__(kCfThreads1) void colfreq_partition_kernel(const ColView c, unsigned short* __restrict__ offs,
                                                                        u32* __restrict__ tuples, u32 parts, u32 slabs,
                                                                        ColFreqStatus* __restrict__ status) {
@@ -343,14 +361,19 @@ __global__ __launch_bounds__(kCfThreads1) void colfreq_partition_kernel(const Co
     __shared__ u32 s_first[kCfLds];  // smallest (record - r0) holding the slot's value
     __shared__ u32 s_hlo[kCfLds];    // hash bits 0..31 of the slot's value (written by the claimer, read after the barrier)
     __shared__ u32 s_hmid[kCfLds];   // hash bits 32..63 again, for the partition (cheaper than unpacking the key)
+    __shared__ u32 s_rlen[kCfLds];   // ROWS_IN_LDS: the representative's length; bit 31 = its row is in s_buf (set last)
     __shared__ u32 s_hist[kCfMaxParts];
     __shared__ u32 s_scan[kCfThreads1];
     __shared__ u32 s_fill, s_trunc;
+    // phase A: the representatives' rows (kCfLds x 32 bytes); phase B: this block's tuples, sorted, before they leave
+    __shared__ __attribute__((aligned(16))) u32 s_buf[kCfSlab * kCfTupleWords];
+    static_assert(kCfSlab * kCfTupleWords * 4 >= kCfLds * 32, "the tuple staging doubles as the row cache");
     const u32 t = threadIdx.x, w = blockIdx.x;
     for (u32 k = t; k < kCfLds; k += kCfThreads1) {
         s_key[k] = 0;
         s_count[k] = 0;
         s_first[k] = 0xffffffffu;
+        s_rlen[k] = 0;
     }
     for (u32 k = t; k < parts; k += kCfThreads1) s_hist[k] = 0;
     if (t == 0) {
@@ -364,19 +387,33 @@ __global__ __launch_bounds__(kCfThreads1) void colfreq_partition_kernel(const Co
     __syncthreads();
     const u64 r0 = (u64)w * kCfSlab;
     const u32 nrec = (u32)(c.n_rows - r0 < kCfSlab ? c.n_rows - r0 : kCfSlab);
+    u32x4c* const s_rows = reinterpret_cast<u32x4c*>(s_buf);  // slot s: s_rows[2 s], s_rows[2 s + 1]
     // ---- phase A: hash every record; repeated values meet in the LDS table -----------------------------------------
     u64 hs[kCfPerThread];
+    u32 lens[kCfPerThread];
     u32 single = 0, trunc = 0;  // bit j: record j of this thread goes out as its own tuple
+    // all of this thread's rows are requested before the first one is used: eight independent load -> hash chains
+    // instead of eight round trips one after the other (the probing below is a chain of its own)
 #pragma unroll
     for (u32 j = 0; j < kCfPerThread; ++j) {
         const u32 li = j * kCfThreads1 + t;  // consecutive lanes, consecutive records: coalesced loads
         hs[j] = 0;
+        lens[j] = 0;
+        if (li < nrec) {
+            const u64 i = r0 + li;
+            const u32 len = c.len ? c.len[i] : c.stride;
+            lens[j] = len;
+            if (len > c.stride) ++trunc;
+            hs[j] = hash_row(c, i, len);
+        }
+    }
+#pragma unroll
+    for (u32 j = 0; j < kCfPerThread; ++j) {
+        const u32 li = j * kCfThreads1 + t;
         if (li >= nrec) continue;
         const u64 i = r0 + li;
-        const u32 len = c.len ? c.len[i] : c.stride;
-        if (len > c.stride) ++trunc;
-        const u64 h = hash_row(c, i, len);
-        hs[j] = h;
+        const u32 len = lens[j];
+        const u64 h = hs[j];
         const u64 mine = (h & 0xffffffff00000000ull) | (u64)(li + 1u);
         bool done = false;
         // a column of many distinct values fills the table with its first rows; from then on new values only find full
@@ -392,11 +429,32 @@ __global__ __launch_bounds__(kCfThreads1) void colfreq_partition_kernel(const Co
                 atomicAdd(&s_fill, 1u);
                 atomicAdd(&s_count[s], 1u);
                 atomicMin(&s_first[s], li);
+                if (ROWS_IN_LDS) {
+                    // this record's row (its lines are in the L1: it was just hashed) becomes the slot's copy; the flag
+                    // goes up behind it (release at workgroup scope: LDS operations of a wave complete in order)
+                    const u32x4c* const p0 = reinterpret_cast<const u32x4c*>(c.col + i * c.stride);
+                    s_rows[2 * s] = p0[0];
+                    s_rows[2 * s + 1] = c.stride > 16 ? p0[1] : u32x4c{0, 0, 0, 0};
+                    __hip_atomic_store(&s_rlen[s], len | 0x80000000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
                 done = true;
-            } else if ((old >> 32) == (mine >> 32) && rows_equal(c, i, r0 + ((u32)old - 1u), len)) {
-                atomicAdd(&s_count[s], 1u);
-                atomicMin(&s_first[s], li);
-                done = true;
+            } else if ((old >> 32) == (mine >> 32)) {
+                bool eq;
+                const u32 rl = ROWS_IN_LDS ? __hip_atomic_load(&s_rlen[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+                if (ROWS_IN_LDS && (rl >> 31)) {
+                    const u32x4c* const p0 = reinterpret_cast<const u32x4c*>(c.col + i * c.stride);
+                    const u32x4c a0 = p0[0], a1 = c.stride > 16 ? p0[1] : u32x4c{0, 0, 0, 0};
+                    const u32x4c b0 = s_rows[2 * s], b1 = s_rows[2 * s + 1];
+                    eq = (rl & 0x7fffffffu) == len && a0.x == b0.x && a0.y == b0.y && a0.z == b0.z && a0.w == b0.w &&
+                         a1.x == b1.x && a1.y == b1.y && a1.z == b1.z && a1.w == b1.w;
+                } else {
+                    eq = rows_equal(c, i, r0 + ((u32)old - 1u), len);  // (the copy is not there yet, or strides > 32)
+                }
+                if (eq) {
+                    atomicAdd(&s_count[s], 1u);
+                    atomicMin(&s_first[s], li);
+                    done = true;
+                }
             }
         }
         if (!done) single |= 1u << j;
@@ -405,7 +463,9 @@ __global__ __launch_bounds__(kCfThreads1) void colfreq_partition_kernel(const Co
     __syncthreads();
     // ---- phase B: counting sort of this workgroup's tuples by partition ----------------------------------------------
     // every tuple takes a rank within its partition (one returning LDS atomic), the histogram is scanned, and the tuple
-    // goes to block[prefix[partition] + rank]: the block is written once, nothing is staged
+    // goes to slot prefix[partition] + rank of the staging buffer, which then leaves as one contiguous, coalesced write
+    // (scattered straight to memory the 12-byte tuples were 64 different lines per wave store: 12 of the kernel's 35 us
+    // on a column of distinct values)
     u32 rank[kCfPerThread + 1], part[kCfPerThread + 1];
 #pragma unroll
     for (u32 j = 0; j < kCfPerThread; ++j) {
@@ -430,15 +490,13 @@ __global__ __launch_bounds__(kCfThreads1) void colfreq_partition_kernel(const Co
         const u32 bin = t * per + k;
         if (bin < parts) local += s_hist[bin];
     }
-    s_scan[t] = local;
+    const u32 incl = wave_incl_scan_u32(local);
+    if ((t & 63u) == 63u) s_scan[t >> 6] = incl;
     __syncthreads();
-    for (u32 d = 1; d < kCfThreads1; d <<= 1) {  // Hillis-Steele over 1 024 partial sums
-        const u32 v = t >= d ? s_scan[t - d] : 0u;
-        __syncthreads();
-        s_scan[t] += v;
-        __syncthreads();
-    }
-    u32 run = s_scan[t] - local;  // exclusive prefix of this thread's first bin
+    u32 run = incl - local;  // exclusive prefix of this thread's first bin: within the wave, + the waves before it
+    for (u32 k = 0; k < (t >> 6); ++k) run += s_scan[k];
+    u32 total = 0;
+    for (u32 k = 0; k < kCfThreads1 / 64; ++k) total += s_scan[k];
     for (u32 k = 0; k < per; ++k) {
         const u32 bin = t * per + k;
         if (bin < parts) {
@@ -448,30 +506,39 @@ __global__ __launch_bounds__(kCfThreads1) void colfreq_partition_kernel(const Co
             run += cnt;
         }
     }
-    if (t == kCfThreads1 - 1) {
-        offs[(u64)parts * slabs + w] = (unsigned short)s_scan[t];          // tuples in this block (<= 8 192)
-        offs[(u64)(parts + 1) * slabs + w] = (unsigned short)s_trunc;      // (<= 8 192 as well)
+    if (t == 0) {
+        offs[(u64)parts * slabs + w] = (unsigned short)total;             // tuples in this block (<= 8 192)
+        offs[(u64)(parts + 1) * slabs + w] = (unsigned short)s_trunc;     // (<= 8 192 as well)
     }
-    __syncthreads();
-    u32* const block = tuples + (u64)w * kCfSlab * kCfTupleWords;
+    __syncthreads();  // (the row copies in s_buf are no longer read: phase A ended two barriers ago)
 #pragma unroll
     for (u32 j = 0; j < kCfPerThread; ++j) {
         if ((single >> j) & 1u) {
-            u32* const q = block + (u64)(s_hist[part[j]] + rank[j]) * kCfTupleWords;
-            const u32 rec = (u32)r0 + j * kCfThreads1 + t;
-            q[0] = rec;
+            u32* const q = s_buf + (s_hist[part[j]] + rank[j]) * kCfTupleWords;
+            q[0] = (u32)r0 + j * kCfThreads1 + t;
             q[1] = 1u;
             q[2] = (u32)hs[j];
         }
     }
     if (own_slot) {
-        u32* const q = block + (u64)(s_hist[part[kCfPerThread]] + rank[kCfPerThread]) * kCfTupleWords;
+        u32* const q = s_buf + (s_hist[part[kCfPerThread]] + rank[kCfPerThread]) * kCfTupleWords;
         q[0] = (u32)r0 + s_first[t];  // the smallest record holding the value stands for it from here on
         q[1] = s_count[t];
         q[2] = s_hlo[t];
     }
+    __syncthreads();
+    u32* const block = tuples + (u64)w * kCfSlab * kCfTupleWords;  // 96 KiB apart: 16-byte aligned
+    const u32 words = total * kCfTupleWords;
+    for (u32 k = 4 * t; k < words; k += 4 * kCfThreads1) {
+        if (k + 4 <= words) {
+            *reinterpret_cast<u32x4c*>(block + k) = *reinterpret_cast<const u32x4c*>(s_buf + k);
+        } else {
+            for (u32 q = k; q < words; ++q) block[q] = s_buf[q];
+        }
+    }
 }
 
+static constexpr u32 kCfGroup = 2048;  // blocks whose runs a pass-2 workgroup lines up at a time
 __global__ __launch_bounds__(kCfThreads2) void colfreq_reduce_kernel(const ColView c, const unsigned short* __restrict__ offs,
                                                                     const u32* __restrict__ tuples, u32 parts, u32 slabs,
                                                                     u64 first_record, ColFreqEntry* __restrict__ out, u64 out_cap,
@@ -479,6 +546,8 @@ __global__ __launch_bounds__(kCfThreads2) void colfreq_reduce_kernel(const ColVi
     __shared__ u64 s_key[kCfCap2];    // low 32 hash bits << 32 | representative record + 1; 0 = empty
     __shared__ u32 s_count[kCfCap2];
     __shared__ u32 s_first[kCfCap2];
+    __shared__ unsigned short s_beg[kCfGroup];  // where the partition's run starts in block w0 + k
+    __shared__ u32 s_pre[kCfGroup + 1];         // tuples of the partition in blocks w0 .. w0 + k - 1
     __shared__ u32 s_wave[kCfThreads2 / 64];
     __shared__ u32 s_total, s_overflow;
     __shared__ u64 s_base;
@@ -491,7 +560,8 @@ __global__ __launch_bounds__(kCfThreads2) void colfreq_reduce_kernel(const ColVi
         u32 mine = 0;
         for (u32 w = t; w < slabs; w += kCfThreads2)
             mine += (u32)offs[(u64)(p + 1) * slabs + w] - (u32)offs[(u64)p * slabs + w];
-        if (mine) atomicAdd(&s_total, mine);
+        mine = wave_sum_u32(mine);
+        if (lane == 0 && mine) atomicAdd(&s_total, mine);
         __syncthreads();
         const u32 total = s_total;
         const u32 rounds = total ? (total + kCfRound2 - 1) / kCfRound2 : 0;  // a skewed or huge partition: several passes over its tuples
@@ -501,14 +571,41 @@ __global__ __launch_bounds__(kCfThreads2) void colfreq_reduce_kernel(const ColVi
                 s_count[k] = 0;
                 s_first[k] = 0xffffffffu;
             }
-            __syncthreads();
-            // 16 lanes per block run: a run is ~16 tuples when all values are distinct, a few when they are not
-            for (u32 w = t >> 4; w < slabs; w += kCfThreads2 >> 4) {
-                const u32 b = offs[(u64)p * slabs + w], e = offs[(u64)(p + 1) * slabs + w];
-                const u32* const block = tuples + (u64)w * kCfSlab * kCfTupleWords;
-                for (u32 i = b + (t & 15u); i < e; i += 16) {
-                    const u32 rec = block[(u64)i * kCfTupleWords], cnt = block[(u64)i * kCfTupleWords + 1],
-                              h32 = block[(u64)i * kCfTupleWords + 2];
+            for (u32 w0 = 0; w0 < slabs; w0 += kCfGroup) {
+                // line the runs of kCfGroup blocks up: s_pre = exclusive prefix of their lengths (two blocks per thread, a
+                // wave scan, sixteen wave totals), so that tuple k of the group is found by a search in LDS and EVERY thread
+                // has a tuple to work on — a run is one tuple when the column has few values, sixteen when all differ
+                const u32 g = slabs - w0 < kCfGroup ? slabs - w0 : kCfGroup;
+                u32 len2[2];
+#pragma unroll
+                for (u32 j = 0; j < 2; ++j) {
+                    const u32 k = 2 * t + j;
+                    len2[j] = 0;
+                    if (k < g) {
+                        const u32 b = offs[(u64)p * slabs + w0 + k];
+                        len2[j] = (u32)offs[(u64)(p + 1) * slabs + w0 + k] - b;
+                        s_beg[k] = (unsigned short)b;
+                    }
+                }
+                const u32 incl = wave_incl_scan_u32(len2[0] + len2[1]);
+                if (lane == 63) s_wave[wv] = incl;
+                __syncthreads();  // (also: the table is cleared, the previous group's s_pre / s_beg are no longer read)
+                u32 before = 0;
+                for (u32 k = 0; k < wv; ++k) before += s_wave[k];
+                const u32 excl = before + incl - (len2[0] + len2[1]);
+                if (2 * t < g) s_pre[2 * t] = excl;
+                if (2 * t + 1 < g) s_pre[2 * t + 1] = excl + len2[0];
+                if (t == kCfThreads2 - 1) s_pre[g] = before + incl;  // (threads past g hold zeros: the last thread's inclusive sum is the total)
+                __syncthreads();
+                const u32 tg = s_pre[g];
+                for (u32 k = t; k < tg; k += kCfThreads2) {
+                    u32 lo = 0, hi = g;  // the block whose run holds tuple k: the last one with s_pre <= k
+                    while (hi - lo > 1) {
+                        const u32 mid = (lo + hi) >> 1;
+                        if (s_pre[mid] <= k) lo = mid; else hi = mid;
+                    }
+                    const u32* const q = tuples + ((u64)(w0 + lo) * kCfSlab + s_beg[lo] + (k - s_pre[lo])) * kCfTupleWords;
+                    const u32 rec = q[0], cnt = q[1], h32 = q[2];
                     if (rounds > 1 && ((h32 >> 13) % rounds) != r) continue;
                     const u64 key = ((u64)h32 << 32) | ((u64)rec + 1);
                     const u32 len = c.len ? c.len[rec] : c.stride;
@@ -525,8 +622,8 @@ __global__ __launch_bounds__(kCfThreads2) void colfreq_reduce_kernel(const ColVi
                     }
                     if (!done) s_overflow = 1;  // more distinct values with these hash bits than a table holds
                 }
+                __syncthreads();
             }
-            __syncthreads();
             // occupied slots -> entries; ONE reservation per workgroup and round
             u32 used[kCfCap2 / kCfThreads2], wave_total = 0;
 #pragma unroll
@@ -587,11 +684,15 @@ hipError_t launch_colfreq(const void* d_col, const void* d_len, u64 n_rows, u32 
     const ColView c = {(const uint8_t*)d_col, (const u32*)d_len, n_rows, stride};
     unsigned short* const offs = (unsigned short*)d_scratch;
     u32* const tuples = (u32*)((char*)d_scratch + g.offs_bytes);
-    hipLaunchKernelGGL(colfreq_partition_kernel, dim3(g.slabs), dim3(kCfThreads1), 0, stream, c, offs, tuples, g.parts, g.slabs,
-                       status);
+    if (stride <= 32)
+        hipLaunchKernelGGL(colfreq_partition_kernel<true>, dim3(g.slabs), dim3(kCfThreads1), 0, stream, c, offs, tuples, g.parts,
+                           g.slabs, status);
+    else
+        hipLaunchKernelGGL(colfreq_partition_kernel<false>, dim3(g.slabs), dim3(kCfThreads1), 0, stream, c, offs, tuples, g.parts,
+                           g.slabs, status);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const u32 cap = (u32)(n_cus > 0 ? n_cus : 256);  // one 144-KiB workgroup per CU
+    const u32 cap = (u32)(n_cus > 0 ? n_cus : 256);  // one 140-KiB workgroup per CU
     hipLaunchKernelGGL(colfreq_reduce_kernel, dim3(g.parts < cap ? g.parts : cap), dim3(kCfThreads2), 0, stream, c, offs, tuples,
                        g.parts, g.slabs, first_record, (ColFreqEntry*)d_entries, entries_cap, status);
     return hipGetLastError();

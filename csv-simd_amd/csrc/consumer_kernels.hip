@@ -49,12 +49,27 @@ __device__ __forceinline__ void field_span(const Column& c, u64 i, u64& b, u64& 
 // ---------------------------------------------------------------------------------------------
 // bulk seek_field / seek_record over a run of rows
 // ---------------------------------------------------------------------------------------------
+// longest: optional; the longest span seen is folded into *longest (one atomic per wave that has something to say)
 __global__ void chunk_spans_kernel(const u64* __restrict__ index, u64 first_key, u64 jump, u32 field, u32 fields, u64 n_rows,
-                                   u64* __restrict__ begin, u64* __restrict__ end) {
+                                   u64* __restrict__ begin, u64* __restrict__ end, u64* __restrict__ longest) {
+    u64 m = 0;
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += (u64)gridDim.x * blockDim.x) {
         const u64 k = first_key + i * jump + field;
-        begin[i] = index[k] + 1;
-        end[i] = index[k + fields];
+        const u64 b = index[k] + 1, e = index[k + fields];
+        begin[i] = b;
+        end[i] = e;
+        m = e > b && e - b > m ? e - b : m;
+    }
+    if (longest) {
+        for (int d = 32; d >= 1; d >>= 1) {
+            const u64 o = ((u64)(u32)__shfl_xor((int)(u32)(m >> 32), d) << 32) | (u32)__shfl_xor((int)(u32)m, d);
+            m = o > m ? o : m;
+        }
+        // an atomic on ONE word retires at ~90 per microsecond chip-wide (31 k waves: 0.35 ms, measured): a wave only
+        // sends one if the word it sees does not already say as much — on a column of similar lengths almost none do
+        if ((threadIdx.x & 63u) == 0 &&
+            m > __hip_atomic_load((const unsigned long long*)longest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax((unsigned long long*)longest, (unsigned long long)m);
     }
 }
 
@@ -107,33 +122,17 @@ __global__ void gather_fields_kernel(const uint8_t* __restrict__ bytes, u64 byte
 // counting algorithm here (64-bit hashes in a 32-byte-slot device table + a verification pass over every record:
 // 11-22 x the column's bytes in traffic).  Now the column is gathered once into fixed-stride rows (the two kernels
 // above) and counted by the ONE implementation of columnar_kernels.hip; what is left here is the glue:
-//   span_stats_kernel    the longest field of the column (the gather's stride) and the tape's last entry (how far the
-//                        gather may read)
+//   chunk_spans_kernel   (above) also reports the longest field of the column: the gather's stride
 //   freq_entries_kernel  the count's (row, count) entries -> csvsimd_freq_entry {record id, text span, count}
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void span_stats_kernel(const u64* __restrict__ begin, const u64* __restrict__ end, u64 n,
-                                                         const u64* __restrict__ index, u64 index_len, u64* __restrict__ out) {
-    u64 m = 0;
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
-        const u64 len = end[i] - begin[i];
-        m = len > m ? len : m;
-    }
-    for (int d = 32; d >= 1; d >>= 1) {
-        const u64 o = ((u64)(u32)__shfl_xor((int)(u32)(m >> 32), d) << 32) | (u32)__shfl_xor((int)(u32)m, d);
-        m = o > m ? o : m;
-    }
-    if ((threadIdx.x & 63u) == 0 && m) atomicMax((unsigned long long*)&out[0], (unsigned long long)m);
-    if (blockIdx.x == 0 && threadIdx.x == 0) out[1] = index[index_len - 1];
-}
-
-struct FreqRowMap {  // one per chunk: rows [row0, row0 + rows) of the gathered column are records first_record + ...
-    u64 row0, first_record;
+struct FreqRowMap {  // one per chunk: rows [row0, row0 + rows) of the gathered column are records first_record + ..., whose
+    u64 row0, first_record, first_key;  // field sits at tape key first_key + (row - row0) * jump + field
 };
 struct FreqEntry {  // == csvsimd_freq_entry: 32 bytes
     u64 first_record, begin, end, count;
 };
 __global__ __launch_bounds__(256) void freq_entries_kernel(const u64* __restrict__ ent16, const u64* __restrict__ cf_status,
-                                                           const u64* __restrict__ begin, const u64* __restrict__ end,
+                                                           const u64* __restrict__ index, u64 jump, u32 field,
                                                            const FreqRowMap* __restrict__ map, u32 n_chunks,
                                                            FreqEntry* __restrict__ out, u64 out_cap) {
     const u64 n = cf_status[1] < out_cap ? cf_status[1] : out_cap;  // n_distinct
@@ -144,7 +143,10 @@ __global__ __launch_bounds__(256) void freq_entries_kernel(const u64* __restrict
             const u32 mid = (lo + hi) >> 1;
             if (map[mid].row0 <= row) lo = mid; else hi = mid;
         }
-        out[k] = FreqEntry{map[lo].first_record + (row - map[lo].row0), begin[row], end[row], cnt};
+        const u64 d = row - map[lo].row0, key = map[lo].first_key + d * jump + field;
+        // the span again, from the tape itself: two neighbouring entries (the begin / end arrays would be two random reads)
+        const u64 b = index[key] + 1, e = index[key + 1];
+        out[k] = FreqEntry{map[lo].first_record + d, b, e > b ? e : b, cnt};
     }
 }
 
@@ -308,10 +310,10 @@ static u32 grid_for(u64 items, u32 per_block, u32 cap) {
 }
 
 hipError_t launch_chunk_spans(const void* dindex, u64 first_key, u64 jump, u32 field, u32 fields, u64 n_rows, void* d_begin,
-                              void* d_end, hipStream_t stream) {
+                              void* d_end, hipStream_t stream, void* d_longest) {
     if (n_rows == 0) return hipSuccess;
     hipLaunchKernelGGL(chunk_spans_kernel, dim3(grid_for(n_rows, 256, 4096)), dim3(256), 0, stream, (const u64*)dindex,
-                       first_key, jump, field, fields, n_rows, (u64*)d_begin, (u64*)d_end);
+                       first_key, jump, field, fields, n_rows, (u64*)d_begin, (u64*)d_end, (u64*)d_longest);
     return hipGetLastError();
 }
 
@@ -337,18 +339,11 @@ static Column make_column(const void* dbytes, const void* dindex, u64 first_key,
     return c;
 }
 
-hipError_t launch_span_stats(const void* d_begin, const void* d_end, u64 n, const void* dindex, u64 index_len, void* d_out,
-                             hipStream_t stream) {
-    hipLaunchKernelGGL(span_stats_kernel, dim3(grid_for(n, 256 * 8, 2048)), dim3(256), 0, stream, (const u64*)d_begin,
-                       (const u64*)d_end, n, (const u64*)dindex, index_len, (u64*)d_out);
-    return hipGetLastError();
-}
-
-hipError_t launch_freq_entries(const void* d_ent16, const void* d_cf_status, const void* d_begin, const void* d_end,
+hipError_t launch_freq_entries(const void* d_ent16, const void* d_cf_status, const void* dindex, u64 jump, u32 field,
                                const void* d_map, u32 n_chunks, void* d_out, u64 out_cap, u64 n_max, hipStream_t stream) {
     if (n_max == 0 || out_cap == 0) return hipSuccess;
-    hipLaunchKernelGGL(freq_entries_kernel, dim3(grid_for(n_max < out_cap ? n_max : out_cap, 256, 4096)), dim3(256), 0, stream,
-                       (const u64*)d_ent16, (const u64*)d_cf_status, (const u64*)d_begin, (const u64*)d_end,
+    hipLaunchKernelGGL(freq_entries_kernel, dim3(grid_for(n_max < out_cap ? n_max : out_cap, 256, 8192)), dim3(256), 0, stream,
+                       (const u64*)d_ent16, (const u64*)d_cf_status, (const u64*)dindex, jump, field,
                        (const FreqRowMap*)d_map, n_chunks, (FreqEntry*)d_out, out_cap);
     return hipGetLastError();
 }

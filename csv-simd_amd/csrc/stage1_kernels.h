@@ -104,12 +104,10 @@ hipError_t launch_stage1_batch(void* d_items, void* d_first_tiles, void* d_tots,
 const char* stage1_kernel_name(bool emit, int dialect);
 // consumer_kernels.hip: consumers of a finished, device-resident tape
 hipError_t launch_chunk_spans(const void* dindex, uint64_t first_key, uint64_t jump, uint32_t field, uint32_t fields,
-                              uint64_t n_rows, void* d_begin, void* d_end, hipStream_t stream);
+                              uint64_t n_rows, void* d_begin, void* d_end, hipStream_t stream, void* d_longest = nullptr);
 hipError_t launch_gather_fields(const void* dbytes, uint64_t bytes_len, const void* d_begin, const void* d_end,
                                 uint64_t n_records, void* d_dst, uint32_t stride, void* d_len, hipStream_t stream);
-hipError_t launch_span_stats(const void* d_begin, const void* d_end, uint64_t n, const void* dindex, uint64_t index_len,
-                             void* d_out, hipStream_t stream);
-hipError_t launch_freq_entries(const void* d_ent16, const void* d_cf_status, const void* d_begin, const void* d_end,
+hipError_t launch_freq_entries(const void* d_ent16, const void* d_cf_status, const void* dindex, uint64_t jump, uint32_t field,
                                const void* d_map, uint32_t n_chunks, void* d_out, uint64_t out_cap, uint64_t n_max,
                                hipStream_t stream);
 hipError_t launch_search(const void* dbytes, uint64_t bytes_len, const void* dindex, uint64_t first_key, uint64_t jump, uint64_t n_rows,
