@@ -1126,7 +1126,7 @@ def main():
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": load_traffic(args.workload, sb.n),
         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
-        "kernel": pkg.stage1_kernel_name(True), "kernels_per_launch": 1, "kernel_ms": round(kern_ms, 4),
+        "kernel": sb.ctx.kernel_name(), "kernels_per_launch": 1, "kernel_ms": round(kern_ms, 4),
         "kernel_ms_per_rank": {"min": round(min(per_rank_ms), 4), "max": round(max(per_rank_ms), 4),
                                "all": [round(x, 4) for x in per_rank_ms],
                                "note": "every rank times its own launches (HIP events on its stream); `kernel_ms`, "
@@ -1237,7 +1237,7 @@ def main():
                 del_sb = ShardBench(pkg, device, name, 1 << 30, 0, 1)
                 r = sharded.result_from_words(del_sb.run_pass(0).tolist())
                 ms = kernel_time_ms(del_sb, 20)
-                extra[name] = {"bytes": del_sb.n, "entries": r.count, "kernel_ms": round(ms, 4),
+                extra[name] = {"bytes": del_sb.n, "entries": r.count, "kernel": del_sb.ctx.kernel_name(), "kernel_ms": round(ms, 4),
                                "GiB/s": round(del_sb.n / (ms * 1e-3) / 2**30, 2),
                                "hbm_read_frac": round(del_sb.n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                                "read_plus_tape_write_GBps": round((del_sb.n + 8 * r.count) / (ms * 1e-3) / 1e9, 1)}

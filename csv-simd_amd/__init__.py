@@ -168,6 +168,8 @@ _PROTOTYPES = {
                                             C.c_int, C.POINTER(C.c_float)]),
     "csvsimd_tape_record_spans_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint64,
                                                    C.c_uint64, C.c_void_p, C.c_void_p, _u64p, C.c_void_p]),
+    "csvsimd_ctx_hint_density": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64]),
+    "csvsimd_ctx_kernel_name": (C.c_char_p, [C.c_void_p, C.POINTER(Dialect)]),
     "csvsimd_stage1_bound": (C.c_int, [C.c_uint64, _u64p]),
     "csvsimd_stage1_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, _u64p,
                                        C.POINTER(C.c_uint32)]),
@@ -289,6 +291,14 @@ class Context:
         _check(lib().csvsimd_ctx_create(device, C.byref(h)))
         self._h = h
         self.device = device
+
+    def hint_density(self, entries: int, nbytes: int) -> None:
+        """Entries per byte of the data about to be indexed (nbytes 0: forget): chooses the kernel instantiation of the
+        following launches (same tape either way)."""
+        _check(lib().csvsimd_ctx_hint_density(self._h, entries, nbytes))
+
+    def kernel_name(self, dialect: "Dialect" = None) -> str:
+        return lib().csvsimd_ctx_kernel_name(self._h, C.byref(dialect) if dialect is not None else None).decode()
 
     def reserve(self, max_len: int) -> None:
         _check(lib().csvsimd_ctx_reserve(self._h, max_len))

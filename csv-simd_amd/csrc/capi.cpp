@@ -265,13 +265,21 @@ struct csvsimd_ctx {
     int device = 0;
     void* scratch = nullptr;
     uint64_t scratch_bytes = 0;
+    // entries per input byte of the data this context indexes, as far as the host knows (< 0: not known): what the
+    // synchronous entry points and the ingest pipeline saw last, or what the caller said (csvsimd_ctx_hint_density).
+    // Above kDenseThreshold an emitting launch of the reference dialect runs the instantiation whose emit path is built
+    // for many entries per byte (stage1_kernels.hip: DENSE) — same tape, bit for bit; only the instruction mix differs.
+    double density = -1.0;
+    static constexpr double kDenseThreshold = 0.1;
     hipStream_t last_stream = nullptr;  // stream of the most recent launch that used the scratch
     bool launched = false;
     uint32_t max_blocks = 0;
     int n_cus = 0;
     csvsimd_shard_result* d_result = nullptr;  // for the synchronous entry points
-    void* d_small = nullptr;                   // 8 KiB: [0, 16) match / truncation counters, [64, 328) search needle,
-                                               // [1024, 5120) field list of csvsimd_chunk_to_columns_device
+    void* d_small = nullptr;                   // 8 KiB: [0, 16) match / truncation counters, [64, 328) search needle, [512, 544)
+                                               // status of the synchronous frequency count, [1024, 5120) field list of
+                                               // csvsimd_chunk_to_columns_device
+    void* h_small = nullptr;                   // 256 B pinned: where the synchronous consumers' few result words land
     // host-buffer path (csvsimd_stage1_index): kSlots-slot pipeline; every slot is allocated when a call first needs it
     static constexpr uint64_t kChunk = 32ull << 20;  // bytes per slot
     static constexpr int kSlots = 4;
@@ -359,6 +367,7 @@ int csvsimd_ctx_create(int device, csvsimd_ctx** out) {
     ctx->max_blocks = (uint32_t)(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256) * (uint32_t)per_cu;
     HIP_TRY(hipMalloc((void**)&ctx->d_result, sizeof(csvsimd_shard_result)));
     HIP_TRY(hipMalloc(&ctx->d_small, 8192));
+    HIP_TRY(hipHostMalloc(&ctx->h_small, 256, hipHostMallocDefault));
     *out = ctx.release();
     const int rc = csvsimd_ctx_reserve(*out, 1ull << 30);
     if (rc != CSVSIMD_OK) {
@@ -376,6 +385,7 @@ void csvsimd_ctx_destroy(csvsimd_ctx* ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->d_result) (void)hipFree(ctx->d_result);
     if (ctx->d_small) (void)hipFree(ctx->d_small);
+    if (ctx->h_small) (void)hipHostFree(ctx->h_small);
     if (ctx->d_batch) (void)hipFree(ctx->d_batch);
     for (int k = 0; k < 2; ++k) {
         if (ctx->pin_up[k]) (void)hipHostFree(ctx->pin_up[k]);
@@ -479,6 +489,7 @@ static int stage1_async_impl(csvsimd_ctx* ctx, const csvsimd_dialect* dialect, c
     L.max_blocks = ctx->max_blocks;
     L.d_state = d_state;
     L.d_chain = d_chain;
+    L.dense = !dialect && dtape && ctx->density > csvsimd_ctx::kDenseThreshold;
     if (dialect) {
         L.delimiter = dialect->delimiter;
         L.quote = dialect->quote;
@@ -606,8 +617,25 @@ int csvsimd_stage1_index_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len
         g_last_error = "stage1 kernel: look-back spin bound hit";
         return CSVSIMD_ERR_INTERNAL;
     }
+    // what this data looks like, for the next launch's choice of instantiation (a guessed entering state may have counted
+    // the wrong hypothesis: the larger of the two is what the text holds)
+    if (len >= (1u << 16))
+        ctx->density = (double)std::max(result->count_enter_outside, result->count_enter_inside) / (double)len;
     if (dtape && result->count > tape_cap) return CSVSIMD_ERR_TAPE_CAPACITY;
     return CSVSIMD_OK;
+}
+
+int csvsimd_ctx_hint_density(csvsimd_ctx* ctx, uint64_t entries, uint64_t bytes) {
+    if (!ctx) return CSVSIMD_ERR_INVALID_ARG;
+    ctx->density = bytes ? (double)entries / (double)bytes : -1.0;
+    return CSVSIMD_OK;
+}
+
+const char* csvsimd_ctx_kernel_name(const csvsimd_ctx* ctx, const csvsimd_dialect* dialect) {
+    if (!ctx) return "";
+    if (!dialect || (dialect->delimiter == ',' && dialect->quote == '"' && !dialect->escape))
+        return csvsimd::stage1_kernel_name(true, 0, !dialect && ctx->density > csvsimd_ctx::kDenseThreshold);
+    return csvsimd_stage1_kernel_name(1, dialect);
 }
 
 int csvsimd_stage1_bound(uint64_t len, uint64_t* max_entries) {
@@ -995,7 +1023,10 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
         }
         sh.cv.notify_all();
         n += r.count;
-        if (cuts[j + 1] > cuts[j]) entries_per_byte = (double)r.count / (double)(cuts[j + 1] - cuts[j]);
+        if (cuts[j + 1] > cuts[j]) {
+            entries_per_byte = (double)r.count / (double)(cuts[j + 1] - cuts[j]);
+            ctx->density = entries_per_byte;  // the following chunks' launches choose their instantiation by it
+        }
         host_inq = r.in_quote_out;
         host_esc = r.escape_out;
         return CSVSIMD_OK;
@@ -1530,11 +1561,11 @@ int csvsimd_gather_fields_device(const void* dbytes, uint64_t bytes_len, const v
     return CSVSIMD_OK;
 }
 
-// scratch of csvsimd_column_frequency_device: [64 B: max field length, last tape entry | chunk map | begin[n] | end[n] |
-// column n x stride | lengths n x 4 | the count's own scratch | its (row, count) entries n x 16 | its status 64 B]
+// scratch of csvsimd_column_frequency_device: [64 B: longest field | chunk map | begin[n] | end[n] | column n x stride |
+// lengths n x 4 | the count's own scratch | its status 64 B]
 namespace {
 struct FreqLayout {
-    uint64_t off_map, off_begin, off_end, off_col, off_len, off_cf, off_ent, off_status, total;
+    uint64_t off_map, off_begin, off_end, off_col, off_len, off_cf, off_status, total;
 };
 FreqLayout freq_layout(uint64_t n, uint32_t n_chunks, uint64_t stride) {
     auto up = [](uint64_t v) { return (v + 255) & ~(uint64_t)255; };
@@ -1545,8 +1576,7 @@ FreqLayout freq_layout(uint64_t n, uint32_t n_chunks, uint64_t stride) {
     L.off_col = up(L.off_end + n * 8);
     L.off_len = up(L.off_col + n * stride);
     L.off_cf = up(L.off_len + n * 4);
-    L.off_ent = up(L.off_cf + csvsimd::colfreq_scratch_bytes(n));
-    L.off_status = up(L.off_ent + n * 16);
+    L.off_status = up(L.off_cf + csvsimd::colfreq_scratch_bytes(n));
     L.total = L.off_status + 64;
     return L;
 }
@@ -1571,7 +1601,7 @@ int csvsimd_column_frequency_device(csvsimd_ctx* ctx, const void* dbytes, const 
     if (field_idx >= field_cnt) return CSVSIMD_ERR_INVALID_ARG;
     WITH_DEVICE_OF(ctx);
     std::vector<uint64_t> rows(n_chunks);
-    struct RowMap { uint64_t row0, first_record, first_key; };
+    using RowMap = csvsimd::FreqRowMap;
     std::vector<RowMap> map(n_chunks);
     uint64_t n = 0;
     for (uint32_t i = 0; i < n_chunks; ++i) {
@@ -1594,24 +1624,26 @@ int csvsimd_column_frequency_device(csvsimd_ctx* ctx, const void* dbytes, const 
     for (uint32_t i = 0; i < n_chunks; ++i)
         HIP_TRY(csvsimd::launch_chunk_spans(dindex, chunks[i].start, row_size, field_idx, 1, rows[i],
                                             base + L.off_begin + map[i].row0 * 8, base + L.off_end + map[i].row0 * 8, s, base));
-    uint64_t stats[2] = {0, 0};  // longest field; the tape's last entry (the file is at least that long + 1)
-    HIP_TRY(hipMemcpyAsync(&stats[0], base, 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&stats[1], (const char*)dindex + (index_len - 1) * 8, 8, hipMemcpyDeviceToHost, s));
+    // longest field; the tape's last entry (the file is at least that long + 1): two words into the context's pinned block
+    volatile uint64_t* const stats = (volatile uint64_t*)ctx->h_small;
+    HIP_TRY(hipMemcpyAsync((void*)&stats[0], base, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync((void*)&stats[1], (const char*)dindex + (index_len - 1) * 8, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     status->max_field_bytes = stats[0];
-    const uint64_t stride = stride_for(stats[0]);
+    const uint64_t longest = stats[0], last_entry = stats[1];
+    const uint64_t stride = stride_for(longest);
     if (stride > 0xfffffff0ull) return CSVSIMD_ERR_INVALID_ARG;
     L = freq_layout(n, n_chunks, stride);
     if (scratch_bytes < L.total) return CSVSIMD_ERR_TAPE_CAPACITY;  // csvsimd_column_frequency_scratch_bytes(n, n_chunks, status->max_field_bytes)
-    HIP_TRY(csvsimd::launch_gather_fields(dbytes, stats[1] + 1, base + L.off_begin, base + L.off_end, n, base + L.off_col,
+    HIP_TRY(csvsimd::launch_gather_fields(dbytes, last_entry + 1, base + L.off_begin, base + L.off_end, n, base + L.off_col,
                                           (uint32_t)stride, base + L.off_len, s));
-    HIP_TRY(csvsimd::launch_colfreq(base + L.off_col, base + L.off_len, n, (uint32_t)stride, 0, base + L.off_cf, base + L.off_ent, n,
-                                    base + L.off_status, ctx->n_cus, s));
-    HIP_TRY(csvsimd::launch_freq_entries(base + L.off_ent, base + L.off_status, dindex, row_size, field_idx, base + L.off_map,
-                                         n_chunks, d_entries, entries_cap, n, s));
-    csvsimd_colfreq_status cs;
-    HIP_TRY(hipMemcpyAsync(&cs, base + L.off_status, sizeof cs, hipMemcpyDeviceToHost, s));
+    // the count's second pass writes the entries in their final form: record id through the chunk map, text span from the tape
+    const csvsimd::FreqWideOut wide = {(const uint64_t*)dindex, row_size, field_idx, n_chunks, (const RowMap*)(base + L.off_map)};
+    HIP_TRY(csvsimd::launch_colfreq(base + L.off_col, base + L.off_len, n, (uint32_t)stride, 0, base + L.off_cf, d_entries,
+                                    entries_cap, base + L.off_status, ctx->n_cus, s, &wide));
+    HIP_TRY(hipMemcpyAsync((char*)ctx->h_small + 64, base + L.off_status, sizeof(csvsimd_colfreq_status), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    const csvsimd_colfreq_status cs = *reinterpret_cast<const csvsimd_colfreq_status*>((const char*)ctx->h_small + 64);
     status->n_distinct = cs.n_distinct;
     status->overflow = cs.overflow;
     if (cs.overflow) return CSVSIMD_ERR_TAPE_CAPACITY;
@@ -1736,8 +1768,9 @@ int csvsimd_columnar_frequency_device(csvsimd_ctx* ctx, const void* d_col, const
     if (rc != CSVSIMD_OK) return rc;
     WITH_DEVICE_OF(ctx);
     hipStream_t s = (hipStream_t)hip_stream;
-    HIP_TRY(hipMemcpyAsync(status, d_status, sizeof(*status), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync((char*)ctx->h_small + 128, d_status, sizeof(*status), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    memcpy(status, (const char*)ctx->h_small + 128, sizeof(*status));
     if (status->overflow) return CSVSIMD_ERR_TAPE_CAPACITY;   // more values with equal hash bits than a partition's table holds
     if (status->truncated) return CSVSIMD_ERR_TAPE_CAPACITY;  // values longer than the stride: counts would merge them
     if (status->n_distinct > entries_cap) return CSVSIMD_ERR_TAPE_CAPACITY;
@@ -1859,6 +1892,7 @@ int csvsimd_stage1_time_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len,
     L.d_result = (csvsimd_shard_result*)d_result;
     L.bind_scratch(ctx->scratch);
     L.max_blocks = ctx->max_blocks;
+    L.dense = dtape && ctx->density > csvsimd_ctx::kDenseThreshold;
 #ifdef CSVSIMD_DEV_PROBES
     // development builds only (libcsvsimd_probes.so for scripts/probe*.py): the product library has neither
     // these hooks nor the kernel instantiations behind them
@@ -1893,6 +1927,18 @@ int csvsimd_stage1_time_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len,
     ctx->last_stream = s;
     ctx->launched = true;
     for (int i = 0; i < warmup; ++i) HIP_TRY(csvsimd::launch_stage1(L, s));
+#ifndef CSVSIMD_DEV_PROBES
+    if (warmup > 0 && dtape) {
+        // the timed launches run what a caller's launches run once the context has seen this data: the warm-up's record
+        // says how dense it is (csvsimd_stage1_index_device learns it the same way)
+        csvsimd_shard_result* const hr = (csvsimd_shard_result*)ctx->h_small;
+        HIP_TRY(hipMemcpyAsync(hr, d_result, sizeof(*hr), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (!hr->error && len >= (1u << 16)) ctx->density = (double)hr->count / (double)len;
+        L.dense = ctx->density > csvsimd_ctx::kDenseThreshold;
+        for (int i = 0; i < std::min(warmup, 4); ++i) HIP_TRY(csvsimd::launch_stage1(L, s));
+    }
+#endif
     // one event pair per launch, recorded on the launch stream right around the stage-1 kernel (a launch
     // IS that one kernel)
     EventBatch eb;

@@ -539,10 +539,14 @@ __global__ __launch_bounds__(kCfThreads1) void colfreq_partition_kernel(const Co
 }
 
 static constexpr u32 kCfGroup = 2048;  // blocks whose runs a pass-2 workgroup lines up at a time
+struct ColFreqWideEntry {  // == csvsimd_freq_entry
+    u64 first_record, begin, end, count;
+};
+template <bool WIDE>
 __global__ __launch_bounds__(kCfThreads2) void colfreq_reduce_kernel(const ColView c, const unsigned short* __restrict__ offs,
                                                                     const u32* __restrict__ tuples, u32 parts, u32 slabs,
                                                                     u64 first_record, ColFreqEntry* __restrict__ out, u64 out_cap,
-                                                                    ColFreqStatus* __restrict__ status) {
+                                                                    ColFreqStatus* __restrict__ status, const FreqWideOut wide) {
     __shared__ u64 s_key[kCfCap2];    // low 32 hash bits << 32 | representative record + 1; 0 = empty
     __shared__ u32 s_count[kCfCap2];
     __shared__ u32 s_first[kCfCap2];
@@ -647,7 +651,22 @@ __global__ __launch_bounds__(kCfThreads2) void colfreq_reduce_kernel(const ColVi
                 if (used[j]) {
                     const u64 o = at + (u64)__builtin_popcountll(m & ((1ull << lane) - 1ull));
                     const u32 slot = j * kCfThreads2 + t;
-                    if (o < out_cap) out[o] = ColFreqEntry{first_record + s_first[slot], (u64)s_count[slot]};
+                    if (o < out_cap) {
+                        if (WIDE) {
+                            const u64 row = s_first[slot];
+                            u32 lo = 0, hi = wide.n_chunks;  // the last chunk whose row0 <= row
+                            while (hi - lo > 1) {
+                                const u32 mid = (lo + hi) >> 1;
+                                if (wide.map[mid].row0 <= row) lo = mid; else hi = mid;
+                            }
+                            const u64 d = row - wide.map[lo].row0, key = wide.map[lo].first_key + d * wide.jump + wide.field;
+                            const u64 b = wide.index[key] + 1, e = wide.index[key + 1];  // two neighbouring tape entries
+                            reinterpret_cast<ColFreqWideEntry*>(out)[o] =
+                                ColFreqWideEntry{wide.map[lo].first_record + d, b, e > b ? e : b, (u64)s_count[slot]};
+                        } else {
+                            out[o] = ColFreqEntry{first_record + s_first[slot], (u64)s_count[slot]};
+                        }
+                    }
                 }
                 at += (u64)__builtin_popcountll(m);
             }
@@ -677,7 +696,7 @@ static u32 cgrid_for(u64 items, u32 per_block, u32 cap) {
 }
 
 hipError_t launch_colfreq(const void* d_col, const void* d_len, u64 n_rows, u32 stride, u64 first_record, void* d_scratch,
-                          void* d_entries, u64 entries_cap, void* d_status, int n_cus, hipStream_t stream) {
+                          void* d_entries, u64 entries_cap, void* d_status, int n_cus, hipStream_t stream, const FreqWideOut* wide) {
     ColFreqStatus* const status = (ColFreqStatus*)d_status;
     if (n_rows == 0) return hipMemsetAsync(status, 0, sizeof(ColFreqStatus), stream);
     const ColFreqGeom g = colfreq_geom(n_rows);
@@ -693,8 +712,12 @@ hipError_t launch_colfreq(const void* d_col, const void* d_len, u64 n_rows, u32 
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const u32 cap = (u32)(n_cus > 0 ? n_cus : 256);  // one 140-KiB workgroup per CU
-    hipLaunchKernelGGL(colfreq_reduce_kernel, dim3(g.parts < cap ? g.parts : cap), dim3(kCfThreads2), 0, stream, c, offs, tuples,
-                       g.parts, g.slabs, first_record, (ColFreqEntry*)d_entries, entries_cap, status);
+    if (wide)
+        hipLaunchKernelGGL(colfreq_reduce_kernel<true>, dim3(g.parts < cap ? g.parts : cap), dim3(kCfThreads2), 0, stream, c, offs,
+                           tuples, g.parts, g.slabs, first_record, (ColFreqEntry*)d_entries, entries_cap, status, *wide);
+    else
+        hipLaunchKernelGGL(colfreq_reduce_kernel<false>, dim3(g.parts < cap ? g.parts : cap), dim3(kCfThreads2), 0, stream, c, offs,
+                           tuples, g.parts, g.slabs, first_record, (ColFreqEntry*)d_entries, entries_cap, status, FreqWideOut{});
     return hipGetLastError();
 }
 

@@ -75,21 +75,23 @@ __global__ void chunk_spans_kernel(const u64* __restrict__ index, u64 first_key,
 
 // ---------------------------------------------------------------------------------------------
 // gather: text of each span -> row i of dst (stride bytes, truncated, zero padded); len[i] = untruncated length.
-// A 16-lane group per record, each lane moves 16 bytes per step with one unaligned 16-byte load and one 16-byte
-// store (stride % 16 == 0 and an aligned dst) — round 1 moved single bytes.
+// A group of 2^gshift lanes per record (as many as the row has 16-byte pieces, at most 16: with 16 lanes on a 32-byte
+// row, rounds 1-3, seven lanes in eight had nothing to do), each lane moves 16 bytes per step with one unaligned 16-byte
+// load and one 16-byte store (stride % 16 == 0 and an aligned dst) — round 1 moved single bytes.
 // ---------------------------------------------------------------------------------------------
 __global__ void gather_fields_kernel(const uint8_t* __restrict__ bytes, u64 bytes_len, const u64* __restrict__ begin,
                                      const u64* __restrict__ end, u64 n_records, uint8_t* __restrict__ dst, u32 stride,
-                                     u32* __restrict__ len, int wide) {
-    const u32 sub = threadIdx.x & 15u;
-    for (u64 i = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 4; i < n_records;
-         i += ((u64)gridDim.x * blockDim.x) >> 4) {
+                                     u32* __restrict__ len, int wide, u32 gshift) {
+    const u32 lanes = 1u << gshift;
+    const u32 sub = threadIdx.x & (lanes - 1u);
+    for (u64 i = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> gshift; i < n_records;
+         i += ((u64)gridDim.x * blockDim.x) >> gshift) {
         const u64 b = begin[i], e = end[i];
         const u64 n = e > b ? e - b : 0;
         if (sub == 0 && len) len[i] = (u32)(n > 0xffffffffull ? 0xffffffffull : n);
         uint8_t* const row = dst + i * stride;
         if (wide) {
-            for (u32 k = sub * 16u; k < stride; k += 256u) {
+            for (u32 k = sub * 16u; k < stride; k += lanes * 16u) {
                 u32x4 v = {0, 0, 0, 0};
                 if (k < n) {
                     if (b + k + 16 <= bytes_len) {
@@ -112,7 +114,7 @@ __global__ void gather_fields_kernel(const uint8_t* __restrict__ bytes, u64 byte
                 *reinterpret_cast<u32x4*>(row + k) = v;
             }
         } else {
-            for (u32 k = sub; k < stride; k += 16) row[k] = k < n ? bytes[b + k] : (uint8_t)0;
+            for (u32 k = sub; k < stride; k += lanes) row[k] = k < n ? bytes[b + k] : (uint8_t)0;
         }
     }
 }
@@ -123,33 +125,8 @@ __global__ void gather_fields_kernel(const uint8_t* __restrict__ bytes, u64 byte
 // 11-22 x the column's bytes in traffic).  Now the column is gathered once into fixed-stride rows (the two kernels
 // above) and counted by the ONE implementation of columnar_kernels.hip; what is left here is the glue:
 //   chunk_spans_kernel   (above) also reports the longest field of the column: the gather's stride
-//   freq_entries_kernel  the count's (row, count) entries -> csvsimd_freq_entry {record id, text span, count}
+// and the count's second pass writes csvsimd_freq_entry {record id, text span, count} itself (FreqWideOut).
 // ---------------------------------------------------------------------------------------------
-struct FreqRowMap {  // one per chunk: rows [row0, row0 + rows) of the gathered column are records first_record + ..., whose
-    u64 row0, first_record, first_key;  // field sits at tape key first_key + (row - row0) * jump + field
-};
-struct FreqEntry {  // == csvsimd_freq_entry: 32 bytes
-    u64 first_record, begin, end, count;
-};
-__global__ __launch_bounds__(256) void freq_entries_kernel(const u64* __restrict__ ent16, const u64* __restrict__ cf_status,
-                                                           const u64* __restrict__ index, u64 jump, u32 field,
-                                                           const FreqRowMap* __restrict__ map, u32 n_chunks,
-                                                           FreqEntry* __restrict__ out, u64 out_cap) {
-    const u64 n = cf_status[1] < out_cap ? cf_status[1] : out_cap;  // n_distinct
-    for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (u64)gridDim.x * blockDim.x) {
-        const u64 row = ent16[2 * k], cnt = ent16[2 * k + 1];
-        u32 lo = 0, hi = n_chunks;  // the last chunk whose row0 <= row
-        while (hi - lo > 1) {
-            const u32 mid = (lo + hi) >> 1;
-            if (map[mid].row0 <= row) lo = mid; else hi = mid;
-        }
-        const u64 d = row - map[lo].row0, key = map[lo].first_key + d * jump + field;
-        // the span again, from the tape itself: two neighbouring entries (the begin / end arrays would be two random reads)
-        const u64 b = index[key] + 1, e = index[key + 1];
-        out[k] = FreqEntry{map[lo].first_record + d, b, e > b ? e : b, cnt};
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // search: one bit per row of the chunk (bit i of word i / 64 = row i matches) + the number of matches.
 //   mode 0 = field == needle, 1 = field starts with needle, 2 = field contains needle
@@ -321,9 +298,11 @@ hipError_t launch_gather_fields(const void* dbytes, u64 bytes_len, const void* d
                                 void* d_dst, u32 stride, void* d_len, hipStream_t stream) {
     if (n_records == 0 || stride == 0) return hipSuccess;
     const int wide = (stride % 16 == 0) && (((uintptr_t)d_dst & 15) == 0);
-    hipLaunchKernelGGL(gather_fields_kernel, dim3(grid_for(n_records * 16, 256, 8192)), dim3(256), 0, stream,
+    u32 gshift = 0;  // lanes per record: one per 16-byte piece of the row (per byte on the narrow path), a power of two <= 16
+    while (gshift < 4 && (1u << gshift) < (wide ? (stride + 15) / 16 : stride)) ++gshift;
+    hipLaunchKernelGGL(gather_fields_kernel, dim3(grid_for(n_records << gshift, 256, 16384)), dim3(256), 0, stream,
                        (const uint8_t*)dbytes, bytes_len, (const u64*)d_begin, (const u64*)d_end, n_records, (uint8_t*)d_dst,
-                       stride, (u32*)d_len, wide);
+                       stride, (u32*)d_len, wide, gshift);
     return hipGetLastError();
 }
 
@@ -337,15 +316,6 @@ static Column make_column(const void* dbytes, const void* dindex, u64 first_key,
     c.first_row = first_key / jump;
     c.field = field;
     return c;
-}
-
-hipError_t launch_freq_entries(const void* d_ent16, const void* d_cf_status, const void* dindex, u64 jump, u32 field,
-                               const void* d_map, u32 n_chunks, void* d_out, u64 out_cap, u64 n_max, hipStream_t stream) {
-    if (n_max == 0 || out_cap == 0) return hipSuccess;
-    hipLaunchKernelGGL(freq_entries_kernel, dim3(grid_for(n_max < out_cap ? n_max : out_cap, 256, 8192)), dim3(256), 0, stream,
-                       (const u64*)d_ent16, (const u64*)d_cf_status, (const u64*)dindex, jump, field,
-                       (const FreqRowMap*)d_map, n_chunks, (FreqEntry*)d_out, out_cap);
-    return hipGetLastError();
 }
 
 hipError_t launch_search(const void* dbytes, u64 bytes_len, const void* dindex, u64 first_key, u64 jump, u64 n_rows, u32 field,

@@ -55,6 +55,7 @@ struct Stage1Launch {
     uint8_t delimiter = ',', quote = '"', escape = 0;
     uint32_t escape_in = 0;
     bool allow_hashed_dialect = true;  // escape dialects: use the hashed LUT classification when the bytes allow it
+    bool dense = false;                // reference dialect, emitting launch: the instantiation with the test-free emit path
 
     static uint64_t scratch_bytes_for(uint64_t len) {
         // + 1 tile: an unaligned dbuf shifts the data by up to 127 bytes
@@ -101,15 +102,12 @@ static_assert(sizeof(BatchItemHost) == 64, "mirrors the device-side BatchItem");
 hipError_t launch_stage1_batch(void* d_items, void* d_first_tiles, void* d_tots, uint32_t n_items, uint32_t total_tiles,
                                csvsimd_shard_result* d_results, void* scratch_base, uint64_t* scratch_desc,
                                uint32_t max_blocks, hipStream_t stream);
-const char* stage1_kernel_name(bool emit, int dialect);
+const char* stage1_kernel_name(bool emit, int dialect, bool dense = false);
 // consumer_kernels.hip: consumers of a finished, device-resident tape
 hipError_t launch_chunk_spans(const void* dindex, uint64_t first_key, uint64_t jump, uint32_t field, uint32_t fields,
                               uint64_t n_rows, void* d_begin, void* d_end, hipStream_t stream, void* d_longest = nullptr);
 hipError_t launch_gather_fields(const void* dbytes, uint64_t bytes_len, const void* d_begin, const void* d_end,
                                 uint64_t n_records, void* d_dst, uint32_t stride, void* d_len, hipStream_t stream);
-hipError_t launch_freq_entries(const void* d_ent16, const void* d_cf_status, const void* dindex, uint64_t jump, uint32_t field,
-                               const void* d_map, uint32_t n_chunks, void* d_out, uint64_t out_cap, uint64_t n_max,
-                               hipStream_t stream);
 hipError_t launch_search(const void* dbytes, uint64_t bytes_len, const void* dindex, uint64_t first_key, uint64_t jump, uint64_t n_rows,
                          uint32_t field, const void* d_needle, uint32_t needle_len, int mode, void* d_bitmap, void* d_count,
                          hipStream_t stream);
@@ -122,8 +120,20 @@ hipError_t launch_to_columns(const void* dbytes, uint64_t bytes_len, const void*
 uint32_t to_columns_window_bytes();
 // exact frequency count on a column: two launches, no device-memory table (columnar_kernels.hip)
 uint64_t colfreq_scratch_bytes(uint64_t n_rows);
+// csvsimd_column_frequency_device: the column was gathered from chunks of the row-major file; the entries then leave as
+// csvsimd_freq_entry {record id, text span, count} — row -> record through the chunk map, span from the tape itself
+struct FreqRowMap {  // one per chunk, ascending row0: rows [row0, next row0) of the column are records first_record + ...,
+    uint64_t row0, first_record, first_key;  // whose field sits at tape key first_key + (row - row0) * jump + field
+};
+struct FreqWideOut {
+    const uint64_t* index;   // the tape WITH its sentinel
+    uint64_t jump;
+    uint32_t field, n_chunks;
+    const FreqRowMap* map;   // device
+};
 hipError_t launch_colfreq(const void* d_col, const void* d_len, uint64_t n_rows, uint32_t stride, uint64_t first_record,
-                          void* d_scratch, void* d_entries, uint64_t entries_cap, void* d_status, int n_cus, hipStream_t stream);
+                          void* d_scratch, void* d_entries, uint64_t entries_cap, void* d_status, int n_cus, hipStream_t stream,
+                          const FreqWideOut* wide = nullptr);
 hipError_t launch_colsearch(const void* d_col, const void* d_len, uint64_t n_rows, uint32_t stride, const void* d_needle,
                             uint32_t needle_len, int mode, void* d_bitmap, void* d_count, void* d_truncated,
                             hipStream_t stream);

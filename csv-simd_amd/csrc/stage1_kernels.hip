@@ -900,6 +900,112 @@ __device__ __forceinline__ void emit_span(u64* const tape, const u64 tape_cap, c
     wave_lds_fence();
 }
 
+// ---------------------------------------------------------------------------------------------
+// DENSE instantiation (round 4): the emit phase of a delimiter-dense file.  On the 1024 x 4 corpus a wave span holds
+// ~6 500 entries, the emit phase is ~21 us of INSTRUCTIONS per tile (profiles/r03_tile_timeline_dense_nostore.txt) and
+// the kernel is bound by their issue, not by HBM.  emit_span above spends ~16 instructions per entry and loop trip in
+// its scatter (a capacity test around every LDS store: its window may be smaller than a round) and ~25 per pair in its
+// flush (a tape-capacity test around every global store).  Here:
+//   * the window is the wave's two stage images side by side, 4 096 entries: a round (<= 4 096 set bits) ALWAYS fits, so
+//     the scatter needs no test and never takes several passes, and a dense span flushes twice instead of four times;
+//   * the tape's capacity is tested once per window: the flush loop is loads, adds, store;
+//   * both halves of a pair come from one 32-bit LDS read when the window index is even, and the 64-bit add of the
+//     span's offset shrinks to a 32-bit one when it cannot carry (tested once per flush).
+// A window that does not fit the tape's capacity leaves entry by entry (the capacity protocol is the rare case).
+// Chosen per launch by the entries-per-byte the context has last seen (capi.cpp); results are identical by
+// construction and by test (tests/test_gpu_dense_variant.py runs every configuration through both).
+// ---------------------------------------------------------------------------------------------
+static constexpr int kDenseCap = 2 * kRoundBytes / 2;  // u16 entries in 8 KiB
+static_assert(kDenseCap >= kRoundBytes, "a round's set bits always fit the dense window");
+
+__device__ __forceinline__ void scatter_bits_nocheck(unsigned short* comp, u64 R, u32 p, u32 stripe_rel) {
+    u32 lo = (u32)R, hi = (u32)(R >> 32);
+    unsigned short* q = comp + p;
+    while (lo) {
+        *q++ = (unsigned short)(stripe_rel + (u32)__builtin_ctz(lo));
+        lo &= lo - 1;
+    }
+    stripe_rel += 32u;
+    while (hi) {
+        *q++ = (unsigned short)(stripe_rel + (u32)__builtin_ctz(hi));
+        hi &= hi - 1;
+    }
+}
+
+// comp[0, n) -> tape[run, run + n).  ONE capacity test per window: a window that does not fit the tape whole (the caller's
+// tape is too small: the capacity protocol, never the timed case) leaves entry by entry, each store guarded — a loop of
+// a dozen instructions (emit_span inlined as the fallback cost this instantiation two spilled VGPRs).
+__device__ __forceinline__ void flush_window_dense(u64* const tape, const u64 tape_cap, const unsigned short* comp, u32 n, u64 run,
+                                                   u64 span_off, u32 lane) {
+    if (n == 0) return;
+    if (run + n > tape_cap) {  // wave-uniform
+        for (u32 k = lane; k < n; k += 64)
+            if (run + k < tape_cap) __builtin_nontemporal_store(span_off + comp[k], tape + run + k);
+        return;
+    }
+    u32 head = (0u - (u32)(((uintptr_t)tape >> 3) + run)) & (u32)(kStoreAlignEntries - 1);  // see flush_window
+    head = head < n ? head : n;
+    if (lane < head) __builtin_nontemporal_store(span_off + comp[lane], tape + run + lane);
+    const u32 npairs = (n - head) >> 1;
+    const u32 base_lo = (u32)span_off, base_hi = (u32)(span_off >> 32);
+    u64* const out = tape + run + head;
+    if (base_lo <= 0xffff0000u) {  // offset + u16 cannot carry: 32-bit adds (wave-uniform)
+        if ((head & 1u) == 0u) {   // pairs sit in aligned dwords of the window (wave-uniform)
+            const u32* const pairs = reinterpret_cast<const u32*>(comp + head);
+            for (u32 i = lane; i < npairs; i += 64) {
+                const u32 pr = pairs[i];
+                const u32x4 x = {base_lo + (pr & 0xffffu), base_hi, base_lo + (pr >> 16), base_hi};
+                __builtin_nontemporal_store(x, reinterpret_cast<u32x4*>(out + 2 * i));
+            }
+        } else {
+            for (u32 i = lane; i < npairs; i += 64) {
+                const u32 c0 = comp[head + 2 * i], c1 = comp[head + 2 * i + 1];
+                const u32x4 x = {base_lo + c0, base_hi, base_lo + c1, base_hi};
+                __builtin_nontemporal_store(x, reinterpret_cast<u32x4*>(out + 2 * i));
+            }
+        }
+    } else {
+        for (u32 i = lane; i < npairs; i += 64) {
+            const u64 e0 = span_off + comp[head + 2 * i], e1 = span_off + comp[head + 2 * i + 1];
+            const u32x4 x = {(u32)e0, (u32)(e0 >> 32), (u32)e1, (u32)(e1 >> 32)};
+            __builtin_nontemporal_store(x, reinterpret_cast<u32x4*>(out + 2 * i));
+        }
+    }
+    if (((n - head) & 1u) && lane == 0) __builtin_nontemporal_store(span_off + comp[n - 1], tape + run + n - 1);
+}
+
+// emit_span for the DENSE instantiation: comp = the wave's 8-KiB window
+__device__ __forceinline__ void emit_span_dense(u64* const tape, const u64 tape_cap, const RoundMasks (&m)[kRounds], u32 lane,
+                                                const u64 span_off, u32 wstate, u64 run, unsigned short* comp) {
+    const u64 flipall = wstate ? ~0ull : 0ull;
+    u32 fill = 0;
+    run = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(run >> 32)) << 32) |
+          (u32)__builtin_amdgcn_readfirstlane((int)(u32)run);
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+        const u64 R = m[r].st & ~(m[r].s ^ flipall);
+        const u32 c = (u32)__builtin_popcountll(R);
+        const u32 incl = wave_incl_scan_add(c);
+        const u32 n_r = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        u32 roff = (u32)r * kRoundBytes;
+        asm volatile("" : "+s"(roff));  // (see emit_span)
+        if (fill + n_r > (u32)kDenseCap) {
+            wave_lds_fence();
+            flush_window_dense(tape, tape_cap, comp, fill, run, span_off, lane);
+            wave_lds_fence();
+            run += fill;
+            fill = 0;
+        }
+        scatter_bits_nocheck(comp, R, fill + incl - c, roff + lane * 64u);
+        fill += n_r;
+        asm volatile("" : "+s"(fill), "+s"(run));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    wave_lds_fence();
+    flush_window_dense(tape, tape_cap, comp, fill, run, span_off, lane);
+    wave_lds_fence();
+}
+
 // The end of a launch (wave 0 of every workgroup): count this workgroup done; the workgroup whose add completes the
 // count writes the result record from the last tile's inclusive word and leaves the control block ready for the next
 // launch.
@@ -1181,17 +1287,23 @@ __device__ __forceinline__ u32 batch_item_of(const u32* first_tiles, u32 n_items
     return idx;
 }
 
-template <bool EMIT, int DBG = 0, int DIALECT = 0, bool BATCH = false>
+template <bool EMIT, int DBG = 0, int DIALECT = 0, bool BATCH = false, bool DENSE = false>
 __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
     __shared__ u32 s_tile;
     __shared__ u32 s_wdesc[kWaves][3];
     __shared__ u32 s_pin;
     __shared__ u64 s_base;
     // wave-private images: input transpose in the count phase (two, double-buffered LDS-DMA), u16
-    // compaction window in the emit phase (the uses never overlap in time within a wave)
-    __shared__ uint4 s_stage[kWaves][kRoundBytes / 16];
-    __shared__ uint4 s_stage_b[kWaves][kRoundBytes / 16];
+    // compaction window in the emit phase (the uses never overlap in time within a wave).
+    // DENSE: a wave's two images are ONE 8-KiB block, so that together they are its 4 096-entry emit window
+    // (for the default instantiation the two stay separate arrays: side by side they cost it 6 %, NOTEBOOK.md round 2)
+    constexpr int kImg = kRoundBytes / 16;
+    __shared__ uint4 s_stage_a[kWaves][DENSE ? 2 * kImg : kImg];
+    __shared__ uint4 s_stage_bb[DENSE ? 1 : kWaves][DENSE ? 1 : kImg];
     static_assert(kCompCap * 2 <= kRoundBytes, "compaction window must fit the stage image");
+    static_assert(!DENSE || (EMIT && DBG == 0 && DIALECT == 0 && !BATCH), "the dense emit path exists for the reference dialect's emitting launch");
+#define s_stage_of(wave) (s_stage_a[wave])
+#define s_stage_b_of(wave) (DENSE ? s_stage_a[wave] + kImg : s_stage_bb[DENSE ? 0 : (wave)])
     // escape dialects only (the array does not exist in the other instantiations): the masks of the held tile's LAST
     // round are parked here across the count phase of the next tile — those variants are four VGPRs short there (a third
     // mask and the run-parity chain are in flight), and what hipcc spills otherwise is exactly this pair, to scratch
@@ -1384,7 +1496,7 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
                 // pacing (NOTEBOOK.md "Pacing"): the phase that keeps HBM loads in flight gets the SIMD's issue
                 // priority over the partner workgroup's resolve / emit phase
                 if (uniform_again<(DIALECT >= 2 || BATCH)>(args.count_prio)) __builtin_amdgcn_s_setprio(3);
-                count_phase<DIALECT>(rsrc, lane, w, ek, s_stage[w], s_stage_b[w], m, carry, cnt_a, cnt_t, dr,
+                count_phase<DIALECT>(rsrc, lane, w, ek, s_stage_of(w), s_stage_b_of(w), m, carry, cnt_a, cnt_t, dr,
                                      esc_carry);
                 if (uniform_again<(DIALECT >= 2 || BATCH)>(args.count_prio)) __builtin_amdgcn_s_setprio(0);
             }
@@ -1434,7 +1546,7 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
             if (uniform_again<(DIALECT >= 2 || BATCH)>(inq_in) == kEnterGuess && have_cur && tile < kGuessTiles && !(DBG & 4))
                 guess_vote(args.desc, args.ctl, args.num_tiles, epoch, lane, err);
             // into wave 0's second stage image: idle until the next count phase
-            if (have_held && !(DBG & 4)) lookback_issue(args.desc, held_tile, lane, s_stage_b[0]);
+            if (have_held && !(DBG & 4)) lookback_issue(args.desc, held_tile, lane, s_stage_b_of(0));
         }
         bool spec_done = false;
         const u32 spec_pin = held_agg.b > held_agg.a ? 1u : 0u;      // the guess: the hypothesis with more entries
@@ -1446,7 +1558,7 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
                 held[kRounds - 1].st = ((u64)pk.y << 32) | pk.x;
                 held[kRounds - 1].s = ((u64)pk.w << 32) | pk.z;
             }
-            scatter_span_spec(held, lane, spec_state, reinterpret_cast<unsigned short*>(s_stage[w]));
+            scatter_span_spec(held, lane, spec_state, reinterpret_cast<unsigned short*>(s_stage_of(w)));
             spec_done = true;
         }
         if (have_held) {
@@ -1470,11 +1582,11 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef CSVSIMD_DEV_PROBES
                 if (DBG & 32) trace_landed = __builtin_amdgcn_s_memrealtime();
-                lookback_fetch(s_stage_b[0], held_tile, lane, pre);
+                lookback_fetch(s_stage_b_of(0), held_tile, lane, pre);
                 resolve<true>(args.desc, held_tile, epoch, held_agg, inq_eff, lane, pin, base, err, pre,
                               (DBG & 32) ? &trace_ws : nullptr, held_first);
 #else
-                lookback_fetch(s_stage_b[0], held_tile, lane, pre);
+                lookback_fetch(s_stage_b_of(0), held_tile, lane, pre);
                 resolve<true>(args.desc, held_tile, epoch, held_agg, inq_eff, lane, pin, base, err, pre, nullptr, held_first);
 #endif
             }
@@ -1527,11 +1639,14 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
             if (spec_done && pin == (held_agg.b > held_agg.a ? 1u : 0u)) {
                 // the guess was right: the window already holds the span's entries, only the stores are left
                 wave_lds_fence();
-                flush_window(e_tape, e_cap, reinterpret_cast<unsigned short*>(s_stage[w]), spec_n,
+                flush_window(e_tape, e_cap, reinterpret_cast<unsigned short*>(s_stage_of(w)), spec_n,
                              ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(run >> 32)) << 32) |
                                  (u32)__builtin_amdgcn_readfirstlane((int)(u32)run),
                              e_off + span0, lane);
                 wave_lds_fence();
+            } else if (DENSE) {
+                // (wave 0's look-back window, which shares the 8 KiB, was consumed before barrier B)
+                emit_span_dense(e_tape, e_cap, held, lane, e_off + span0, wstate, run, reinterpret_cast<unsigned short*>(s_stage_of(w)));
             } else {
                 if (kPark) {  // (the speculative scatter may not have run: the pair is fetched again)
                     const uint4 pk = s_park[w][lane];
@@ -1539,7 +1654,7 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
                     held[kRounds - 1].s = ((u64)pk.w << 32) | pk.z;
                 }
                 emit_span<(DBG & 16) != 0>(e_tape, e_cap, held, lane, e_off + span0, wstate, run,
-                                           reinterpret_cast<unsigned short*>(s_stage[w]));
+                                           reinterpret_cast<unsigned short*>(s_stage_of(w)));
             }
         }
         if (have_held) { CSVSIMD_TRACE(5, held_tile) }
@@ -1592,6 +1707,8 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
 #undef CSVSIMD_TRACE
 #undef CSVSIMD_TRACEX
 
+#undef s_stage_of
+#undef s_stage_b_of
     // ---- this workgroup is done; the last one to get here completes the launch --------------------
     if (w != 0) return;
     finish_launch<DIALECT, (DBG & 4) != 0, BATCH>(args, epoch_v & kEpochMask, inq_in,
@@ -1963,6 +2080,8 @@ hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream) {
         hipLaunchKernelGGL((stage1_kernel<true, 0, 1>), dim3(grid), dim3(kThreads), 0, stream, a);
     else if (dialect == 1)
         hipLaunchKernelGGL((stage1_kernel<false, 0, 1>), dim3(grid), dim3(kThreads), 0, stream, a);
+    else if (a.tape && L.dense)
+        hipLaunchKernelGGL((stage1_kernel<true, 0, 0, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);
     else if (a.tape)
         hipLaunchKernelGGL((stage1_kernel<true, 0>), dim3(grid), dim3(kThreads), 0, stream, a);
     else
@@ -1998,16 +2117,17 @@ hipError_t launch_stage1_batch(void* d_items, void* d_first_tiles, void* d_tots,
 }
 
 // name of the kernel launch_stage1 runs for this configuration (bench.py reports it next to the time)
-const char* stage1_kernel_name(bool emit, int dialect) {
+const char* stage1_kernel_name(bool emit, int dialect, bool dense) {
     static const char* names[2][4] = {
-        {"void csvsimd::stage1_kernel<false, 0, 0, false>(csvsimd::KernelArgs)",
-         "void csvsimd::stage1_kernel<false, 0, 1, false>(csvsimd::KernelArgs)",
-         "void csvsimd::stage1_kernel<false, 0, 2, false>(csvsimd::KernelArgs)",
-         "void csvsimd::stage1_kernel<false, 0, 3, false>(csvsimd::KernelArgs)"},
-        {"void csvsimd::stage1_kernel<true, 0, 0, false>(csvsimd::KernelArgs)",
-         "void csvsimd::stage1_kernel<true, 0, 1, false>(csvsimd::KernelArgs)",
-         "void csvsimd::stage1_kernel<true, 0, 2, false>(csvsimd::KernelArgs)",
-         "void csvsimd::stage1_kernel<true, 0, 3, false>(csvsimd::KernelArgs)"}};
+        {"void csvsimd::stage1_kernel<false, 0, 0, false, false>(csvsimd::KernelArgs)",
+         "void csvsimd::stage1_kernel<false, 0, 1, false, false>(csvsimd::KernelArgs)",
+         "void csvsimd::stage1_kernel<false, 0, 2, false, false>(csvsimd::KernelArgs)",
+         "void csvsimd::stage1_kernel<false, 0, 3, false, false>(csvsimd::KernelArgs)"},
+        {"void csvsimd::stage1_kernel<true, 0, 0, false, false>(csvsimd::KernelArgs)",
+         "void csvsimd::stage1_kernel<true, 0, 1, false, false>(csvsimd::KernelArgs)",
+         "void csvsimd::stage1_kernel<true, 0, 2, false, false>(csvsimd::KernelArgs)",
+         "void csvsimd::stage1_kernel<true, 0, 3, false, false>(csvsimd::KernelArgs)"}};
+    if (emit && dense && dialect == 0) return "void csvsimd::stage1_kernel<true, 0, 0, false, true>(csvsimd::KernelArgs)";
     return names[emit ? 1 : 0][dialect < 0 || dialect > 3 ? 0 : dialect];
 }
 

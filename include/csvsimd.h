@@ -207,6 +207,17 @@ int csvsimd_stage1_index_dialect(csvsimd_ctx* ctx, const csvsimd_dialect* dialec
                                  uint64_t len, uint64_t* tape, uint64_t tape_cap, uint64_t* tape_len,
                                  uint32_t* in_quote_out);
 
+/* Entries per input byte of the data this context is about to index (entries structural bytes in `bytes` bytes of
+ * text like it; bytes == 0: forget).  The device entry points choose between two instantiations of the stage-1 kernel
+ * by it — above ~0.1 (delimiter-dense files: BASELINE config 5 holds 0.2) the one whose emit path spends fewer
+ * instructions per entry — and produce the same tape either way (reference: crush_set_bits is one routine for every
+ * density, src/stage1.rs:162-296).  The synchronous entry points and csvsimd_stage1_index learn the figure themselves
+ * from the records they read; a caller of the _async entry points, which return before any record exists, may say it.
+ * csvsimd_ctx_kernel_name: the kernel the context's next emitting launch of `dialect` (NULL: the reference's) runs. */
+int csvsimd_ctx_hint_density(csvsimd_ctx* ctx, uint64_t entries, uint64_t bytes);
+const char* csvsimd_ctx_kernel_name(const csvsimd_ctx* ctx, const csvsimd_dialect* dialect);
+
+
 /* ---- multi-GPU stitch (host arithmetic; the exchange itself is one all-gather of these
  * descriptors over RCCL, done by the caller's communicator) -----------------------------------
  * New relative to the reference (single-threaded; README.md:24 lists it as a TODO).  Given the

@@ -45,19 +45,20 @@ def test_product_library_has_no_probe_hooks(pkg):
     assert os.path.basename(so) == "libcsvsimd_hip.so"
     assert not pkg.build_has_probes()
     nm = subprocess.run(["nm", "-C", so], check=True, capture_output=True, text=True).stdout
-    inst = sorted(set(re.findall(r"__device_stub__stage1_kernel<(\w+), (\d+), (\d+), (\w+)>", nm)))
-    # emit / count-only x four dialect classifications, DBG always 0; + the batched launch (reference dialect, emit)
-    assert inst == sorted([(e, "0", d, "false") for e in ("false", "true") for d in ("0", "1", "2", "3")]
-                          + [("true", "0", "0", "true")]), inst
+    inst = sorted(set(re.findall(r"__device_stub__stage1_kernel<(\w+), (\d+), (\d+), (\w+), (\w+)>", nm)))
+    # emit / count-only x four dialect classifications, DBG always 0; + the batched launch and the dense-emit instantiation
+    # (reference dialect, emit)
+    assert inst == sorted([(e, "0", d, "false", "false") for e in ("false", "true") for d in ("0", "1", "2", "3")]
+                          + [("true", "0", "0", "true", "false"), ("true", "0", "0", "false", "true")]), inst
     raw = open(so, "rb").read()
     assert b"CSVSIMD_PROBE" not in raw and b"zero_kernel" not in raw and b"finalize_kernel" not in raw
     # what bench.py reports as the timed kernel comes from the library, and is the default instantiation
-    assert pkg.stage1_kernel_name(True) == "void csvsimd::stage1_kernel<true, 0, 0, false>(csvsimd::KernelArgs)"
+    assert pkg.stage1_kernel_name(True) == "void csvsimd::stage1_kernel<true, 0, 0, false, false>(csvsimd::KernelArgs)"
     # an escape dialect runs the hashed classification (<..., 3>) when its special bytes hash without a collision,
     # the direct compares (<..., 2>) otherwise: the library says which
-    assert pkg.stage1_kernel_name(False, pkg.Dialect(";", "'", "\\")).endswith("<false, 0, 3, false>(csvsimd::KernelArgs)")
+    assert pkg.stage1_kernel_name(False, pkg.Dialect(";", "'", "\\")).endswith("<false, 0, 3, false, false>(csvsimd::KernelArgs)")
     names = {pkg.stage1_kernel_name(True, pkg.Dialect(d, q, e)) for d in ";|\t:A" for q in "'`\"" for e in "\\^~%/"}
-    assert {n.split(", ")[-2] for n in names} == {"2", "3"}
+    assert {n.split(", ")[-3] for n in names} == {"2", "3"}
 
 
 def test_no_cpu_fallback(pkg):
