@@ -19,6 +19,7 @@
 #define CSVSIMD_WAVES_PER_EU 4
 #endif
 #define CSVSIMD_TILE_BYTES (CSVSIMD_COMPUTE_WAVES * CSVSIMD_ROUNDS * 4096)
+#define CSVSIMD_MIN_TILE_BYTES (CSVSIMD_COMPUTE_WAVES * 2 * 4096) /* the dense instantiation: 2 rounds (stage1_dense.hip) */
 
 namespace csvsimd {
 
@@ -58,8 +59,9 @@ struct Stage1Launch {
     bool dense = false;                // reference dialect, emitting launch: the instantiation with the test-free emit path
 
     static uint64_t scratch_bytes_for(uint64_t len) {
-        // + 1 tile: an unaligned dbuf shifts the data by up to 127 bytes
-        const uint64_t tiles = (len + 127 + CSVSIMD_TILE_BYTES - 1) / CSVSIMD_TILE_BYTES + 1;
+        // one descriptor word per tile of the SMALLEST geometry a launch may choose (the dense instantiation's 64-KiB
+        // tiles: 8 bytes per 64 KiB of input); + 1 tile: an unaligned dbuf shifts the data by up to 127 bytes
+        const uint64_t tiles = (len + 127 + CSVSIMD_MIN_TILE_BYTES - 1) / CSVSIMD_MIN_TILE_BYTES + 1;
         return CSVSIMD_SCRATCH_DESC_OFFSET + 8 * tiles + 16;
     }
     void bind_scratch(void* base) {
@@ -75,6 +77,11 @@ struct DialectHash {
 };
 bool dialect_hash(uint32_t delim, uint32_t quote, uint32_t esc, DialectHash& h);
 hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream);
+}  // namespace csvsimd
+namespace csvsimd_dense {
+hipError_t launch_stage1_dense(const csvsimd::Stage1Launch& L, hipStream_t stream);  // stage1_dense.hip
+}
+namespace csvsimd {
 hipError_t launch_synth(void* dbuf, uint64_t file_off, uint64_t len, uint32_t cols, uint32_t width,
                         uint64_t seed, uint32_t quote_pct, hipStream_t stream);
 hipError_t launch_checksum(const void* dtape, uint64_t n, uint64_t first_index, void* d_out,

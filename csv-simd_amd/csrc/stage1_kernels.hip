@@ -35,7 +35,19 @@
 
 #include "stage1_kernels.h"
 
+// This file is compiled TWICE (Makefile): as itself — every kernel and launcher, the 8-round geometry (256-KiB tiles) —
+// and through stage1_dense.hip with CSVSIMD_DENSE_TU: only stage1_kernel<..., DENSE> at 2 rounds per wave (64-KiB tiles)
+// and its launcher, in namespace csvsimd_dense.  Write-heavy streams run faster the smaller the unit a workgroup draws
+// (the delimiter-dense corpus writes 1.6 bytes per byte read), the sparse corpora slower: the geometry is
+// a per-instantiation choice, made per launch by the data's density.
+#ifdef CSVSIMD_DENSE_TU
+#define CSVSIMD_KERNEL_NS csvsimd_dense
+namespace csvsimd_dense {
+using namespace csvsimd;
+#else
+#define CSVSIMD_KERNEL_NS csvsimd
 namespace csvsimd {
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // geometry
@@ -1137,6 +1149,8 @@ __device__ __forceinline__ void finish_launch(const KernelArgs& args, u32 epoch,
 // quoted and nearly every separator disappears; a quote-free tile has no entries at all "entered inside") — and only
 // the tape index base is still missing, which the window does not need.  A wrong guess costs the tile the ordinary
 // emit after the look-back, never correctness.  The caller makes sure the span's entries fit one window.
+__device__ __forceinline__ void scatter_bits_nocheck(unsigned short* comp, u64 R, u32 p, u32 stripe_rel);
+template <bool NOCHECK = false>
 __device__ __forceinline__ void scatter_span_spec(const RoundMasks (&m)[kRounds], u32 lane, u32 wstate, unsigned short* comp) {
     const u64 flipall = wstate ? ~0ull : 0ull;
     u32 fill = 0;
@@ -1148,7 +1162,8 @@ __device__ __forceinline__ void scatter_span_spec(const RoundMasks (&m)[kRounds]
         const u32 n_r = (u32)__builtin_amdgcn_readlane((int)incl, 63);
         u32 roff = (u32)r * kRoundBytes;
         asm volatile("" : "+s"(roff));
-        scatter_bits(comp, R, fill + incl - c, roff + lane * 64u);
+        if (NOCHECK) scatter_bits_nocheck(comp, R, fill + incl - c, roff + lane * 64u);  // (the caller made sure the span fits)
+        else scatter_bits(comp, R, fill + incl - c, roff + lane * 64u);
         fill += n_r;
         asm volatile("" : "+s"(fill));
         __builtin_amdgcn_sched_barrier(0);
@@ -1222,7 +1237,7 @@ static_assert(offsetof(csvsimd_stitch, reemit) == 4 * kStitchReemitWord && offse
 // them.)  The voters' count phases run concurrently at the start of the launch and wait for nothing, so the choice
 // is there before any workgroup needs it (wave 0 of a workgroup that resolves a tile: wait_for_guess); no tile
 // becomes inclusive before the choice exists, so the words read back here are still aggregates.
-constexpr u32 kGuessTiles = 8;
+constexpr u32 kGuessTiles = (2u << 20) / (u32)kTileBytes;  // 8 tiles of 256 KiB (32 of the dense geometry's 64 KiB)
 __device__ __forceinline__ void guess_vote(u64* desc, Control* ctl, u32 num_tiles, u32 epoch, u32 lane, u32& err) {
     const u32 voters = num_tiles < kGuessTiles ? num_tiles : kGuessTiles;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's aggregate has left before it is counted in
@@ -1558,7 +1573,7 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
                 held[kRounds - 1].st = ((u64)pk.y << 32) | pk.x;
                 held[kRounds - 1].s = ((u64)pk.w << 32) | pk.z;
             }
-            scatter_span_spec(held, lane, spec_state, reinterpret_cast<unsigned short*>(s_stage_of(w)));
+            scatter_span_spec<DENSE>(held, lane, spec_state, reinterpret_cast<unsigned short*>(s_stage_of(w)));
             spec_done = true;
         }
         if (have_held) {
@@ -1639,10 +1654,10 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
             if (spec_done && pin == (held_agg.b > held_agg.a ? 1u : 0u)) {
                 // the guess was right: the window already holds the span's entries, only the stores are left
                 wave_lds_fence();
-                flush_window(e_tape, e_cap, reinterpret_cast<unsigned short*>(s_stage_of(w)), spec_n,
-                             ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(run >> 32)) << 32) |
-                                 (u32)__builtin_amdgcn_readfirstlane((int)(u32)run),
-                             e_off + span0, lane);
+                const u64 run_u = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(run >> 32)) << 32) |
+                                  (u32)__builtin_amdgcn_readfirstlane((int)(u32)run);
+                if (DENSE) flush_window_dense(e_tape, e_cap, reinterpret_cast<unsigned short*>(s_stage_of(w)), spec_n, run_u, e_off + span0, lane);
+                else flush_window(e_tape, e_cap, reinterpret_cast<unsigned short*>(s_stage_of(w)), spec_n, run_u, e_off + span0, lane);
                 wave_lds_fence();
             } else if (DENSE) {
                 // (wave 0's look-back window, which shares the 8 KiB, was consumed before barrier B)
@@ -1717,6 +1732,69 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
                                            // would otherwise have to survive the tile loop in a register the loop needs
                                            __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
 }
+
+// KernelArgs of one launch over L's buffer (everything but the dialect's hashed tables)
+static void fill_kernel_args(const Stage1Launch& L, KernelArgs& a) {
+    const uintptr_t addr = (uintptr_t)L.dbuf;
+    a.abase = (const uint8_t*)(addr & ~(uintptr_t)15);
+    a.lo = (u64)(addr & 15);
+    a.hi = a.lo + L.len;
+    a.base_off = L.base_off;
+    a.in_quote_in = L.in_quote_in <= CSVSIMD_ENTER_GUESS ? L.in_quote_in : 1u;  // 0, 1 or CSVSIMD_ENTER_GUESS
+    a.num_tiles = (u32)((a.hi + kTileBytes - 1) / kTileBytes);
+    if (L.len == 0) a.num_tiles = 0;
+    a.tape = (u64*)L.dtape;
+    a.tape_cap = L.dtape ? L.tape_cap : 0;
+    a.desc = L.scratch_desc;
+    a.ctl = reinterpret_cast<Control*>(L.scratch_base);
+    a.result = L.d_result;
+    a.state_ptr = L.d_state;
+    a.chain = L.d_chain;
+    a.delim = L.delimiter;
+    a.quote = L.quote;
+    a.escape = L.escape;
+    a.escape_in = (L.escape && L.escape_in) ? 1u : 0u;
+    // Pacing: the two workgroups of a CU take turns in the count phase (a token per physical CU in the scratch block,
+    // taken by thread 0 before it draws the ticket, released after barrier A), and count phases run at s_setprio 3.
+    // Measured on MI355X (scripts/sweep_token.sh, probe build; kernel ms: 8 GiB / 2 GiB 64x31, 1 GiB 16x32, 1 GiB dense):
+    //   no token, no pause            1.848  -      0.2506  0.528   both workgroups often count at once: they share the
+    //   no token, ~2 us pause before  1.739  0.463  0.2504  0.530   SIMDs' issue slots and double the loads in flight — the
+    //     emit (interim default)                                    bare stream, too, is fastest at 8 waves per CU
+    //   token + priority              1.681  0.439  0.2315  0.522   <- default: 63.9 / 61.1 / 58.0 / 25.7 % of 8 TB/s
+    //   token + priority + pause      1.691  0.442  0.2332  0.518
+    //   token, both atomics at once   1.789  0.463  0.2413  0.526   (a workgroup may then wait for the token holding a ticket)
+    // (taken before the speculative scatter went in; with it the default row reads 1.645 / 0.427 / 0.2235 / 0.523 =
+    // 65.3 / 62.9 / 60.0 / 25.6 %, and the ordering of the rows is unchanged.)
+    // The pause knob stays (0 by default); the probe build's environment hooks override all three per launch.
+    a.emit_delay = L.pace_emit_delay >= 0 ? (u32)L.pace_emit_delay : 0u;
+    a.count_prio = L.pace_count_prio >= 0 ? (u32)L.pace_count_prio : 1u;
+    const int token_mode = L.pace_cu_token >= 0 ? L.pace_cu_token : 1;
+    a.cu_token = token_mode > 0
+        ? reinterpret_cast<u32*>(reinterpret_cast<char*>(L.scratch_base) + CSVSIMD_SCRATCH_TOKEN_OFFSET) : nullptr;
+    a.token_mode = (u32)token_mode;
+#ifdef CSVSIMD_DEV_PROBES
+    a.prof = L.scratch_prof;
+#endif
+    a.hash_sh1 = a.hash_sh2 = a.hash_lut_lo = a.hash_lut_hi = a.hash_cls_lo = a.hash_cls_hi = 0;
+}
+
+#ifdef CSVSIMD_DENSE_TU
+// the dense geometry's launcher: reference dialect, emitting launch (launch_stage1 of the other compilation hands over)
+hipError_t launch_stage1_dense(const Stage1Launch& L, hipStream_t stream) {
+    KernelArgs a;
+    fill_kernel_args(L, a);
+    const u32 want = a.num_tiles ? a.num_tiles : 1u;
+    const u32 grid = want < L.max_blocks ? want : L.max_blocks;
+    hipError_t e;
+    if (L.ev_begin && (e = hipEventRecord(L.ev_begin, stream)) != hipSuccess) return e;
+    hipLaunchKernelGGL((stage1_kernel<true, 0, 0, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (L.ev_end && (e = hipEventRecord(L.ev_end, stream)) != hipSuccess) return e;
+    return hipSuccess;
+}
+}  // namespace csvsimd_dense
+#else
 
 // ---------------------------------------------------------------------------------------------
 // utilities: synthetic corpus, checksum, self-test
@@ -1997,51 +2075,14 @@ bool dialect_hash(u32 delim, u32 quote, u32 esc, DialectHash& h) {
 }
 
 hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream) {
-    const uintptr_t addr = (uintptr_t)L.dbuf;
+    // delimiter-dense data, reference dialect, emitting launch: the other geometry (stage1_dense.hip)
+    if (L.dense && L.dtape && !L.escape && L.delimiter == ',' && L.quote == '"' && L.debug_mode == 0)
+        return csvsimd_dense::launch_stage1_dense(L, stream);
     KernelArgs a;
-    a.abase = (const uint8_t*)(addr & ~(uintptr_t)15);
-    a.lo = (u64)(addr & 15);
-    a.hi = a.lo + L.len;
-    a.base_off = L.base_off;
-    a.in_quote_in = L.in_quote_in <= CSVSIMD_ENTER_GUESS ? L.in_quote_in : 1u;  // 0, 1 or CSVSIMD_ENTER_GUESS
-    a.num_tiles = (u32)((a.hi + kTileBytes - 1) / kTileBytes);
-    if (L.len == 0) a.num_tiles = 0;
-    a.tape = (u64*)L.dtape;
-    a.tape_cap = L.dtape ? L.tape_cap : 0;
-    a.desc = L.scratch_desc;
-    a.ctl = reinterpret_cast<Control*>(L.scratch_base);
-    a.result = L.d_result;
-    a.state_ptr = L.d_state;
-    a.chain = L.d_chain;
-    a.delim = L.delimiter;
-    a.quote = L.quote;
-    a.escape = L.escape;
-    a.escape_in = (L.escape && L.escape_in) ? 1u : 0u;
-    // Pacing: the two workgroups of a CU take turns in the count phase (a token per physical CU in the scratch block,
-    // taken by thread 0 before it draws the ticket, released after barrier A), and count phases run at s_setprio 3.
-    // Measured on MI355X (scripts/sweep_token.sh, probe build; kernel ms: 8 GiB / 2 GiB 64x31, 1 GiB 16x32, 1 GiB dense):
-    //   no token, no pause            1.848  -      0.2506  0.528   both workgroups often count at once: they share the
-    //   no token, ~2 us pause before  1.739  0.463  0.2504  0.530   SIMDs' issue slots and double the loads in flight — the
-    //     emit (interim default)                                    bare stream, too, is fastest at 8 waves per CU
-    //   token + priority              1.681  0.439  0.2315  0.522   <- default: 63.9 / 61.1 / 58.0 / 25.7 % of 8 TB/s
-    //   token + priority + pause      1.691  0.442  0.2332  0.518
-    //   token, both atomics at once   1.789  0.463  0.2413  0.526   (a workgroup may then wait for the token holding a ticket)
-    // (taken before the speculative scatter went in; with it the default row reads 1.645 / 0.427 / 0.2235 / 0.523 =
-    // 65.3 / 62.9 / 60.0 / 25.6 %, and the ordering of the rows is unchanged.)
-    // The pause knob stays (0 by default); the probe build's environment hooks override all three per launch.
-    a.emit_delay = L.pace_emit_delay >= 0 ? (u32)L.pace_emit_delay : 0u;
-    a.count_prio = L.pace_count_prio >= 0 ? (u32)L.pace_count_prio : 1u;
-    const int token_mode = L.pace_cu_token >= 0 ? L.pace_cu_token : 1;
-    a.cu_token = token_mode > 0
-        ? reinterpret_cast<u32*>(reinterpret_cast<char*>(L.scratch_base) + CSVSIMD_SCRATCH_TOKEN_OFFSET) : nullptr;
-    a.token_mode = (u32)token_mode;
-#ifdef CSVSIMD_DEV_PROBES
-    a.prof = L.scratch_prof;
-#endif
+    fill_kernel_args(L, a);
     // 0 = the reference dialect (the tuned LUT classification), 1 = other delimiter / quote, 2 = + escape (direct
     // compares), 3 = + escape with the hashed LUT classification (when the special bytes have a collision-free hash)
     int dialect = L.escape ? 2 : (L.delimiter != ',' || L.quote != '"') ? 1 : 0;
-    a.hash_sh1 = a.hash_sh2 = a.hash_lut_lo = a.hash_lut_hi = a.hash_cls_lo = a.hash_cls_hi = 0;
     DialectHash dh;
     if (dialect == 2 && L.allow_hashed_dialect && dialect_hash(L.delimiter, L.quote, L.escape, dh)) {
         dialect = 3;
@@ -2080,8 +2121,6 @@ hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream) {
         hipLaunchKernelGGL((stage1_kernel<true, 0, 1>), dim3(grid), dim3(kThreads), 0, stream, a);
     else if (dialect == 1)
         hipLaunchKernelGGL((stage1_kernel<false, 0, 1>), dim3(grid), dim3(kThreads), 0, stream, a);
-    else if (a.tape && L.dense)
-        hipLaunchKernelGGL((stage1_kernel<true, 0, 0, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);
     else if (a.tape)
         hipLaunchKernelGGL((stage1_kernel<true, 0>), dim3(grid), dim3(kThreads), 0, stream, a);
     else
@@ -2127,7 +2166,7 @@ const char* stage1_kernel_name(bool emit, int dialect, bool dense) {
          "void csvsimd::stage1_kernel<true, 0, 1, false, false>(csvsimd::KernelArgs)",
          "void csvsimd::stage1_kernel<true, 0, 2, false, false>(csvsimd::KernelArgs)",
          "void csvsimd::stage1_kernel<true, 0, 3, false, false>(csvsimd::KernelArgs)"}};
-    if (emit && dense && dialect == 0) return "void csvsimd::stage1_kernel<true, 0, 0, false, true>(csvsimd::KernelArgs)";
+    if (emit && dense && dialect == 0) return "void csvsimd_dense::stage1_kernel<true, 0, 0, false, true>(csvsimd_dense::KernelArgs)";
     return names[emit ? 1 : 0][dialect < 0 || dialect > 3 ? 0 : dialect];
 }
 
@@ -2201,3 +2240,4 @@ int stage1_max_blocks_per_cu() {
 }
 
 }  // namespace csvsimd
+#endif  // CSVSIMD_DENSE_TU

@@ -85,7 +85,14 @@ typedef struct csvsimd_shard_result {
  * (2 MiB; their quote parities and counts composed in order) hold more entries — read with the wrong quote parity, text
  * outside strings looks quoted and nearly every separator disappears — and reports the choice in in_quote_in_used.  `count`, `in_quote_out` and the tape are those of that
  * state; the two hypothesis counts and quote_parity are state independent as always.  A wrong guess is found by the
- * stitch (csvsimd_stitch.reemit) and costs the re-emit launch, exactly like a wrong in_quote_in = 0 speculation. */
+ * stitch (csvsimd_stitch.reemit) and costs the re-emit launch, exactly like a wrong in_quote_in = 0 speculation.
+ * Progress: tile 0 resolves only when the aggregates of the first eight tiles exist, and a workgroup counts at most two
+ * tiles before it waits for that choice — so a GUESS launch needs FOUR of its workgroups resident at once (every other
+ * launch makes progress with any resident prefix).  Alone on a GPU that always holds (the grid is two workgroups per
+ * CU); a launch squeezed in beside several other contexts' persistent grids may wait for them, and if it waits past
+ * the spin bound it ends with result.error set (CSVSIMD_ERR_INTERNAL) instead of hanging — run it again, or give
+ * shards that share a GPU their entering state (csvsimd_stage1_index_multi's shards each own a share of the GPU's
+ * slots in practice: tests/test_gpu_multi.py runs three at once). */
 #define CSVSIMD_ENTER_OUTSIDE 0u
 #define CSVSIMD_ENTER_INSIDE 1u
 #define CSVSIMD_ENTER_GUESS 2u
@@ -285,6 +292,9 @@ int csvsimd_stage1_index_sharded(csvsimd_ctx* ctx, csvsimd_comm* comm, const voi
  * and only a shard that guessed wrong is indexed again.  The bytes and the tapes STAY on the devices, sharded in order
  * (absolute offsets: concatenated behind the sentinel 0 they are reader::read's index), ready for the consumers above.
  * In: ctx (one context per shard; contexts may share a device), dbuf (>= the shard's bytes), dtape / tape_cap.
+ * The call works on the contexts' PRIVATE streams: dbuf and dtape must be idle when it starts (work the caller has
+ * enqueued on them — a fill, a previous consumer — must have completed: synchronise first), and are complete when it
+ * returns.  The calling thread's current HIP device is left as it was found.
  * Out: begin / end (the shard's byte range), result (its final record), stitch (entering state, tape_index_base,
  * totals).  CSVSIMD_ERR_TAPE_CAPACITY if some shard's tape_cap was too small (its result.count says what it needs).
  * Multi-process jobs (one rank per GPU, torch.distributed / RCCL) use csvsimd_stage1_index_sharded instead. */
@@ -436,9 +446,11 @@ int csvsimd_bitmap_select_device(const void* d_bitmap, uint64_t n_rows, uint64_t
  *     its untruncated length -> d_lens[c * n + i] (uint32; d_lens may be NULL),      n = *n_records = chunk->record_cnt.
  * Field text is RecordSource::seek_field's (src/record_source.rs:106-140), quotes included.  fields = HOST array of
  * n_fields <= 1024 field ids; fields == NULL: the first n_fields columns (n_fields 0 = all field_cnt of them).  stride: a
- * multiple of 16, <= 4096; d_cols 16-byte aligned.  Asynchronous on hip_stream (nothing is waited for).  Frequency
- * count and search then run on a column with contiguous 16-byte loads (below), and any columnar engine can take the
- * buffers as they are. */
+ * multiple of 16, <= 4096; d_cols 16-byte aligned.  Asynchronous on hip_stream.  With fields == NULL nothing is waited
+ * for, allocated or copied (capturable into a hipGraph); with a field list the call stages it through one of the
+ * context's two pinned blocks first, so it may wait for the upload of the call before last and may (re)allocate that
+ * block: not capturable, like csvsimd_stage1_index_batch_device_async.  Frequency count and search then run on a column
+ * with contiguous 16-byte loads (below), and any columnar engine can take the buffers as they are. */
 int csvsimd_chunk_to_columns_device(csvsimd_ctx* ctx, const void* dbytes, uint64_t bytes_len, const void* dindex,
                                     uint64_t index_len, uint32_t field_cnt, int new_line, const csvsimd_chunk* chunk,
                                     const uint32_t* fields, uint32_t n_fields, void* d_cols, uint32_t stride, void* d_lens,

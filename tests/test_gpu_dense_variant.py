@@ -1,7 +1,8 @@
 """The second instantiation of the stage-1 kernel — the one a context runs on delimiter-dense data (entries per byte above
 ~0.1: csvsimd_ctx_hint_density, or what the synchronous entry points learn by themselves) — against the oracle and against
 the default instantiation, bit for bit, on EVERY BASELINE configuration and on the edge cases the default one is tested on:
-its emit path (an 8-KiB window per wave, no per-entry capacity tests) is different code, its results must not be.
+its geometry (2 rounds per wave: 64-KiB tiles) and its emit path (an 8-KiB window per wave, no per-entry capacity tests)
+are different code, its results must not be.
 Reference: crush_set_bits is one routine for every density (src/stage1.rs:162-296)."""
 import numpy as np
 import pytest
@@ -10,7 +11,7 @@ from conftest import random_csvish
 
 pytestmark = pytest.mark.gpu
 
-DENSE = "void csvsimd::stage1_kernel<true, 0, 0, false, true>(csvsimd::KernelArgs)"
+DENSE = "void csvsimd_dense::stage1_kernel<true, 0, 0, false, true>(csvsimd_dense::KernelArgs)"
 DEFAULT = "void csvsimd::stage1_kernel<true, 0, 0, false, false>(csvsimd::KernelArgs)"
 
 
@@ -89,7 +90,9 @@ def test_every_size_residue_alignment_and_entering_state(pkg, dctx, ctx, oracle)
     import torch
     rng = np.random.default_rng(404)
     T = pkg.tile_bytes()
-    sizes = list(range(0, 140)) + [4095, 4096, 4097, 32767, 32768, 32769, T - 1, T, T + 1, 2 * T + 63, 3 * T + 4097]
+    D = 64 << 10                                                      # the dense instantiation's tile
+    sizes = (list(range(0, 140)) + [4095, 4096, 4097, 8191, 8192, 8193, 32767, 32768, 32769, D - 1, D, D + 1, 2 * D - 17, 9 * D + 5,
+                                    33 * D + 4097, T - 1, T, T + 1, 2 * T + 63, 3 * T + 4097])
     for i, n in enumerate(sizes):
         p_quote = (None, 0.0, 0.02, 0.3)[i % 4]
         d = random_csvish(rng, n, p_quote)
