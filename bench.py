@@ -146,6 +146,10 @@ class ShardBench:
         self.h_words = self.h_results.numpy()             # the same pinned bytes, cheap to read per step
         self.ctx = pkg.Context(device.index)
         self.ctx.reserve(self.n)
+        # the timed launches are asynchronous: no record reaches the host before the next one is enqueued, so the context
+        # is TOLD what this bench knows from the corpus' shape (it sizes the tape from the same knowledge): entries per
+        # byte.  Above ~0.1 (the 1024 x 4 corpus: 0.2) the library runs its dense instantiation (csvsimd_ctx_hint_density)
+        self.ctx.hint_density(self.n // (width + 1), self.n)
         self.ctx_tail = None    # sharded steps with an overlapped tail: the re-emit launch's own context (see reemit)
         torch.cuda.synchronize(device)
 
@@ -155,6 +159,7 @@ class ShardBench:
         if self.ctx_tail is None:
             self.ctx_tail = self.pkg.Context(self.device.index)
             self.ctx_tail.reserve(self.n)
+            self.ctx_tail.hint_density(self.n // (self.width + 1), self.n)
         return self.ctx_tail
 
     def stream(self):

@@ -26,8 +26,9 @@ def main():
             for row in csv.DictReader(f):
                 kn = row.get("Kernel_Name", "")
                 flat = kn.replace(" ", "")
-                if KERNEL not in flat or not ("<true,0,0,false>" in flat or "<true,0,0>" in flat or "<true,0>" in flat or "<true>" in flat):
-                    continue  # only the reference-dialect, non-probe instantiation
+                if KERNEL not in flat or not any(t in flat for t in ("<true,0,0,false,false>", "<true,0,0,false,true>", "<true,0,0,false>",
+                                                                   "<true,0,0>", "<true,0>", "<true>")):
+                    continue  # only the reference-dialect, non-probe instantiations (round 4: default or dense geometry)
                 name_seen.add(kn)
                 key = (os.path.basename(os.path.dirname(path)), row.get("Dispatch_Id"))
                 per_counter[row["Counter_Name"]][key] += float(row["Counter_Value"])

@@ -134,7 +134,7 @@ def test_escape_hashed_and_compare_classification_agree_with_the_definition(ctx,
     kinds = {2: [], 3: []}
     for d, q, e in cand:
         name = pkg.stage1_kernel_name(True, pkg.Dialect(d, q or None, e))
-        kinds[int(name.split(",")[-2])].append((d, q, e))
+        kinds[int(name.split(",")[2])].append((d, q, e))          # <emit, DBG, DIALECT, BATCH, DENSE>
     assert len(kinds[3]) > len(kinds[2]) > 0, {k: len(v) for k, v in kinds.items()}     # both paths exist in this sample
     for kind in (2, 3):
         for d, q, e in kinds[kind][:6]:
