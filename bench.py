@@ -724,14 +724,18 @@ def consumers_leg(pkg, oracle, device):
     got = {oracle.seek_field(host, hidx, cols, False, f_, field): c for f_, c in ent[: st_s.n_distinct].cpu().tolist()}
     ok = ok and got == dict(want)
     alg_f = nrec * (stride + 4) + int(st.n_distinct) * 16
-    tr_f = consumer_traffic("colfreq")
-    if isinstance(tr_f, dict):   # (a record of the round-3 kernels: two readings of the counters; the conservative one)
-        tr_f = tr_f.get("fetch_x2_plus_write")
+    tr_rec = consumer_traffic("colfreq")
+    # two launches, two access shapes: FETCH_SIZE counts pass 1's narrow requests in full and pass 2's wide ones at half
+    # (profiles/pmc_traffic.json: note); the per-kernel reading is the figure, the uniform readings are its bounds
+    tr_f = tr_rec.get("per_kernel_best_reading", tr_rec.get("fetch_x2_plus_write")) if isinstance(tr_rec, dict) else tr_rec
     res["frequency_count"] = {"ms": round(t * 1e3, 4), "wall_ms_one_call_plus_sync": round(t_wall * 1e3, 3),
                               "distinct": int(st.n_distinct),
                               "algorithmic_bytes": alg_f, "GBps_algorithmic": round(alg_f / t / 1e9, 1),
                               "hbm_traffic_bytes_profiled": tr_f,
                               "traffic_over_algorithmic": round(tr_f / alg_f, 3) if tr_f else None,
+                              "traffic_over_algorithmic_bounds": ({"fetch_as_counted": round(tr_rec["fetch_as_counted_plus_write"] / alg_f, 3),
+                                                                   "fetch_doubled": round(tr_rec["fetch_x2_plus_write"] / alg_f, 3)}
+                                                                  if isinstance(tr_rec, dict) and "fetch_as_counted_plus_write" in tr_rec else None),
                               "scratch_bytes": need,
                               "note": "on the column, two launches, no table in device memory and nothing cleared per call: slabs "
                                       "of 8 192 records aggregate in LDS and leave (first record, count, hash) tuples partitioned "
@@ -1055,16 +1059,28 @@ def main():
     torch.cuda.set_device(device)
     import torch.distributed as dist
     if dist_on:
-        if rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            if "MASTER_ADDR" not in os.environ:   # CSVSIMD_BENCH_FORCE_DIST=1 without a launcher
-                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
-            # the collective's own stream (torch keeps one per communicator) on a high-priority hardware queue as well:
-            # on a queue it shares with the stage-1 launches its wait for the tail's event would hold those up
-            os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
-            dist.init_process_group("nccl", device_id=device)
-        dist.barrier()
+        # RCCL prints a version banner on the process's stdout when its first communicator comes up; this file's stdout is
+        # ONE JSON line, so file descriptor 1 points at stderr until the group's first collective has run
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if rehearsal:
+                dist.init_process_group("gloo")
+            else:
+                if "MASTER_ADDR" not in os.environ:   # CSVSIMD_BENCH_FORCE_DIST=1 without a launcher
+                    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
+                # the collective's own stream (torch keeps one per communicator) on a high-priority hardware queue as well:
+                # on a queue it shares with the stage-1 launches its wait for the tail's event would hold those up
+                os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
+                dist.init_process_group("nccl", device_id=device)
+            dist.barrier()
+            if not rehearsal:
+                torch.cuda.synchronize(device)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     pkg = graft.load_package()
     refuse_probe_environment(pkg)
     from csv_simd_amd import sharded

@@ -612,13 +612,14 @@ __global__ __launch_bounds__(kCfThreads2) void colfreq_reduce_kernel(const ColVi
                     const u32 rec = q[0], cnt = q[1], h32 = q[2];
                     if (rounds > 1 && ((h32 >> 13) % rounds) != r) continue;
                     const u64 key = ((u64)h32 << 32) | ((u64)rec + 1);
-                    const u32 len = c.len ? c.len[rec] : c.stride;
                     u32 s = h32 & (kCfCap2 - 1);
                     bool done = false;
                     for (u32 probes = 0; probes < kCfCap2 && !done; ++probes, s = (s + 1) & (kCfCap2 - 1)) {
                         u64 old = s_key[s];
                         if (old == 0) old = atomicCAS((unsigned long long*)&s_key[s], 0ull, (unsigned long long)key);
-                        if (old == 0 || ((old >> 32) == h32 && rows_equal(c, rec, (u32)old - 1u, len))) {
+                        // (the record's length is read only when hash bits meet: a partition's records lie all over the
+                        // column, and a 4-byte read per tuple from a random place was a sector of traffic per distinct value)
+                        if (old == 0 || ((old >> 32) == h32 && rows_equal(c, rec, (u32)old - 1u, c.len ? c.len[rec] : c.stride))) {
                             atomicAdd(&s_count[s], cnt);
                             atomicMin(&s_first[s], rec);
                             done = true;
