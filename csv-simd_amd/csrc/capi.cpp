@@ -270,7 +270,7 @@ struct csvsimd_ctx {
     // Above kDenseThreshold an emitting launch of the reference dialect runs the instantiation whose emit path is built
     // for many entries per byte (stage1_kernels.hip: DENSE) — same tape, bit for bit; only the instruction mix differs.
     double density = -1.0;
-    static constexpr double kDenseThreshold = 0.1;
+    static constexpr double kDenseThreshold = 0.125;  // profiles/r04_density_threshold.txt: the two instantiations cross between 0.111 and 0.143
     hipStream_t last_stream = nullptr;  // stream of the most recent launch that used the scratch
     bool launched = false;
     uint32_t max_blocks = 0;

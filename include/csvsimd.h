@@ -216,7 +216,7 @@ int csvsimd_stage1_index_dialect(csvsimd_ctx* ctx, const csvsimd_dialect* dialec
 
 /* Entries per input byte of the data this context is about to index (entries structural bytes in `bytes` bytes of
  * text like it; bytes == 0: forget).  The device entry points choose between two instantiations of the stage-1 kernel
- * by it — above ~0.1 (delimiter-dense files: BASELINE config 5 holds 0.2) the one whose emit path spends fewer
+ * by it — above 0.125 (delimiter-dense files: BASELINE config 5 holds 0.2) the one whose emit path spends fewer
  * instructions per entry — and produce the same tape either way (reference: crush_set_bits is one routine for every
  * density, src/stage1.rs:162-296).  The synchronous entry points and csvsimd_stage1_index learn the figure themselves
  * from the records they read; a caller of the _async entry points, which return before any record exists, may say it.

@@ -123,14 +123,12 @@ def one_case(rng, ctx):
         if max(len(t) for t in texts) > stride:
             continue
         want = Counter(texts)
-        slots = 64
-        while slots < 2 * len(want) + 2:
-            slots *= 2
-        scratch = torch.empty(pkg.columnar_frequency_scratch_bytes(slots), dtype=torch.uint8, device="cuda:0")
+        need = pkg.columnar_frequency_scratch_bytes(n)
+        scratch = torch.empty(need, dtype=torch.uint8, device="cuda:0")
         ent = torch.zeros((len(want) + 2, 2), dtype=torch.int64, device="cuda:0")
         first_record = recs[0]
         st = pkg.columnar_frequency_device(ctx, cols[c].data_ptr(), lens[c].data_ptr(), n, stride, first_record,
-                                           scratch.data_ptr(), slots, ent.data_ptr(), ent.shape[0])
+                                           scratch.data_ptr(), need, ent.data_ptr(), ent.shape[0])
         got, first_of = {}, {}
         for i, t in enumerate(texts):
             first_of.setdefault(t, i)
@@ -186,13 +184,11 @@ def rowmajor_consumers(rng, ctx, data, index, tape, dbuf, mis, dindex):
     all_texts = [oracle.seek_field(data, index, F, crlf, r, f) for c in chunks for r in oracle.chunk_record_ids(c, F, crlf)]
     first_rec = next(iter(oracle.chunk_record_ids(chunks[0], F, crlf)))
     want = Counter(all_texts)
-    slots = 64
-    while slots < 2 * len(want) + 2:
-        slots *= 2
-    scratch = torch.empty(pkg.column_frequency_scratch_bytes(slots), dtype=torch.uint8, device="cuda:0")
+    need = pkg.column_frequency_scratch_bytes(len(all_texts), len(chunks), max([len(t) for t in all_texts] + [1]))
+    scratch = torch.empty(need, dtype=torch.uint8, device="cuda:0")
     ent = torch.zeros((len(want) + 2, 4), dtype=torch.int64, device="cuda:0")
     st = pkg.column_frequency_device(ctx, dbytes, dindex.data_ptr(), index.size, F, tape.new_line, chunks, f,
-                                     scratch.data_ptr(), slots, ent.data_ptr(), ent.shape[0])
+                                     scratch.data_ptr(), need, ent.data_ptr(), ent.shape[0])
     got, first_of = {}, {}
     for i, t in enumerate(all_texts):
         first_of.setdefault(t, i)

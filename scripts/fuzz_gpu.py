@@ -215,6 +215,8 @@ def main():
         dbuf = torch.full((n + 256,), 0x2C, dtype=torch.uint8, device="cuda:0")
         dbuf[mis: mis + n] = torch.from_numpy(d)
         dtape = torch.full((cap + 8,), -1, dtype=torch.int64, device="cuda:0")
+        # either instantiation (round 4: the dense one has another geometry and another emit path, the same results)
+        ctx.hint_density(1, 2) if rng.random() < 0.5 else ctx.hint_density(0, 0)
         r = ctx.stage1_index_device(dbuf.data_ptr() + mis, n, base, inq, dtape.data_ptr(), cap, allow_overflow=True)
         torch.cuda.synchronize()
         k = min(r.count, cap)

@@ -45,6 +45,8 @@ def main():
             t_say = time.time() + 60
         for ci, (name, n, dbuf, dtape, cap, dialect, mis) in enumerate(cases):
             inq = launches % 3   # 0, 1, and 2 = CSVSIMD_ENTER_GUESS (the kernel's own choice must be the same every time too)
+            # both instantiations in turn (round 4): the dense one must give the default one's record and checksum
+            ctx.hint_density(1, 2) if (launches // 3) % 2 else ctx.hint_density(0, 0)
             if dialect is None:
                 ctx.stage1_index_device_async(dbuf.data_ptr() + mis, n, 123, inq, dtape.data_ptr(), cap, dres.data_ptr())
             else:
