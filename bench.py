@@ -793,8 +793,8 @@ def consumers_leg(pkg, oracle, device):
                                            "search_contains_ms": round(t_s * 1e3, 3),
                                            "note": "one column per call straight from the row-major file (a 32-byte field of a "
                                                    "528-byte row costs 1-2 sectors + a slice of tape per record); the frequency "
-                                                   "count = spans + gather + the columnar count above (one implementation), two "
-                                                   "synchronisations"}
+                                                   "count = the column gathered straight from the tape + the columnar count above (one "
+                                                   "implementation), one synchronisation"}
     res["verified"] = bool(ok)
     ctx.close()
     return res

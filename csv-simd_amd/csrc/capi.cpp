@@ -1561,23 +1561,21 @@ int csvsimd_gather_fields_device(const void* dbytes, uint64_t bytes_len, const v
     return CSVSIMD_OK;
 }
 
-// scratch of csvsimd_column_frequency_device: [64 B: longest field | chunk map | begin[n] | end[n] | column n x stride |
-// lengths n x 4 | the count's own scratch | its status 64 B]
+// scratch of csvsimd_column_frequency_device: [64 B: longest field | chunk map | lengths n x 4 | the count's own scratch | its
+// status 64 B | column n x stride]
 namespace {
 struct FreqLayout {
-    uint64_t off_map, off_begin, off_end, off_col, off_len, off_cf, off_status, total;
+    uint64_t off_map, off_len, off_cf, off_status, off_col, total;
 };
 FreqLayout freq_layout(uint64_t n, uint32_t n_chunks, uint64_t stride) {
     auto up = [](uint64_t v) { return (v + 255) & ~(uint64_t)255; };
     FreqLayout L;
     L.off_map = 64;
-    L.off_begin = up(L.off_map + (uint64_t)n_chunks * 24);
-    L.off_end = up(L.off_begin + n * 8);
-    L.off_col = up(L.off_end + n * 8);
-    L.off_len = up(L.off_col + n * stride);
+    L.off_len = up(L.off_map + (uint64_t)n_chunks * sizeof(csvsimd::FreqRowMap));
     L.off_cf = up(L.off_len + n * 4);
     L.off_status = up(L.off_cf + csvsimd::colfreq_scratch_bytes(n));
-    L.total = L.off_status + 64;
+    L.off_col = up(L.off_status + 64);  // the only part whose size depends on the stride: last
+    L.total = L.off_col + n * stride;
     return L;
 }
 uint64_t stride_for(uint64_t max_field_bytes) { return std::max<uint64_t>(16, (max_field_bytes + 15) & ~(uint64_t)15); }
@@ -1614,36 +1612,32 @@ int csvsimd_column_frequency_device(csvsimd_ctx* ctx, const void* dbytes, const 
     *status = csvsimd_freq_status{n, 0, 0, 0};
     if (n == 0) return CSVSIMD_OK;
     hipStream_t s = (hipStream_t)hip_stream;
-    // the part of the layout that does not depend on the stride: spans, then the longest field decides the rest
-    FreqLayout L = freq_layout(n, n_chunks, 16);
-    if (scratch_bytes < L.total) return CSVSIMD_ERR_TAPE_CAPACITY;  // (status->max_field_bytes 0: not even the spans fit)
+    // The column is gathered at the LARGEST stride the scratch holds (the caller sized it for the longest field it expects,
+    // csvsimd_column_frequency_scratch_bytes), without asking the device first how long the longest field really is: the
+    // gather reports that on the side, and the count reports records that did not fit.  One synchronisation, at the end
+    // (rounds 1-3 and the first version of this path waited for the longest field before they gathered).
+    const FreqLayout L0 = freq_layout(n, n_chunks, 0);
+    if (scratch_bytes < L0.total + n * 16) return CSVSIMD_ERR_TAPE_CAPACITY;  // not even 16-byte rows (status->max_field_bytes stays 0)
+    const uint64_t stride = std::min<uint64_t>(((scratch_bytes - L0.total) / n) & ~(uint64_t)15, 0xfffffff0ull);
+    const FreqLayout L = freq_layout(n, n_chunks, stride);
     char* const base = (char*)d_scratch;
     HIP_TRY(hipMemsetAsync(base, 0, 64, s));
     rc = ctx_upload(ctx, base + L.off_map, map.data(), map.size() * sizeof(RowMap), s);
     if (rc != CSVSIMD_OK) return rc;
     for (uint32_t i = 0; i < n_chunks; ++i)
-        HIP_TRY(csvsimd::launch_chunk_spans(dindex, chunks[i].start, row_size, field_idx, 1, rows[i],
-                                            base + L.off_begin + map[i].row0 * 8, base + L.off_end + map[i].row0 * 8, s, base));
-    // longest field; the tape's last entry (the file is at least that long + 1): two words into the context's pinned block
-    volatile uint64_t* const stats = (volatile uint64_t*)ctx->h_small;
-    HIP_TRY(hipMemcpyAsync((void*)&stats[0], base, 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync((void*)&stats[1], (const char*)dindex + (index_len - 1) * 8, 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    status->max_field_bytes = stats[0];
-    const uint64_t longest = stats[0], last_entry = stats[1];
-    const uint64_t stride = stride_for(longest);
-    if (stride > 0xfffffff0ull) return CSVSIMD_ERR_INVALID_ARG;
-    L = freq_layout(n, n_chunks, stride);
-    if (scratch_bytes < L.total) return CSVSIMD_ERR_TAPE_CAPACITY;  // csvsimd_column_frequency_scratch_bytes(n, n_chunks, status->max_field_bytes)
-    HIP_TRY(csvsimd::launch_gather_fields(dbytes, last_entry + 1, base + L.off_begin, base + L.off_end, n, base + L.off_col,
-                                          (uint32_t)stride, base + L.off_len, s));
+        HIP_TRY(csvsimd::launch_gather_column(dbytes, dindex, index_len, chunks[i].start, row_size, field_idx, rows[i],
+                                              base + L.off_col + map[i].row0 * stride, (uint32_t)stride,
+                                              base + L.off_len + map[i].row0 * 4, base, s));
     // the count's second pass writes the entries in their final form: record id through the chunk map, text span from the tape
     const csvsimd::FreqWideOut wide = {(const uint64_t*)dindex, row_size, field_idx, n_chunks, (const RowMap*)(base + L.off_map)};
     HIP_TRY(csvsimd::launch_colfreq(base + L.off_col, base + L.off_len, n, (uint32_t)stride, 0, base + L.off_cf, d_entries,
                                     entries_cap, base + L.off_status, ctx->n_cus, s, &wide));
     HIP_TRY(hipMemcpyAsync((char*)ctx->h_small + 64, base + L.off_status, sizeof(csvsimd_colfreq_status), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(ctx->h_small, base, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     const csvsimd_colfreq_status cs = *reinterpret_cast<const csvsimd_colfreq_status*>((const char*)ctx->h_small + 64);
+    status->max_field_bytes = *reinterpret_cast<const volatile uint64_t*>(ctx->h_small);
+    if (cs.truncated) return CSVSIMD_ERR_TAPE_CAPACITY;  // fields longer than the scratch allows: size it from status->max_field_bytes
     status->n_distinct = cs.n_distinct;
     status->overflow = cs.overflow;
     if (cs.overflow) return CSVSIMD_ERR_TAPE_CAPACITY;

@@ -120,6 +120,58 @@ __global__ void gather_fields_kernel(const uint8_t* __restrict__ bytes, u64 byte
 }
 
 // ---------------------------------------------------------------------------------------------
+// spans + gather in one kernel, straight from the tape (csvsimd_column_frequency_device): field `field` of rows
+// [0, n_rows) of a chunk -> rows of dst, lengths -> len, the longest length seen -> *longest.  The file's end is taken
+// from the tape itself (its last entry is the last structural byte: the buffer is at least that long + 1).
+// ---------------------------------------------------------------------------------------------
+__global__ void gather_column_kernel(const uint8_t* __restrict__ bytes, const u64* __restrict__ index, u64 index_len, u64 first_key,
+                                     u64 jump, u32 field, u64 n_rows, uint8_t* __restrict__ dst, u32 stride, u32* __restrict__ len,
+                                     u64* __restrict__ longest, u32 gshift) {
+    const u32 lanes = 1u << gshift;
+    const u32 sub = threadIdx.x & (lanes - 1u);
+    const u64 bytes_len = index[index_len - 1] + 1;
+    u64 m = 0;
+    for (u64 i = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> gshift; i < n_rows;
+         i += ((u64)gridDim.x * blockDim.x) >> gshift) {
+        const u64 k0 = first_key + i * jump + field;
+        const u64 b = index[k0] + 1, e = index[k0 + 1];
+        const u64 n = e > b ? e - b : 0;
+        m = n > m ? n : m;
+        if (sub == 0) len[i] = (u32)(n > 0xffffffffull ? 0xffffffffull : n);
+        uint8_t* const row = dst + i * stride;
+        for (u32 k = sub * 16u; k < stride; k += lanes * 16u) {
+            u32x4 v = {0, 0, 0, 0};
+            if (k < n) {
+                if (b + k + 16 <= bytes_len) {
+                    v = *reinterpret_cast<const u32x4u*>(bytes + b + k);
+                } else {  // the last 15 bytes of the buffer: never read past it
+                    uint8_t t[16];
+                    for (u32 j = 0; j < 16; ++j) t[j] = b + k + j < bytes_len ? bytes[b + k + j] : (uint8_t)0;
+                    v = *reinterpret_cast<const u32x4*>(t);
+                }
+                if (n - k < 16) {  // zero the bytes past the field's end
+                    const u32 keep = (u32)(n - k);
+                    const u32 full = keep >> 2, part = keep & 3u;
+                    const u32 mk = part ? (0xffffffffu >> (32u - 8u * part)) : 0u;
+                    v.x = full > 0 ? v.x : (full == 0 ? v.x & mk : 0u);
+                    v.y = full > 1 ? v.y : (full == 1 ? v.y & mk : 0u);
+                    v.z = full > 2 ? v.z : (full == 2 ? v.z & mk : 0u);
+                    v.w = full > 3 ? v.w : (full == 3 ? v.w & mk : 0u);
+                }
+            }
+            *reinterpret_cast<u32x4*>(row + k) = v;
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        const u64 o = ((u64)(u32)__shfl_xor((int)(u32)(m >> 32), d) << 32) | (u32)__shfl_xor((int)(u32)m, d);
+        m = o > m ? o : m;
+    }
+    // (one atomic per wave that has something new to say: see chunk_spans_kernel)
+    if ((threadIdx.x & 63u) == 0 && m > __hip_atomic_load((const unsigned long long*)longest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax((unsigned long long*)longest, (unsigned long long)m);
+}
+
+// ---------------------------------------------------------------------------------------------
 // frequency count of a column of the ROW-MAJOR file (csvsimd_column_frequency_device).  Rounds 1-3 kept a second
 // counting algorithm here (64-bit hashes in a 32-byte-slot device table + a verification pass over every record:
 // 11-22 x the column's bytes in traffic).  Now the column is gathered once into fixed-stride rows (the two kernels
@@ -316,6 +368,17 @@ static Column make_column(const void* dbytes, const void* dindex, u64 first_key,
     c.first_row = first_key / jump;
     c.field = field;
     return c;
+}
+
+hipError_t launch_gather_column(const void* dbytes, const void* dindex, u64 index_len, u64 first_key, u64 jump, u32 field, u64 n_rows,
+                                void* d_dst, u32 stride, void* d_len, void* d_longest, hipStream_t stream) {
+    if (n_rows == 0) return hipSuccess;
+    u32 gshift = 0;  // lanes per record: one per 16-byte piece of the row, a power of two <= 16
+    while (gshift < 4 && (1u << gshift) < (stride + 15) / 16) ++gshift;
+    hipLaunchKernelGGL(gather_column_kernel, dim3(grid_for(n_rows << gshift, 256, 16384)), dim3(256), 0, stream,
+                       (const uint8_t*)dbytes, (const u64*)dindex, index_len, first_key, jump, field, n_rows, (uint8_t*)d_dst, stride,
+                       (u32*)d_len, (u64*)d_longest, gshift);
+    return hipGetLastError();
 }
 
 hipError_t launch_search(const void* dbytes, u64 bytes_len, const void* dindex, u64 first_key, u64 jump, u64 n_rows, u32 field,

@@ -115,6 +115,10 @@ hipError_t launch_chunk_spans(const void* dindex, uint64_t first_key, uint64_t j
                               uint64_t n_rows, void* d_begin, void* d_end, hipStream_t stream, void* d_longest = nullptr);
 hipError_t launch_gather_fields(const void* dbytes, uint64_t bytes_len, const void* d_begin, const void* d_end,
                                 uint64_t n_records, void* d_dst, uint32_t stride, void* d_len, hipStream_t stream);
+// field `field` of a run of whole rows -> fixed-stride rows + lengths, straight from the tape; *d_longest = max(it, longest field)
+hipError_t launch_gather_column(const void* dbytes, const void* dindex, uint64_t index_len, uint64_t first_key, uint64_t jump,
+                                uint32_t field, uint64_t n_rows, void* d_dst, uint32_t stride, void* d_len, void* d_longest,
+                                hipStream_t stream);
 hipError_t launch_search(const void* dbytes, uint64_t bytes_len, const void* dindex, uint64_t first_key, uint64_t jump, uint64_t n_rows,
                          uint32_t field, const void* d_needle, uint32_t needle_len, int mode, void* d_bitmap, void* d_count,
                          hipStream_t stream);

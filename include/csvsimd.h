@@ -397,13 +397,15 @@ int csvsimd_gather_fields_device(const void* dbytes, uint64_t bytes_len, const v
  * csvsimd_gather_fields_device at the stride of its longest field — and counts it with that ONE implementation).
  * Definition checked against: collections.Counter over seek_field.
  *   d_scratch   : scratch_bytes >= csvsimd_column_frequency_scratch_bytes(n_records, n_chunks, max_field_bytes), 256-byte
- *                 aligned; n_records = the chunks' records together.  The longest field is only known once the call
- *                 has looked: if the scratch is too small for it the call returns CSVSIMD_ERR_TAPE_CAPACITY with
- *                 status->max_field_bytes set — size the scratch from that and call again
+ *                 aligned; n_records = the chunks' records together.  The column is gathered at the largest stride the
+ *                 scratch holds — size it for the longest field you expect, not generously: a stride of 256 bytes for
+ *                 8-byte values moves 32 x the bytes.  If some field is longer than that stride the call returns
+ *                 CSVSIMD_ERR_TAPE_CAPACITY with status->max_field_bytes set (the longest field of the column, always
+ *                 reported) — size the scratch from that and call again
  *   d_entries   : entries_cap csvsimd_freq_entry, unordered (sort by first_record for a deterministic order);
  *                 status->n_distinct of them are valid (CSVSIMD_ERR_TAPE_CAPACITY if more exist than fit)
- * Synchronous on hip_stream (it waits twice: for the longest field, and at the end).  The slow path next to the
- * columnar one: it touches one or two 64-byte sectors of the file plus a slice of tape per record. */
+ * Synchronous on hip_stream (one wait, at the end).  The slow path next to the columnar one: it touches one or two
+ * 64-byte sectors of the file plus a slice of tape per record. */
 typedef struct csvsimd_freq_entry {
     uint64_t first_record; /* first record (seek_field numbering) that holds this value */
     uint64_t begin, end;   /* bytes[begin..end) = the value's text (of that record)      */

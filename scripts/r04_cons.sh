@@ -1,11 +1,9 @@
 #!/bin/bash
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd $REPO
-mkdir -p gpurun_out/r04_full
-timeout -k 10 400 bash scripts/collect_profiles_r04_consumers.sh > gpurun_out/r04_full/prof_r04_consumers.log 2>&1; echo "consumers rc=$?"
-python3 - <<'PY'
-import json,os
-d=json.load(open(os.environ.get("GRAFT_REPO_ROOT","/root/repo")+"/gpurun_out/prof_r04_consumers/pmc_consumers.json"))
-for k,v in d.items():
-    if "colfreq" in k: print(k, {a:round(b/1e6,1) for a,b in v.items() if "bytes" in a})
-PY
+timeout -k 10 300 python -m pytest tests/test_gpu_consumers.py tests/test_gpu_columnar.py -x -q -m gpu 2>&1 | tail -3
+python3 bench.py --only-consumers 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])['consumers']
+print(d['per_column_on_row_major_file']); print(d['frequency_count']['ms'], d['frequency_count']['few_distinct_values'], d['frequency_count']['traffic_over_algorithmic'], d['frequency_count']['traffic_over_algorithmic_bounds'], d['verified'])"
+timeout -k 10 120 python3 scripts/fuzz_columnar.py 40 2>/dev/null | tail -c 300
