@@ -166,7 +166,7 @@ private:
     }
     // unit = source bytes per item of n
     void run_sliced(Job whole, size_t unit) {
-        constexpr size_t kMinSlice = 2u << 20;  // source bytes
+        constexpr size_t kMinSlice = 2u << 20;  // source bytes (512 KiB slices — eight threads on a 4-MiB chunk — measured: no gain)
         const size_t bytes = whole.n * unit;
         const size_t parts = std::min<size_t>(threads_.size() + 1, std::max<size_t>(1, bytes / kMinSlice));
         if (parts <= 1) {
@@ -737,6 +737,9 @@ static std::vector<uint64_t> ingest_chunk_plan(uint64_t len, uint64_t uniform_ov
     cuts.push_back(0);
     uint64_t uniform = uniform_override;
     if (!uniform && len < 4 * kMax) {
+        // a mid-size file: ~4 chunks of >= 4 MiB.  (Measured in round 4 with ~8 chunks of >= 1 MiB instead: no gain at any
+        // size from 2 to 128 MiB — below ~16 MiB a call is a chain of four or five steps of 40-80 us each whatever the cut,
+        // and a chunk under 2 MiB is staged by one thread at ~12 GB/s.)
         const uint64_t target = ((len / 4 + kMiB - 1) >> 20) << 20;
         uniform = std::min<uint64_t>(kMax, std::max<uint64_t>(kMin, target));
     }
@@ -1138,22 +1141,27 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
             return rc;
         }
     } else {
-        // one or two chunks: the same steps in turn on the caller's thread (no thread is worth starting for a file that
-        // is indexed in the time it takes to start one)
+        // a file of a few MiB: the same steps in turn on the caller's thread (no thread is worth starting for a file that is
+        // indexed in the time it takes to start two) — still a pipeline: chunk i's H2D copy and kernels run while chunk
+        // i + 1 is staged, records are read kLag chunks behind
+        if (!tape) {
+            std::lock_guard<std::mutex> g(sh.m);
+            sh.expanded = nchunks;
+        }
         for (uint64_t i = 0; i < nchunks; ++i) {
             if (!stage_one(i)) return sh.err;
             rc = submit(i);
             if (rc != CSVSIMD_OK) return rc;
-            if (i >= 1) {
-                rc = finish(i - 1);
+            if (i >= kLag) {
+                rc = finish(i - kLag);
                 if (rc != CSVSIMD_OK) return rc;
-                if (tape && !expand_one(i - 1)) return sh.err;
+                if (tape && !expand_one(i - kLag)) return sh.err;
             }
         }
-        if (nchunks) {
-            rc = finish(nchunks - 1);
+        for (uint64_t j = nchunks > kLag ? nchunks - kLag : 0; j < nchunks; ++j) {
+            rc = finish(j);
             if (rc != CSVSIMD_OK) return rc;
-            if (tape && !expand_one(nchunks - 1)) return sh.err;
+            if (tape && !expand_one(j)) return sh.err;
         }
     }
 #undef CSVSIMD_TIMED

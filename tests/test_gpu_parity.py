@@ -545,10 +545,13 @@ def test_host_ingest_three_threads_many_slot_reuses(pkg, oracle, monkeypatch):
         rc, cnt, _ = c.read_into(d, small)
         assert rc == pkg.ERR_TAPE_CAPACITY and cnt == want.size and np.array_equal(small, want[:12345])
         monkeypatch.delenv("CSVSIMD_INGEST_CHUNK_MIB")
-        two = d[: 2 * chunk + 17]
+        two = d[: 2 * chunk + 17]                                        # two chunks: pipelined on the caller's thread
         assert pkg.ingest_chunk_plan(two.size) == [0, chunk, two.size]
         assert np.array_equal(c.read(two), oracle.scalar_read(two))
         assert pkg.ingest_last_phases()["host_threads"] == 1
+        mid = d[7 * chunk - 5: 12 * chunk + 99]                          # 20 MiB: four chunks, two of them dense, three threads
+        assert np.array_equal(c.read(mid), oracle.scalar_read(mid))
+        assert pkg.ingest_last_phases()["host_threads"] == 3
         tiny = d[9 * chunk - 150: 9 * chunk + 150]
         assert np.array_equal(c.read(tiny), oracle.scalar_read(tiny))
         assert np.array_equal(c.read(d), want)                         # and the large file again after the small ones

@@ -108,7 +108,7 @@ def test_ingest_chunk_plan_has_no_degenerate_chunk(pkg):
     # still paid two launches and an event wait)
     MiB = 1 << 20
     rng = np.random.default_rng(4)
-    lens = [0, 1, 300, 4 * MiB, 4 * MiB + 1, 12 * MiB + 1, 16 * MiB + 1, 64 * MiB + 1, 128 * MiB - 1, 128 * MiB, 128 * MiB + 1,
+    lens = [0, 1, 300, MiB, MiB + 1, 2 * MiB + 77, 4 * MiB, 4 * MiB + 1, 12 * MiB + 1, 16 * MiB + 1, 64 * MiB + 1, 128 * MiB - 1, 128 * MiB, 128 * MiB + 1,
             148 * MiB + 1, 152 * MiB + 1, 136 * MiB + 1, 2048 * MiB, 2048 * MiB + 777]
     lens += [int(x) for x in rng.integers(1, 600 * MiB, 300)]
     for n in lens:
