@@ -986,6 +986,64 @@ __device__ __forceinline__ void flush_window_dense(u64* const tape, const u64 ta
     if (((n - head) & 1u) && lane == 0) __builtin_nontemporal_store(span_off + comp[n - 1], tape + run + n - 1);
 }
 
+// The DENSE instantiation's speculative path, workgroup wide: its tile is 64 KiB, so an offset relative to the TILE fits the
+// window's u16, and the eight waves' 8-KiB windows are one contiguous 64-KiB block: every wave scatters its span's entries
+// at their place in the TILE's order (its entries start behind those of the waves before it: known from the aggregates,
+// before the look-back), and after barrier B all 512 threads write the tile's run of the tape front to back — one stream
+// of stores per workgroup instead of eight (a bare stream of this write-heavy mix gains 4-7 % from that order alone,
+// profiles/r03_ubench_dense_write_patterns.txt).
+static constexpr u32 kWgCap = (u32)kWaves * (u32)kDenseCap;  // entries the workgroup's window holds
+__device__ __forceinline__ void scatter_span_tile(const RoundMasks (&m)[kRounds], u32 lane, u32 wstate, unsigned short* win,
+                                                  u32 first, u32 span_rel) {
+    const u64 flipall = wstate ? ~0ull : 0ull;
+    u32 fill = first;  // the tile-order index of this wave's first entry
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+        const u64 R = m[r].st & ~(m[r].s ^ flipall);
+        const u32 c = (u32)__builtin_popcountll(R);
+        const u32 incl = wave_incl_scan_add(c);
+        const u32 n_r = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        u32 roff = span_rel + (u32)r * kRoundBytes;
+        asm volatile("" : "+s"(roff));
+        scatter_bits_nocheck(win, R, fill + incl - c, roff + lane * 64u);
+        fill += n_r;
+        asm volatile("" : "+s"(fill));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// win[0, n) (tile-relative u16 offsets, tile order) -> tape[run, run + n) by ALL threads of the workgroup (t = thread id)
+__device__ __forceinline__ void flush_tile_dense(u64* const tape, const u64 tape_cap, const unsigned short* win, u32 n, u64 run,
+                                                 u64 tile_off, u32 t) {
+    if (n == 0) return;
+    if (run + n > tape_cap) {  // workgroup-uniform: the caller's tape is too small (capacity protocol)
+        for (u32 k = t; k < n; k += (u32)kThreads)
+            if (run + k < tape_cap) __builtin_nontemporal_store(tile_off + win[k], tape + run + k);
+        return;
+    }
+    u32 head = (0u - (u32)(((uintptr_t)tape >> 3) + run)) & (u32)(kStoreAlignEntries - 1);  // see flush_window
+    head = head < n ? head : n;
+    if (t < head) __builtin_nontemporal_store(tile_off + win[t], tape + run + t);
+    const u32 npairs = (n - head) >> 1;
+    const u32 base_lo = (u32)tile_off, base_hi = (u32)(tile_off >> 32);
+    u64* const out = tape + run + head;
+    if (base_lo <= 0xffff0000u && (head & 1u) == 0u) {  // 32-bit adds, pairs in aligned dwords (workgroup-uniform)
+        const u32* const pairs = reinterpret_cast<const u32*>(win + head);
+        for (u32 i = t; i < npairs; i += (u32)kThreads) {
+            const u32 pr = pairs[i];
+            const u32x4 x = {base_lo + (pr & 0xffffu), base_hi, base_lo + (pr >> 16), base_hi};
+            __builtin_nontemporal_store(x, reinterpret_cast<u32x4*>(out + 2 * i));
+        }
+    } else {
+        for (u32 i = t; i < npairs; i += (u32)kThreads) {
+            const u64 e0 = tile_off + win[head + 2 * i], e1 = tile_off + win[head + 2 * i + 1];
+            const u32x4 x = {(u32)e0, (u32)(e0 >> 32), (u32)e1, (u32)(e1 >> 32)};
+            __builtin_nontemporal_store(x, reinterpret_cast<u32x4*>(out + 2 * i));
+        }
+    }
+    if (((n - head) & 1u) && t == 0) __builtin_nontemporal_store(tile_off + win[n - 1], tape + run + n - 1);
+}
+
 // emit_span for the DENSE instantiation: comp = the wave's 8-KiB window
 __device__ __forceinline__ void emit_span_dense(u64* const tape, const u64 tape_cap, const RoundMasks (&m)[kRounds], u32 lane,
                                                 const u64 span_off, u32 wstate, u64 run, unsigned short* comp) {
@@ -1317,8 +1375,11 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
     __shared__ uint4 s_stage_bb[DENSE ? 1 : kWaves][DENSE ? 1 : kImg];
     static_assert(kCompCap * 2 <= kRoundBytes, "compaction window must fit the stage image");
     static_assert(!DENSE || (EMIT && DBG == 0 && DIALECT == 0 && !BATCH), "the dense emit path exists for the reference dialect's emitting launch");
+    // DENSE: wave 0's look-back window has a place of its own (2 KiB): the waves' images are the WORKGROUP's emit window there
+    __shared__ uint4 s_lb[DENSE ? 128 : 1];
 #define s_stage_of(wave) (s_stage_a[wave])
 #define s_stage_b_of(wave) (DENSE ? s_stage_a[wave] + kImg : s_stage_bb[DENSE ? 0 : (wave)])
+#define s_lookback_win() (DENSE ? s_lb : s_stage_b_of(0))
     // escape dialects only (the array does not exist in the other instantiations): the masks of the held tile's LAST
     // round are parked here across the count phase of the next tile — those variants are four VGPRs short there (a third
     // mask and the run-parity chain are in flight), and what hipcc spills otherwise is exactly this pair, to scratch
@@ -1561,19 +1622,26 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
             if (uniform_again<(DIALECT >= 2 || BATCH)>(inq_in) == kEnterGuess && have_cur && tile < kGuessTiles && !(DBG & 4))
                 guess_vote(args.desc, args.ctl, args.num_tiles, epoch, lane, err);
             // into wave 0's second stage image: idle until the next count phase
-            if (have_held && !(DBG & 4)) lookback_issue(args.desc, held_tile, lane, s_stage_b_of(0));
+            if (have_held && !(DBG & 4)) lookback_issue(args.desc, held_tile, lane, s_lookback_win());
         }
         bool spec_done = false;
         const u32 spec_pin = held_agg.b > held_agg.a ? 1u : 0u;      // the guess: the hypothesis with more entries
         const u32 spec_state = spec_pin ^ held_before.p;             // this wave's entering state under it
         const u32 spec_n = spec_state ? held_wb : held_wa;           // ... and its entry count
-        if (EMIT && have_held && !(DBG & 16) && spec_n <= (u32)kCompCap) {
+        const u32 spec_tile_n = spec_pin ? held_agg.b : held_agg.a;  // the whole tile's entries under the guess
+        if (DENSE) {
+            if (EMIT && have_held && spec_tile_n <= kWgCap) {
+                scatter_span_tile(held, lane, spec_state, reinterpret_cast<unsigned short*>(s_stage_a[0]),
+                                  spec_pin ? held_before.b : held_before.a, w * (u32)kSpanBytes);
+                spec_done = true;
+            }
+        } else if (EMIT && have_held && !(DBG & 16) && spec_n <= (u32)kCompCap) {
             if (kPark) {
                 const uint4 pk = s_park[w][lane];
                 held[kRounds - 1].st = ((u64)pk.y << 32) | pk.x;
                 held[kRounds - 1].s = ((u64)pk.w << 32) | pk.z;
             }
-            scatter_span_spec<DENSE>(held, lane, spec_state, reinterpret_cast<unsigned short*>(s_stage_of(w)));
+            scatter_span_spec(held, lane, spec_state, reinterpret_cast<unsigned short*>(s_stage_of(w)));
             spec_done = true;
         }
         if (have_held) {
@@ -1597,11 +1665,11 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef CSVSIMD_DEV_PROBES
                 if (DBG & 32) trace_landed = __builtin_amdgcn_s_memrealtime();
-                lookback_fetch(s_stage_b_of(0), held_tile, lane, pre);
+                lookback_fetch(s_lookback_win(), held_tile, lane, pre);
                 resolve<true>(args.desc, held_tile, epoch, held_agg, inq_eff, lane, pin, base, err, pre,
                               (DBG & 32) ? &trace_ws : nullptr, held_first);
 #else
-                lookback_fetch(s_stage_b_of(0), held_tile, lane, pre);
+                lookback_fetch(s_lookback_win(), held_tile, lane, pre);
                 resolve<true>(args.desc, held_tile, epoch, held_agg, inq_eff, lane, pin, base, err, pre, nullptr, held_first);
 #endif
             }
@@ -1651,16 +1719,23 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
             }
             const u64 span0 = (u64)(held_tile - e_first) * kTileBytes + (u64)w * kSpanBytes;
             CSVSIMD_TRACEX(7, held_tile, 0, __builtin_amdgcn_s_memrealtime())
-            if (spec_done && pin == (held_agg.b > held_agg.a ? 1u : 0u)) {
+            if (DENSE && spec_done && pin == (held_agg.b > held_agg.a ? 1u : 0u)) {
+                // the guess was right: the workgroup's window holds the TILE's entries in order (barrier B made every wave's
+                // scatter visible); all threads write them out front to back
+                const u64 sb = s_base;
+                const u64 base_u = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(sb >> 32)) << 32) |
+                                   (u32)__builtin_amdgcn_readfirstlane((int)(u32)sb);
+                flush_tile_dense(e_tape, e_cap, reinterpret_cast<const unsigned short*>(s_stage_a[0]), spec_tile_n, base_u,
+                                 e_off + (u64)(held_tile - e_first) * kTileBytes, w * 64u + lane);
+            } else if (spec_done && pin == (held_agg.b > held_agg.a ? 1u : 0u)) {
                 // the guess was right: the window already holds the span's entries, only the stores are left
                 wave_lds_fence();
                 const u64 run_u = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(run >> 32)) << 32) |
                                   (u32)__builtin_amdgcn_readfirstlane((int)(u32)run);
-                if (DENSE) flush_window_dense(e_tape, e_cap, reinterpret_cast<unsigned short*>(s_stage_of(w)), spec_n, run_u, e_off + span0, lane);
-                else flush_window(e_tape, e_cap, reinterpret_cast<unsigned short*>(s_stage_of(w)), spec_n, run_u, e_off + span0, lane);
+                flush_window(e_tape, e_cap, reinterpret_cast<unsigned short*>(s_stage_of(w)), spec_n, run_u, e_off + span0, lane);
                 wave_lds_fence();
             } else if (DENSE) {
-                // (wave 0's look-back window, which shares the 8 KiB, was consumed before barrier B)
+                // (the guess was wrong, or the tile holds more entries than the workgroup's window: wave by wave)
                 emit_span_dense(e_tape, e_cap, held, lane, e_off + span0, wstate, run, reinterpret_cast<unsigned short*>(s_stage_of(w)));
             } else {
                 if (kPark) {  // (the speculative scatter may not have run: the pair is fetched again)
@@ -1724,6 +1799,7 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
 
 #undef s_stage_of
 #undef s_stage_b_of
+#undef s_lookback_win
     // ---- this workgroup is done; the last one to get here completes the launch --------------------
     if (w != 0) return;
     finish_launch<DIALECT, (DBG & 4) != 0, BATCH>(args, epoch_v & kEpochMask, inq_in,
