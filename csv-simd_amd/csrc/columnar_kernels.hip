@@ -310,7 +310,10 @@ static constexpr u32 kCfMaxParts = 4096;
 static constexpr u32 kCfCap2 = 8192;         // pass-2 LDS table slots.  (4 096 slots and twice the partitions, two workgroups per
                                              // CU instead of one: 20-25 % slower on every cardinality measured)
 static constexpr u32 kCfRound2 = 6144;       // tuples a pass-2 round may be asked to hold (distinct values <= tuples)
-static constexpr u32 kCfThreads2 = 1024;
+#ifndef CSVSIMD_CF_THREADS2
+#define CSVSIMD_CF_THREADS2 1024
+#endif
+static constexpr u32 kCfThreads2 = CSVSIMD_CF_THREADS2;
 static constexpr u32 kCfTupleWords = 3;      // {first record, count, low 32 hash bits}
 
 struct ColFreqGeom {
@@ -538,7 +541,7 @@ __global__ __launch_bounds__(kCfThreads1) void colfreq_partition_kernel(const Co
     }
 }
 
-static constexpr u32 kCfGroup = 2048;  // blocks whose runs a pass-2 workgroup lines up at a time
+static constexpr u32 kCfGroup = 2 * kCfThreads2;  // blocks whose runs a pass-2 workgroup lines up at a time (two per thread)
 struct ColFreqWideEntry {  // == csvsimd_freq_entry
     u64 first_record, begin, end, count;
 };
