@@ -40,10 +40,17 @@ Scaling: weak by default (every rank holds --gib-per-gpu bytes at every N).  --s
 into one shard per rank; the default line also carries that leg (strong_scaling_check: the same 64 GiB file — BASELINE
 config 4 — indexed and verified at this N: all of it on one GPU at N = 1, 8 GiB each at N = 8).
 
-N = 1 only: other_workloads (the 1-GiB configs 2, 3, 5, timed and verified; an independent plain-copy yardstick next to
-the dense corpus' bare-stream probe), batch_many_files (8 x 128 MiB: eight launches vs ONE batched launch), consumers
-(file + tape -> columns in one pass, frequency count and search on a column, PMC traffic of the committed profile),
-ingest (the host-buffer drop-in, PCIe-inclusive, next to the probed H2D rate — never part of `value`).
+N = 1 only: other_workloads (the 1-GiB configs 2, 3, 5, timed and verified — config 5 by the library's dense instantiation,
+which the context chooses from the corpus' density; an independent plain-copy yardstick next to the dense corpus'
+bare-stream probe), batch_many_files (8 and 64 x 128 MiB: that many launches vs ONE batched launch), consumers (file +
+tape -> columns in one pass, frequency count and search on a column, PMC traffic of the committed profile), latency (the
+host-buffer drop-in on 300 B ... 32 MiB with one kept context, one host core beside it), ingest (the same entry point on
+2 GiB, PCIe-inclusive, next to the probed H2D rate, with the call's per-thread phase times — never part of `value`).
+
+`python bench.py --gpus N` (N > 1) without a launcher starts the N ranks itself: torch.distributed.run as a child process,
+before this process has touched the GPU; the child's rank 0 prints the line.  Sharded steps keep three steps in flight:
+the tail of a step (all-gather, stitch, re-emit, copy-out) runs on a second, high-priority stream beside the next step's
+first pass.
 """
 import argparse
 import json

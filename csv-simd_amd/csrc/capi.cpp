@@ -644,11 +644,11 @@ int csvsimd_stage1_bound(uint64_t len, uint64_t* max_entries) {
     return CSVSIMD_OK;
 }
 
-// Host-buffer drop-in for reader::read (ingest).  The file is streamed through
-// the GPU in chunks over a two-slot pipeline on two private streams (H2D; kernels): while the kernels of chunk i
-// run, chunk i+1 is staged (sliced over a few host threads) and already on its way to the device, and the tape of
-// chunk i-1 is expanded from its pinned slot into the caller's tape.  This path is PCIe bound by construction; the
-// HBM-resident entry points are the timed ones.
+// Host-buffer drop-in for reader::read (ingest).  The file is streamed through the GPU in chunks
+// over up to four slots on private streams (H2D, two taking turns; kernels): a stager thread copies chunks into pinned
+// slots ahead of the H2D copies, the caller enqueues copy + kernels per chunk and reads records two chunks late, an
+// expander thread widens the offsets that came back into the caller's tape (stage1_index_host_body).  This path is
+// PCIe bound by construction; the HBM-resident entry points are the timed ones.  Slots are allocated when first needed.
 static int pipe_setup(csvsimd_ctx* ctx, int slots = 2, uint64_t slot_bytes = csvsimd_ctx::kChunk) {
     // everything is created when it is first needed and kept: a previous attempt may have failed half way (out of
     // memory), a small file needs one small slot, a large one all four at full size
