@@ -262,6 +262,17 @@ __device__ __forceinline__ u64 hash_row(const ColView& c, u64 i, u32 len) {
     }
     return h;
 }
+// the same function of a row that is already in registers (strides of 16 and 32 bytes: b is ignored for 16)
+__device__ __forceinline__ u64 hash_regs(u32 stride, u32 len, const u32x4c a, const u32x4c b) {
+    u64 h = 0x243F6A8885A308D3ull ^ ((u64)len * 0x9E3779B97F4A7C15ull);
+    h = cmix64(h ^ (((u64)a.y << 32) | a.x)) + 0x9E3779B97F4A7C15ull;
+    h = cmix64(h ^ (((u64)a.w << 32) | a.z));
+    if (stride > 16) {
+        h = cmix64(h ^ (((u64)b.y << 32) | b.x)) + 0x9E3779B97F4A7C15ull;
+        h = cmix64(h ^ (((u64)b.w << 32) | b.z));
+    }
+    return h;
+}
 __device__ __forceinline__ bool rows_equal(const ColView& c, u64 i, u64 j, u32 len_i) {
     if (c.len && c.len[j] != len_i) return false;
     const u32x4c* p = reinterpret_cast<const u32x4c*>(c.col + i * c.stride);
@@ -296,6 +307,19 @@ __device__ __forceinline__ bool rows_equal(const ColView& c, u64 i, u64 j, u32 l
 // Algorithmic bytes: the column and its lengths read once, 16 bytes per distinct value written; the tuples add 12 bytes
 // written + read per value that survives pass 1's aggregation.
 // ---------------------------------------------------------------------------------------------
+// rows i and j equal (lengths and bytes)?  Both lengths and both rows are requested at once: one trip to memory instead
+// of three dependent ones (length of i, length of j, rows) — pass 2 calls this once per tuple of a column of few values.
+__device__ __forceinline__ bool rows_equal_eager(const ColView& c, u64 i, u64 j) {
+    if (c.stride > 32) return rows_equal(c, i, j, c.len ? c.len[i] : c.stride);
+    const u32x4c* const p = reinterpret_cast<const u32x4c*>(c.col + i * c.stride);
+    const u32x4c* const q = reinterpret_cast<const u32x4c*>(c.col + j * c.stride);
+    const bool two = c.stride > 16;
+    const u32 li = c.len ? c.len[i] : 0u, lj = c.len ? c.len[j] : 0u;
+    const u32x4c x0 = p[0], y0 = q[0];
+    const u32x4c x1 = two ? p[1] : u32x4c{0, 0, 0, 0}, y1 = two ? q[1] : u32x4c{0, 0, 0, 0};
+    return li == lj && x0.x == y0.x && x0.y == y0.y && x0.z == y0.z && x0.w == y0.w && x1.x == y1.x && x1.y == y1.y &&
+           x1.z == y1.z && x1.w == y1.w;
+}
 struct ColFreqStatus {  // == csvsimd_colfreq_status
     u64 n_records, n_distinct, truncated, overflow;
 };
@@ -315,13 +339,15 @@ static constexpr u32 kCfRound2 = 6144;       // tuples a pass-2 round may be ask
 #endif
 static constexpr u32 kCfThreads2 = CSVSIMD_CF_THREADS2;
 static constexpr u32 kCfTupleWords = 3;      // {first record, count, low 32 hash bits}
+static constexpr u32 kCfTickets = 16;        // pass 2's ticket counters, a 128-byte line each
+static constexpr u32 kCfTicketBytes = kCfTickets * 128;
 
 struct ColFreqGeom {
     u32 slabs;       // W: pass-1 workgroups = tuple blocks
     u32 parts;       // P: partitions (a power of two)
     u64 offs_bytes;  // u16 offs[P + 2][W]: row p = where partition p starts in every block, row P = the block's tuple
                      // count, row P + 1 = records of the slab longer than the stride
-    u64 bytes;       // the whole scratch: [offs | tuples: W blocks of kCfSlab x 12 bytes]
+    u64 bytes;       // the whole scratch: [offs | tuples: W blocks of kCfSlab x 12 bytes | pass 2's tickets]
 };
 static ColFreqGeom colfreq_geom(u64 n_rows) {
     ColFreqGeom g;
@@ -332,7 +358,7 @@ static ColFreqGeom colfreq_geom(u64 n_rows) {
     while (p < want && p < kCfMaxParts) p <<= 1;
     g.parts = p;
     g.offs_bytes = (((u64)(g.parts + 2) * g.slabs * 2) + 255) & ~255ull;
-    g.bytes = g.offs_bytes + (u64)g.slabs * kCfSlab * kCfTupleWords * 4 + 256;
+    g.bytes = g.offs_bytes + (u64)g.slabs * kCfSlab * kCfTupleWords * 4 + kCfTicketBytes;
     return g;
 }
 u64 colfreq_scratch_bytes(u64 n_rows) { return colfreq_geom(n_rows).bytes; }
@@ -352,13 +378,29 @@ __device__ __forceinline__ u32 wave_sum_u32(u32 v) {
 }
 __device__ __forceinline__ u32 cf_part(u64 h, u32 parts) { return (u32)(h >> 40) & (parts - 1u); }
 
+// dev builds only (make EXTRA=-DCSVSIMD_CF_TRACE): thread 0 of every workgroup leaves s_memrealtime stamps (100 MHz) at
+// the phase boundaries of both passes; scripts/r04_cf_trace.py reads them back.  The product build has none of this.
+#ifdef CSVSIMD_CF_TRACE
+__device__ u64 g_cf_trace[2][4096][8];
+#define CF_STAMP(pass, wg, idx)                                                          \
+    if (threadIdx.x == 0 && (wg) < 4096) {                                               \
+        __builtin_amdgcn_s_waitcnt(0);                                                   \
+        g_cf_trace[pass][wg][idx] = __builtin_amdgcn_s_memrealtime();                    \
+    }
+#else
+#define CF_STAMP(pass, wg, idx)
+#endif
+
 // ROWS_IN_LDS (strides up to 32 bytes): the table keeps a copy of every slot's representative row.  A record that meets
 // its value in the table compares against LDS instead of gathering the representative's row from memory — on a column
 // of few values that gather (64 lanes, ~64 different lines per load) was 12 of the kernel's 34 us (ablation, round 4).
+// The thread's own eight rows stay in registers from the hashing on: reading them again for the comparison was a trip
+// to the L2 per record, one after the other (the L1 has long moved on: a slab is 256 KiB) — 13 of the remaining 30 us
+// (phase stamps, profiles/r04_cf_trace.txt).
 template <bool ROWS_IN_LDS>
 __global__ __launch_bounds__(kCfThreads1) void colfreq_partition_kernel(const ColView c, unsigned short* __restrict__ offs,
                                                                        u32* __restrict__ tuples, u32 parts, u32 slabs,
-                                                                       ColFreqStatus* __restrict__ status) {
+                                                                       ColFreqStatus* __restrict__ status, u32* __restrict__ ticket) {
     __shared__ u64 s_key[kCfLds];    // hash bits 32..63 << 32 | (record - r0) + 1; 0 = empty
     __shared__ u32 s_count[kCfLds];
     __shared__ u32 s_first[kCfLds];  // smallest (record - r0) holding the slot's value
@@ -372,6 +414,7 @@ __global__ __launch_bounds__(kCfThreads1) void colfreq_partition_kernel(const Co
     __shared__ __attribute__((aligned(16))) u32 s_buf[kCfSlab * kCfTupleWords];
     static_assert(kCfSlab * kCfTupleWords * 4 >= kCfLds * 32, "the tuple staging doubles as the row cache");
     const u32 t = threadIdx.x, w = blockIdx.x;
+    CF_STAMP(0, w, 0)
     for (u32 k = t; k < kCfLds; k += kCfThreads1) {
         s_key[k] = 0;
         s_count[k] = 0;
@@ -385,85 +428,111 @@ __global__ __launch_bounds__(kCfThreads1) void colfreq_partition_kernel(const Co
         if (w == 0) {  // pass 2 (the next launch on this stream) adds to the one and may set the other
             status->n_distinct = 0;
             status->overflow = 0;
+            for (u32 k = 0; k < kCfTickets; ++k) ticket[k * 32] = 0;
         }
     }
     __syncthreads();
     const u64 r0 = (u64)w * kCfSlab;
     const u32 nrec = (u32)(c.n_rows - r0 < kCfSlab ? c.n_rows - r0 : kCfSlab);
-    u32x4c* const s_rows = reinterpret_cast<u32x4c*>(s_buf);  // slot s: s_rows[2 s], s_rows[2 s + 1]
+    // slot s: bytes 0..15 in s_rows[s], bytes 16..31 in s_rows[kCfLds + s] (two arrays of 16-byte elements: a wave's
+    // reads of random slots meet half as many bank conflicts as with 32-byte elements)
+    u32x4c* const s_rows = reinterpret_cast<u32x4c*>(s_buf);
     // ---- phase A: hash every record; repeated values meet in the LDS table -----------------------------------------
     u64 hs[kCfPerThread];
-    u32 lens[kCfPerThread];
     u32 single = 0, trunc = 0;  // bit j: record j of this thread goes out as its own tuple
-    // all of this thread's rows are requested before the first one is used: eight independent load -> hash chains
-    // instead of eight round trips one after the other (the probing below is a chain of its own)
+    // a batch of this thread's rows is requested before the first one is used: independent load -> hash chains instead
+    // of round trips one after the other (the probing below is a chain of its own).  ROWS_IN_LDS keeps the batch's rows in
+    // registers for the comparisons, so a batch is four records (eight would not fit a 1 024-thread workgroup's 128).
+    constexpr u32 kBatch = ROWS_IN_LDS ? 4 : kCfPerThread;
 #pragma unroll
-    for (u32 j = 0; j < kCfPerThread; ++j) {
-        const u32 li = j * kCfThreads1 + t;  // consecutive lanes, consecutive records: coalesced loads
-        hs[j] = 0;
-        lens[j] = 0;
-        if (li < nrec) {
-            const u64 i = r0 + li;
-            const u32 len = c.len ? c.len[i] : c.stride;
-            lens[j] = len;
-            if (len > c.stride) ++trunc;
-            hs[j] = hash_row(c, i, len);
-        }
-    }
+    for (u32 jb = 0; jb < kCfPerThread; jb += kBatch) {
+        u32 lens[kBatch];
+        u32x4c ra[kBatch], rb[kBatch];  // ROWS_IN_LDS: the rows themselves
 #pragma unroll
-    for (u32 j = 0; j < kCfPerThread; ++j) {
-        const u32 li = j * kCfThreads1 + t;
-        if (li >= nrec) continue;
-        const u64 i = r0 + li;
-        const u32 len = lens[j];
-        const u64 h = hs[j];
-        const u64 mine = (h & 0xffffffff00000000ull) | (u64)(li + 1u);
-        bool done = false;
-        // a column of many distinct values fills the table with its first rows; from then on new values only find full
-        // probe sequences, so the probing is limited to a look at the home slot
-        const int max_probes = s_fill < kCfLds * 3 / 4 ? 8 : 1;
-        u32 s = (u32)h & (kCfLds - 1);
-        for (int p = 0; p < max_probes && !done; ++p, s = (s + 1) & (kCfLds - 1)) {
-            u64 old = s_key[s];
-            if (old == 0) old = atomicCAS((unsigned long long*)&s_key[s], 0ull, (unsigned long long)mine);
-            if (old == 0) {
-                s_hlo[s] = (u32)h;
-                s_hmid[s] = (u32)(h >> 32);
-                atomicAdd(&s_fill, 1u);
-                atomicAdd(&s_count[s], 1u);
-                atomicMin(&s_first[s], li);
+        for (u32 jj = 0; jj < kBatch; ++jj) {
+            const u32 j = jb + jj;
+            const u32 li = j * kCfThreads1 + t;  // consecutive lanes, consecutive records: coalesced loads
+            hs[j] = 0;
+            lens[jj] = 0;
+            ra[jj] = rb[jj] = u32x4c{0, 0, 0, 0};
+            if (li < nrec) {
+                const u64 i = r0 + li;
+                const u32 len = c.len ? c.len[i] : c.stride;
+                lens[jj] = len;
+                if (len > c.stride) ++trunc;
                 if (ROWS_IN_LDS) {
-                    // this record's row (its lines are in the L1: it was just hashed) becomes the slot's copy; the flag
-                    // goes up behind it (release at workgroup scope: LDS operations of a wave complete in order)
                     const u32x4c* const p0 = reinterpret_cast<const u32x4c*>(c.col + i * c.stride);
-                    s_rows[2 * s] = p0[0];
-                    s_rows[2 * s + 1] = c.stride > 16 ? p0[1] : u32x4c{0, 0, 0, 0};
-                    __hip_atomic_store(&s_rlen[s], len | 0x80000000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                done = true;
-            } else if ((old >> 32) == (mine >> 32)) {
-                bool eq;
-                const u32 rl = ROWS_IN_LDS ? __hip_atomic_load(&s_rlen[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
-                if (ROWS_IN_LDS && (rl >> 31)) {
-                    const u32x4c* const p0 = reinterpret_cast<const u32x4c*>(c.col + i * c.stride);
-                    const u32x4c a0 = p0[0], a1 = c.stride > 16 ? p0[1] : u32x4c{0, 0, 0, 0};
-                    const u32x4c b0 = s_rows[2 * s], b1 = s_rows[2 * s + 1];
-                    eq = (rl & 0x7fffffffu) == len && a0.x == b0.x && a0.y == b0.y && a0.z == b0.z && a0.w == b0.w &&
-                         a1.x == b1.x && a1.y == b1.y && a1.z == b1.z && a1.w == b1.w;
+                    ra[jj] = p0[0];
+                    if (c.stride > 16) rb[jj] = p0[1];
+                    hs[j] = hash_regs(c.stride, len, ra[jj], rb[jj]);
                 } else {
-                    eq = rows_equal(c, i, r0 + ((u32)old - 1u), len);  // (the copy is not there yet, or strides > 32)
-                }
-                if (eq) {
-                    atomicAdd(&s_count[s], 1u);
-                    atomicMin(&s_first[s], li);
-                    done = true;
+                    hs[j] = hash_row(c, i, len);
                 }
             }
         }
-        if (!done) single |= 1u << j;
+        if (jb == 0) { CF_STAMP(0, w, 1) }
+#pragma unroll
+        for (u32 jj = 0; jj < kBatch; ++jj) {
+            const u32 j = jb + jj;
+            const u32 li = j * kCfThreads1 + t;
+            if (li >= nrec) continue;
+            const u64 i = r0 + li;
+            const u32 len = lens[jj];
+            const u64 h = hs[j];
+            const u64 mine = (h & 0xffffffff00000000ull) | (u64)(li + 1u);
+            bool done = false;
+            // a column of many distinct values fills the table with its first rows; from then on new values only find
+            // full probe sequences, so the probing is limited to a look at the home slot
+            const int max_probes = s_fill < kCfLds * 3 / 4 ? 8 : 1;
+            u32 s = (u32)h & (kCfLds - 1);
+            for (int p = 0; p < max_probes && !done; ++p, s = (s + 1) & (kCfLds - 1)) {
+                u64 old = s_key[s];
+                // (key and flag are requested together; the row is read after the flag, and a wave's LDS operations
+                // execute in order: a flag that is up means the row behind it is complete)
+                u32 rl = ROWS_IN_LDS ? __hip_atomic_load(&s_rlen[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+                if (old == 0) old = atomicCAS((unsigned long long*)&s_key[s], 0ull, (unsigned long long)mine);
+                if (old == 0) {
+                    s_hlo[s] = (u32)h;
+                    s_hmid[s] = (u32)(h >> 32);
+                    atomicAdd(&s_fill, 1u);
+                    atomicAdd(&s_count[s], 1u);
+                    atomicMin(&s_first[s], li);
+                    if (ROWS_IN_LDS) {
+                        // this record's row becomes the slot's copy; the flag goes up behind it (release at workgroup
+                        // scope: LDS operations of a wave complete in order)
+                        s_rows[s] = ra[jj];
+                        s_rows[kCfLds + s] = rb[jj];
+                        __hip_atomic_store(&s_rlen[s], len | 0x80000000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    done = true;
+                } else if ((old >> 32) == (mine >> 32)) {
+                    bool eq;
+                    if (ROWS_IN_LDS && (rl >> 31)) {
+                        asm volatile("" ::: "memory");
+                        const u32x4c a0 = ra[jj], a1 = rb[jj];
+                        const u32x4c b0 = s_rows[s], b1 = s_rows[kCfLds + s];
+                        eq = (rl & 0x7fffffffu) == len && a0.x == b0.x && a0.y == b0.y && a0.z == b0.z && a0.w == b0.w &&
+                             a1.x == b1.x && a1.y == b1.y && a1.z == b1.z && a1.w == b1.w;
+                    } else {
+                        eq = rows_equal(c, i, r0 + ((u32)old - 1u), len);  // (the copy is not there yet, or strides > 32)
+                    }
+                    if (eq) {
+                        atomicAdd(&s_count[s], 1u);
+                        // (a thread meets its records in ascending order and so does the workgroup, roughly: after the
+                        // first round the slot's smallest record is rarely beaten, and a read is cheaper than a contended
+                        // atomic)
+                        if (li < s_first[s]) atomicMin(&s_first[s], li);
+                        done = true;
+                    }
+                }
+            }
+            if (!done) single |= 1u << j;
+        }
     }
+    CF_STAMP(0, w, 2)
     if (trunc) atomicAdd(&s_trunc, trunc);
     __syncthreads();
+    CF_STAMP(0, w, 3)
     // ---- phase B: counting sort of this workgroup's tuples by partition ----------------------------------------------
     // every tuple takes a rank within its partition (one returning LDS atomic), the histogram is scanned, and the tuple
     // goes to slot prefix[partition] + rank of the staging buffer, which then leaves as one contiguous, coalesced write
@@ -530,6 +599,7 @@ __global__ __launch_bounds__(kCfThreads1) void colfreq_partition_kernel(const Co
         q[2] = s_hlo[t];
     }
     __syncthreads();
+    CF_STAMP(0, w, 4)
     u32* const block = tuples + (u64)w * kCfSlab * kCfTupleWords;  // 96 KiB apart: 16-byte aligned
     const u32 words = total * kCfTupleWords;
     for (u32 k = 4 * t; k < words; k += 4 * kCfThreads1) {
@@ -539,6 +609,7 @@ __global__ __launch_bounds__(kCfThreads1) void colfreq_partition_kernel(const Co
             for (u32 q = k; q < words; ++q) block[q] = s_buf[q];
         }
     }
+    CF_STAMP(0, w, 5)
 }
 
 static constexpr u32 kCfGroup = 2 * kCfThreads2;  // blocks whose runs a pass-2 workgroup lines up at a time (two per thread)
@@ -549,62 +620,122 @@ template <bool WIDE>
 __global__ __launch_bounds__(kCfThreads2) void colfreq_reduce_kernel(const ColView c, const unsigned short* __restrict__ offs,
                                                                     const u32* __restrict__ tuples, u32 parts, u32 slabs,
                                                                     u64 first_record, ColFreqEntry* __restrict__ out, u64 out_cap,
-                                                                    ColFreqStatus* __restrict__ status, const FreqWideOut wide) {
+                                                                    ColFreqStatus* __restrict__ status, const FreqWideOut wide,
+                                                                    u32* __restrict__ ticket, u32 groups) {
     __shared__ u64 s_key[kCfCap2];    // low 32 hash bits << 32 | representative record + 1; 0 = empty
     __shared__ u32 s_count[kCfCap2];
     __shared__ u32 s_first[kCfCap2];
     __shared__ unsigned short s_beg[kCfGroup];  // where the partition's run starts in block w0 + k
     __shared__ u32 s_pre[kCfGroup + 1];         // tuples of the partition in blocks w0 .. w0 + k - 1
     __shared__ u32 s_wave[kCfThreads2 / 64];
-    __shared__ u32 s_total, s_overflow;
+    __shared__ u32 s_total, s_trsum, s_overflow, s_next;
     __shared__ u64 s_base;
     const u32 t = threadIdx.x, lane = t & 63u, wv = t >> 6;
-    for (u32 p = blockIdx.x; p < parts; p += gridDim.x) {
-        // tuples of this partition over all blocks (a block's run for partition p ends where its run for p + 1 starts;
-        // the last partition's ends at the block's tuple count — row `parts` of the table)
-        if (t == 0) { s_total = 0; s_overflow = 0; }
+    // A workgroup's first partition is its index; the ones after that come from a ticket (zeroed by pass 1).  A column of
+    // few values leaves most partitions empty (a microsecond each) and a few with seven microseconds of dependent steps:
+    // with a fixed p += gridDim.x walk the call waited for the workgroups that drew two of the latter.  The ticket for
+    // the next partition is requested before the work on this one and read after it: no trip is added.  There are
+    // `groups` counters (workgroup b draws from counter b % groups the partitions congruent to it; gridDim.x is a multiple
+    // of `groups`): 256 draws on ONE word took 3 us to serve, and loads return behind an atomic issued before them.
+    const u32 grp = blockIdx.x % groups;
+    // ---- once per workgroup: how many tuples pass 1 left in all (row `parts` of the table) --------------------------------
+    // With few tuples (a column of few values: a handful per block) most partitions are empty and the rest hold a few
+    // hundred tuples each; `span` neighbouring partitions — neighbours in every block's sorted run as well — are then
+    // merged as one, so that every workgroup has exactly one to do instead of two or more one after the other.
+    // Workgroup 0 adds up the blocks' counts of records longer than the stride on the same trip.
+    u32 span = 1;
+    if (parts > gridDim.x || blockIdx.x == 0) {
+        if (t == 0) { s_total = 0; s_trsum = 0; }
         __syncthreads();
-        u32 mine = 0;
-        for (u32 w = t; w < slabs; w += kCfThreads2)
-            mine += (u32)offs[(u64)(p + 1) * slabs + w] - (u32)offs[(u64)p * slabs + w];
+        u32 mine = 0, tr = 0;
+        for (u32 w = t; w < slabs; w += kCfThreads2) {
+            mine += offs[(u64)parts * slabs + w];
+            if (blockIdx.x == 0) tr += offs[(u64)(parts + 1) * slabs + w];
+        }
         mine = wave_sum_u32(mine);
+        tr = wave_sum_u32(tr);
         if (lane == 0 && mine) atomicAdd(&s_total, mine);
+        if (lane == 0 && tr) atomicAdd(&s_trsum, tr);
         __syncthreads();
-        const u32 total = s_total;
+        if (parts % gridDim.x == 0 && (u64)s_total <= (u64)gridDim.x * (kCfRound2 / 2)) span = parts / gridDim.x;
+        if (blockIdx.x == 0 && t == 0) {
+            status->n_records = c.n_rows;
+            status->truncated = s_trsum;
+        }
+        __syncthreads();  // (s_total is used again below)
+    }
+    const u32 nparts = parts / span;
+    const bool draws = nparts > gridDim.x;
+    const bool one_group = slabs <= kCfGroup;
+    u32 p = blockIdx.x;
+    while (p < nparts) {
+        // the partition's run in block w: [offs[pa][w], offs[pb][w]) (a block's run for partition q ends where its run for
+        // q + 1 starts; the last partition's ends at the block's tuple count — row `parts` of the table)
+        const u32 pa = p * span, pb = pa + span;
+        if (p == blockIdx.x) { CF_STAMP(1, p, 0) }
+        // line the runs of a group of kCfGroup blocks up: s_pre = exclusive prefix of their lengths (two blocks per thread, a
+        // wave scan, sixteen wave totals), so that tuple k of the group is found by a search in LDS and EVERY thread has a
+        // tuple to work on — a run is one tuple when the column has few values, sixteen when all differ.  Returns the
+        // group's tuple count.
+        auto line_up = [&](const u32 w0, const u32 g) -> u32 {
+            u32 len2[2];
+#pragma unroll
+            for (u32 j = 0; j < 2; ++j) {
+                const u32 k = 2 * t + j;
+                len2[j] = 0;
+                if (k < g) {
+                    const u32 b = offs[(u64)pa * slabs + w0 + k];
+                    len2[j] = (u32)offs[(u64)pb * slabs + w0 + k] - b;
+                    s_beg[k] = (unsigned short)b;
+                }
+            }
+            const u32 incl = wave_incl_scan_u32(len2[0] + len2[1]);
+            if (lane == 63) s_wave[wv] = incl;
+            __syncthreads();  // (also: a cleared table is complete, the previous group's s_pre / s_beg are no longer read)
+            u32 before = 0;
+            for (u32 k = 0; k < wv; ++k) before += s_wave[k];
+            const u32 excl = before + incl - (len2[0] + len2[1]);
+            if (2 * t < g) s_pre[2 * t] = excl;
+            if (2 * t + 1 < g) s_pre[2 * t + 1] = excl + len2[0];
+            if (t == kCfThreads2 - 1) s_pre[g] = before + incl;  // (threads past g hold zeros: the last thread's inclusive sum is the total)
+            __syncthreads();
+            return s_pre[g];
+        };
+        u32 total;
+        if (one_group) {
+            // up to kCfGroup blocks (16.7 M records): the line-up is the count — one trip to the table per partition
+            if (t == 0) s_overflow = 0;
+            total = line_up(0, slabs);
+        } else {
+            if (t == 0) { s_total = 0; s_overflow = 0; }
+            __syncthreads();
+            u32 mine = 0;
+            for (u32 w = t; w < slabs; w += kCfThreads2)
+                mine += (u32)offs[(u64)pb * slabs + w] - (u32)offs[(u64)pa * slabs + w];
+            mine = wave_sum_u32(mine);
+            if (lane == 0 && mine) atomicAdd(&s_total, mine);
+            __syncthreads();
+            total = s_total;
+        }
+        u32 drawn = 0;
+        if (draws && t == 0) drawn = atomicAdd(ticket + grp * 32, 1u);  // (behind this partition's first loads)
+        if (p == blockIdx.x) { CF_STAMP(1, p, 1) }
         const u32 rounds = total ? (total + kCfRound2 - 1) / kCfRound2 : 0;  // a skewed or huge partition: several passes over its tuples
+        // the table is as large as this partition needs: >= 2 slots per tuple, a power of two (a partition of a column
+        // of few values holds a few hundred tuples: clearing and scanning 1 024 slots instead of 8 192)
+        u32 cap = kCfThreads2;
+        while (cap < kCfCap2 && cap < 2 * total) cap <<= 1;
         for (u32 r = 0; r < rounds; ++r) {
-            for (u32 k = t; k < kCfCap2; k += kCfThreads2) {
+            for (u32 k = t; k < cap; k += kCfThreads2) {
                 s_key[k] = 0;
                 s_count[k] = 0;
                 s_first[k] = 0xffffffffu;
             }
+            if (one_group) __syncthreads();
             for (u32 w0 = 0; w0 < slabs; w0 += kCfGroup) {
-                // line the runs of kCfGroup blocks up: s_pre = exclusive prefix of their lengths (two blocks per thread, a
-                // wave scan, sixteen wave totals), so that tuple k of the group is found by a search in LDS and EVERY thread
-                // has a tuple to work on — a run is one tuple when the column has few values, sixteen when all differ
                 const u32 g = slabs - w0 < kCfGroup ? slabs - w0 : kCfGroup;
-                u32 len2[2];
-#pragma unroll
-                for (u32 j = 0; j < 2; ++j) {
-                    const u32 k = 2 * t + j;
-                    len2[j] = 0;
-                    if (k < g) {
-                        const u32 b = offs[(u64)p * slabs + w0 + k];
-                        len2[j] = (u32)offs[(u64)(p + 1) * slabs + w0 + k] - b;
-                        s_beg[k] = (unsigned short)b;
-                    }
-                }
-                const u32 incl = wave_incl_scan_u32(len2[0] + len2[1]);
-                if (lane == 63) s_wave[wv] = incl;
-                __syncthreads();  // (also: the table is cleared, the previous group's s_pre / s_beg are no longer read)
-                u32 before = 0;
-                for (u32 k = 0; k < wv; ++k) before += s_wave[k];
-                const u32 excl = before + incl - (len2[0] + len2[1]);
-                if (2 * t < g) s_pre[2 * t] = excl;
-                if (2 * t + 1 < g) s_pre[2 * t + 1] = excl + len2[0];
-                if (t == kCfThreads2 - 1) s_pre[g] = before + incl;  // (threads past g hold zeros: the last thread's inclusive sum is the total)
-                __syncthreads();
-                const u32 tg = s_pre[g];
+                const u32 tg = one_group ? total : line_up(w0, g);
+                if (p == blockIdx.x && w0 == 0 && r == 0) { CF_STAMP(1, p, 2) }
                 for (u32 k = t; k < tg; k += kCfThreads2) {
                     u32 lo = 0, hi = g;  // the block whose run holds tuple k: the last one with s_pre <= k
                     while (hi - lo > 1) {
@@ -615,14 +746,14 @@ __global__ __launch_bounds__(kCfThreads2) void colfreq_reduce_kernel(const ColVi
                     const u32 rec = q[0], cnt = q[1], h32 = q[2];
                     if (rounds > 1 && ((h32 >> 13) % rounds) != r) continue;
                     const u64 key = ((u64)h32 << 32) | ((u64)rec + 1);
-                    u32 s = h32 & (kCfCap2 - 1);
+                    u32 s = h32 & (cap - 1);
                     bool done = false;
-                    for (u32 probes = 0; probes < kCfCap2 && !done; ++probes, s = (s + 1) & (kCfCap2 - 1)) {
+                    for (u32 probes = 0; probes < cap && !done; ++probes, s = (s + 1) & (cap - 1)) {
                         u64 old = s_key[s];
                         if (old == 0) old = atomicCAS((unsigned long long*)&s_key[s], 0ull, (unsigned long long)key);
-                        // (the record's length is read only when hash bits meet: a partition's records lie all over the
+                        // (lengths and rows are read only when hash bits meet: a partition's records lie all over the
                         // column, and a 4-byte read per tuple from a random place was a sector of traffic per distinct value)
-                        if (old == 0 || ((old >> 32) == h32 && rows_equal(c, rec, (u32)old - 1u, c.len ? c.len[rec] : c.stride))) {
+                        if (old == 0 || ((old >> 32) == h32 && rows_equal_eager(c, rec, (u32)old - 1u))) {
                             atomicAdd(&s_count[s], cnt);
                             atomicMin(&s_first[s], rec);
                             done = true;
@@ -631,12 +762,13 @@ __global__ __launch_bounds__(kCfThreads2) void colfreq_reduce_kernel(const ColVi
                     if (!done) s_overflow = 1;  // more distinct values with these hash bits than a table holds
                 }
                 __syncthreads();
+                if (p == blockIdx.x && w0 == 0 && r == 0) { CF_STAMP(1, p, 3) }
             }
             // occupied slots -> entries; ONE reservation per workgroup and round
             u32 used[kCfCap2 / kCfThreads2], wave_total = 0;
 #pragma unroll
             for (u32 j = 0; j < kCfCap2 / kCfThreads2; ++j) {
-                used[j] = s_key[j * kCfThreads2 + t] != 0 ? 1u : 0u;
+                used[j] = j * kCfThreads2 < cap && s_key[j * kCfThreads2 + t] != 0 ? 1u : 0u;
                 wave_total += (u32)__builtin_popcountll(__ballot(used[j] != 0));
             }
             if (lane == 0) s_wave[wv] = wave_total;
@@ -648,6 +780,7 @@ __global__ __launch_bounds__(kCfThreads2) void colfreq_reduce_kernel(const ColVi
             }
             __syncthreads();
             u64 at = s_base;
+            if (p == blockIdx.x && r == 0) { CF_STAMP(1, p, 4) }
             for (u32 k = 0; k < wv; ++k) at += s_wave[k];
 #pragma unroll
             for (u32 j = 0; j < kCfCap2 / kCfThreads2; ++j) {
@@ -676,23 +809,30 @@ __global__ __launch_bounds__(kCfThreads2) void colfreq_reduce_kernel(const ColVi
             }
             __syncthreads();
         }
-        if (t == 0 && s_overflow) status->overflow = 1;
-    }
-    if (blockIdx.x == 0) {
-        // the call's totals: records, and how many of them were longer than the stride (pass 1 left a count per block)
-        if (t == 0) s_total = 0;
-        __syncthreads();
-        u32 mine = 0;
-        for (u32 w = t; w < slabs; w += kCfThreads2) mine += offs[(u64)(parts + 1) * slabs + w];
-        if (mine) atomicAdd(&s_total, mine);
-        __syncthreads();
+        if (p == blockIdx.x) { CF_STAMP(1, p, 5) }
         if (t == 0) {
-            status->n_records = c.n_rows;
-            status->truncated = s_total;
+            if (s_overflow) status->overflow = 1;
+            s_next = draws ? gridDim.x + grp + groups * drawn : nparts;
         }
+        __syncthreads();
+        p = s_next;
     }
+    CF_STAMP(1, blockIdx.x, 6)
 }
 
+#ifdef CSVSIMD_CF_TRACE
+}  // namespace csvsimd
+extern "C" int csvsimd_dev_cf_trace(uint64_t* out, int clear) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(csvsimd::g_cf_trace), sizeof(uint64_t) * 2 * 4096 * 8);
+    if (e == hipSuccess && clear) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(csvsimd::g_cf_trace));
+        if (e == hipSuccess) e = hipMemset(p, 0, sizeof(uint64_t) * 2 * 4096 * 8);
+    }
+    return (int)e;
+}
+namespace csvsimd {
+#endif
 static u32 cgrid_for(u64 items, u32 per_block, u32 cap) {
     u64 blocks = (items + per_block - 1) / per_block;
     if (blocks < 1) blocks = 1;
@@ -707,21 +847,24 @@ hipError_t launch_colfreq(const void* d_col, const void* d_len, u64 n_rows, u32 
     const ColView c = {(const uint8_t*)d_col, (const u32*)d_len, n_rows, stride};
     unsigned short* const offs = (unsigned short*)d_scratch;
     u32* const tuples = (u32*)((char*)d_scratch + g.offs_bytes);
+    u32* const ticket = (u32*)((char*)d_scratch + g.bytes - kCfTicketBytes);
     if (stride <= 32)
         hipLaunchKernelGGL(colfreq_partition_kernel<true>, dim3(g.slabs), dim3(kCfThreads1), 0, stream, c, offs, tuples, g.parts,
-                           g.slabs, status);
+                           g.slabs, status, ticket);
     else
         hipLaunchKernelGGL(colfreq_partition_kernel<false>, dim3(g.slabs), dim3(kCfThreads1), 0, stream, c, offs, tuples, g.parts,
-                           g.slabs, status);
+                           g.slabs, status, ticket);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const u32 cap = (u32)(n_cus > 0 ? n_cus : 256);  // one 140-KiB workgroup per CU
+    const u32 grid2 = g.parts < cap ? g.parts : cap;
+    const u32 groups = grid2 % kCfTickets == 0 ? kCfTickets : 1u;
     if (wide)
-        hipLaunchKernelGGL(colfreq_reduce_kernel<true>, dim3(g.parts < cap ? g.parts : cap), dim3(kCfThreads2), 0, stream, c, offs,
-                           tuples, g.parts, g.slabs, first_record, (ColFreqEntry*)d_entries, entries_cap, status, *wide);
+        hipLaunchKernelGGL(colfreq_reduce_kernel<true>, dim3(grid2), dim3(kCfThreads2), 0, stream, c, offs,
+                           tuples, g.parts, g.slabs, first_record, (ColFreqEntry*)d_entries, entries_cap, status, *wide, ticket, groups);
     else
-        hipLaunchKernelGGL(colfreq_reduce_kernel<false>, dim3(g.parts < cap ? g.parts : cap), dim3(kCfThreads2), 0, stream, c, offs,
-                           tuples, g.parts, g.slabs, first_record, (ColFreqEntry*)d_entries, entries_cap, status, FreqWideOut{});
+        hipLaunchKernelGGL(colfreq_reduce_kernel<false>, dim3(grid2), dim3(kCfThreads2), 0, stream, c, offs,
+                           tuples, g.parts, g.slabs, first_record, (ColFreqEntry*)d_entries, entries_cap, status, FreqWideOut{}, ticket, groups);
     return hipGetLastError();
 }
 

@@ -3,6 +3,8 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/r04_colfreq_cases
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+for lib in "" $LIBS; do
+if [ -n "$lib" ]; then export CSVSIMD_LIB=$REPO/csv-simd_amd/csrc/variants/$lib; echo "== $lib"; else unset CSVSIMD_LIB; echo "== product"; fi
 for c in few mid distinct; do
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$c" -- python3 $REPO/scripts/r04_colfreq_cases.py $c 2>&1 | grep -E "status|rror"
   f=$(find "$OUT/$c" -name "*kernel_stats.csv" | head -1)
@@ -14,6 +16,8 @@ for r in csv.DictReader(open(sys.argv[1])):
 PY
   find "$OUT/$c" -name "*.csv" -delete
 done
+done
+unset CSVSIMD_LIB
 cd $REPO && python3 bench.py --only-consumers 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])['consumers']
