@@ -27,7 +27,7 @@ def call():
 for _ in range(20): call()
 torch.cuda.synchronize()
 buf = np.zeros(2 * 4096 * 8, dtype=np.uint64)
-names = (("start", "hashed", "probed", "barrier", "sorted", "written"),
+names = (("start", "hashed", "probed", "barrier", "sorted", "written", "probed b0", "hashed b1"),
          ("start", "total", "prefix", "merged", "reserved", "end p0", "end all"))
 for flush in (False, True):
     if flush:

@@ -143,12 +143,14 @@ def test_columnar_frequency_is_counter(ctx, pkg, oracle, torch_cuda):
 
 def test_columnar_frequency_async_is_two_launches_and_graph_capturable(ctx, pkg, torch_cuda):
     """The asynchronous form: nothing waited for, allocated or copied — so it can be captured and replayed on new data; the
-    status record is read from device memory by the caller.  Sizes around the slab (8 192 records) and partition geometry,
-    all-distinct and few-valued columns, an empty column."""
+    status record is read from device memory by the caller.  Sizes around the slab (8 192 records) and partition geometry
+    (above 1 Mi records there are more partitions than workgroups: later partitions are drawn from tickets, and neighbouring
+    partitions are merged as one when pass 1 left few tuples), all-distinct, few-valued and in-between columns, an empty
+    column."""
     torch = torch_cuda
     rng = np.random.default_rng(77)
     stride = 32
-    for n in (1, 63, 8191, 8192, 8193, 100_000, 1_000_003):
+    for n in (1, 63, 8191, 8192, 8193, 100_000, 1_000_003, 2_100_000, 4_300_001):
         need = pkg.columnar_frequency_scratch_bytes(n)
         scratch = torch.empty(need, dtype=torch.uint8, device="cuda:0")
         col = torch.zeros((n, stride), dtype=torch.uint8, device="cuda:0")
@@ -165,9 +167,11 @@ def test_columnar_frequency_async_is_two_launches_and_graph_capturable(ctx, pkg,
         with torch.cuda.graph(g):
             pkg.columnar_frequency_device_async(ctx, col.data_ptr(), 0, n, stride, 5, scratch.data_ptr(), need, ent.data_ptr(),
                                                 ent.shape[0], d_status.data_ptr(), torch.cuda.current_stream().cuda_stream)
-        for kind in ("distinct", "few", "one"):
+        for kind in ("distinct", "few", "mid", "one"):
             if kind == "distinct":
                 keys = np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+            elif kind == "mid":
+                keys = rng.integers(0, 3000, size=n).astype(np.uint64) * np.uint64(0x2545F4914F6CDD1D)
             elif kind == "few":
                 keys = rng.integers(0, 37, size=n).astype(np.uint64)
             else:
