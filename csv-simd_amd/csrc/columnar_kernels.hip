@@ -326,10 +326,13 @@ struct ColFreqStatus {  // == csvsimd_colfreq_status
 struct ColFreqEntry {  // == csvsimd_colfreq_entry
     u64 first_record, count;
 };
-static constexpr u32 kCfSlab = 8192;         // records per pass-1 workgroup
-static constexpr u32 kCfThreads1 = 1024;
-static constexpr u32 kCfPerThread = kCfSlab / kCfThreads1;
-static constexpr u32 kCfLds = 1024;          // pass-1 LDS table slots
+#ifndef CSVSIMD_CF_SLAB
+#define CSVSIMD_CF_SLAB 8192
+#endif
+static constexpr u32 kCfSlab = CSVSIMD_CF_SLAB;  // records per pass-1 workgroup
+static constexpr u32 kCfPerThread = 8;       // records per pass-1 thread
+static constexpr u32 kCfThreads1 = kCfSlab / kCfPerThread;
+static constexpr u32 kCfLds = kCfThreads1;   // pass-1 LDS table slots (one per thread when the table goes out)
 static constexpr u32 kCfMaxParts = 4096;
 static constexpr u32 kCfCap2 = 8192;         // pass-2 LDS table slots.  (4 096 slots and twice the partitions, two workgroups per
                                              // CU instead of one: 20-25 % slower on every cardinality measured)
@@ -398,14 +401,13 @@ __device__ u64 g_cf_trace[2][4096][8];
 // to the L2 per record, one after the other (the L1 has long moved on: a slab is 256 KiB) — 13 of the remaining 30 us
 // (phase stamps, profiles/r04_cf_trace.txt).
 template <bool ROWS_IN_LDS>
-__global__ __launch_bounds__(kCfThreads1) void colfreq_partition_kernel(const ColView c, unsigned short* __restrict__ offs,
+__global__ __launch_bounds__(kCfThreads1, 4) void colfreq_partition_kernel(const ColView c, unsigned short* __restrict__ offs,
                                                                        u32* __restrict__ tuples, u32 parts, u32 slabs,
                                                                        ColFreqStatus* __restrict__ status, u32* __restrict__ ticket) {
     __shared__ u64 s_key[kCfLds];    // hash bits 32..63 << 32 | (record - r0) + 1; 0 = empty
     __shared__ u32 s_count[kCfLds];
     __shared__ u32 s_first[kCfLds];  // smallest (record - r0) holding the slot's value
     __shared__ u32 s_hlo[kCfLds];    // hash bits 0..31 of the slot's value (written by the claimer, read after the barrier)
-    __shared__ u32 s_hmid[kCfLds];   // hash bits 32..63 again, for the partition (cheaper than unpacking the key)
     __shared__ u32 s_rlen[kCfLds];   // ROWS_IN_LDS: the representative's length; bit 31 = its row is in s_buf (set last)
     __shared__ u32 s_hist[kCfMaxParts];
     __shared__ u32 s_scan[kCfThreads1];
@@ -495,7 +497,6 @@ __global__ __launch_bounds__(kCfThreads1) void colfreq_partition_kernel(const Co
                 if (old == 0) old = atomicCAS((unsigned long long*)&s_key[s], 0ull, (unsigned long long)mine);
                 if (old == 0) {
                     s_hlo[s] = (u32)h;
-                    s_hmid[s] = (u32)(h >> 32);
                     atomicAdd(&s_fill, 1u);
                     atomicAdd(&s_count[s], 1u);
                     atomicMin(&s_first[s], li);
@@ -555,7 +556,7 @@ __global__ __launch_bounds__(kCfThreads1) void colfreq_partition_kernel(const Co
     const bool own_slot = t < kCfLds && s_key[t] != 0;  // (kCfLds == kCfThreads1: one table slot per thread)
     part[kCfPerThread] = rank[kCfPerThread] = 0;
     if (own_slot) {
-        part[kCfPerThread] = cf_part((u64)s_hmid[t] << 32, parts);
+        part[kCfPerThread] = cf_part(s_key[t], parts);  // (the key's upper half = hash bits 32..63)
         rank[kCfPerThread] = atomicAdd(&s_hist[part[kCfPerThread]], 1u);
     }
     __syncthreads();
