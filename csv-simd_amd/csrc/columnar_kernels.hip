@@ -245,33 +245,45 @@ struct ColView {
     u32 stride;  // multiple of 16
 };
 
-__device__ __forceinline__ u64 cmix64(u64 z) {
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
+// The row hash.  Its quality only decides how evenly slots and partitions fill (values are equal when their BYTES are); its
+// cost is paid once per record by pass 1: the 64-bit finalisers used first (nine 64 x 64-bit multiplies per 32-byte row = 33
+// quarter-rate instructions) were ~5 us of a 23-us kernel.  This one folds 32 x 32 -> 64-bit products (one v_mad_u64_u32 per
+// eight bytes, the scheme of wyhash's 32-bit variant): two words of state, the row xored in eight bytes at a time, each step
+// replacing the state by the two halves of (s0 ^ k0) * (s1 ^ k1).  The low bits of a product are poorly mixed, so the
+// result's halves are s0 ^ s1 after two and after three closing steps.
+__device__ __forceinline__ void cf_mix(u32& s0, u32& s1) {
+    const u64 c = (u64)(s0 ^ 0x53c5ca59u) * (u64)(s1 ^ 0x74743c1bu);
+    s0 = (u32)c;
+    s1 = (u32)(c >> 32);
 }
-
+__device__ __forceinline__ void cf_absorb(u32& s0, u32& s1, const u32x4c v) {
+    s0 ^= v.x;
+    s1 ^= v.y;
+    cf_mix(s0, s1);
+    s0 ^= v.z;
+    s1 ^= v.w;
+    cf_mix(s0, s1);
+}
+__device__ __forceinline__ u64 cf_close(u32 s0, u32 s1) {
+    cf_mix(s0, s1);
+    cf_mix(s0, s1);
+    const u32 lo = s0 ^ s1;
+    cf_mix(s0, s1);
+    return ((u64)(s0 ^ s1) << 32) | lo;
+}
 // hash of record i's padded bytes + length, 16 bytes per step from aligned, coalesced loads
 __device__ __forceinline__ u64 hash_row(const ColView& c, u64 i, u32 len) {
     const u32x4c* p = reinterpret_cast<const u32x4c*>(c.col + i * c.stride);
-    u64 h = 0x243F6A8885A308D3ull ^ ((u64)len * 0x9E3779B97F4A7C15ull);
-    for (u32 k = 0; k < (c.stride >> 4); ++k) {
-        const u32x4c v = p[k];
-        h = cmix64(h ^ (((u64)v.y << 32) | v.x)) + 0x9E3779B97F4A7C15ull;
-        h = cmix64(h ^ (((u64)v.w << 32) | v.z));
-    }
-    return h;
+    u32 s0 = 0x243F6A88u ^ len, s1 = 0x85A308D3u;
+    for (u32 k = 0; k < (c.stride >> 4); ++k) cf_absorb(s0, s1, p[k]);
+    return cf_close(s0, s1);
 }
 // the same function of a row that is already in registers (strides of 16 and 32 bytes: b is ignored for 16)
 __device__ __forceinline__ u64 hash_regs(u32 stride, u32 len, const u32x4c a, const u32x4c b) {
-    u64 h = 0x243F6A8885A308D3ull ^ ((u64)len * 0x9E3779B97F4A7C15ull);
-    h = cmix64(h ^ (((u64)a.y << 32) | a.x)) + 0x9E3779B97F4A7C15ull;
-    h = cmix64(h ^ (((u64)a.w << 32) | a.z));
-    if (stride > 16) {
-        h = cmix64(h ^ (((u64)b.y << 32) | b.x)) + 0x9E3779B97F4A7C15ull;
-        h = cmix64(h ^ (((u64)b.w << 32) | b.z));
-    }
-    return h;
+    u32 s0 = 0x243F6A88u ^ len, s1 = 0x85A308D3u;
+    cf_absorb(s0, s1, a);
+    if (stride > 16) cf_absorb(s0, s1, b);
+    return cf_close(s0, s1);
 }
 __device__ __forceinline__ bool rows_equal(const ColView& c, u64 i, u64 j, u32 len_i) {
     if (c.len && c.len[j] != len_i) return false;

@@ -5,7 +5,7 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for lib in "" $LIBS; do
 if [ -n "$lib" ]; then export CSVSIMD_LIB=$REPO/csv-simd_amd/csrc/variants/$lib; echo "== $lib"; else unset CSVSIMD_LIB; echo "== product"; fi
-for c in few mid distinct; do
+for c in ${CASES:-few mid distinct}; do
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$c" -- python3 $REPO/scripts/r04_colfreq_cases.py $c 2>&1 | grep -E "status|rror"
   f=$(find "$OUT/$c" -name "*kernel_stats.csv" | head -1)
   python3 - "$f" <<'PY'
