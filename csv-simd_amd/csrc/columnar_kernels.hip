@@ -486,7 +486,6 @@ __global__ __launch_bounds__(kCfThreads1, 4) void colfreq_partition_kernel(const
         }
         if (jb == 0) { CF_STAMP(0, w, 1) }
         if (jb == kBatch) { CF_STAMP(0, w, 7) }
-        if (jb == kBatch) { CF_STAMP(0, w, 7) }
 #pragma unroll
         for (u32 jj = 0; jj < kBatch; ++jj) {
             const u32 j = jb + jj;
@@ -543,7 +542,6 @@ __global__ __launch_bounds__(kCfThreads1, 4) void colfreq_partition_kernel(const
             }
             if (!done) single |= 1u << j;
         }
-        if (jb == 0) { CF_STAMP(0, w, 6) }
         if (jb == 0) { CF_STAMP(0, w, 6) }
     }
     CF_STAMP(0, w, 2)
