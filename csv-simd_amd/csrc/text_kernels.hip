@@ -29,7 +29,8 @@ typedef uint64_t u64;
 // Shape: 16 bytes per lane, 4 KiB per wave per iteration in flight; a block that is pure ASCII and
 // does not follow a pending lead (the normal CSV case) costs 5 VALU per 16 bytes and streams at the
 // HBM read rate; any other block runs the rules as SWAR on dwords (flags live in bit 7 of each byte,
-// byte-shifted views via v_alignbyte), ~45 VALU per 4 bytes.
+// byte-shifted views via v_alignbyte), ~45 VALU per 4 bytes — or the first rule alone when a 1-KiB chunk
+// holds none of the bytes the others are about (see utf8_basic below).
 // Pass 2 (utf8_refine_kernel, one thread): backs up from p to a sequence start (<= 7 bytes) and
 // decodes forward sequentially to the exact offset.
 // ---------------------------------------------------------------------------------------------
@@ -51,21 +52,51 @@ __device__ __forceinline__ u32 prev_bytes(u32 cur, u32 prev, int n) {
     return __builtin_amdgcn_alignbyte(cur, prev, 4 - n);
 }
 
-// classifies dword x; returns its error flags given the flags of the dword before it
-__device__ __forceinline__ u32 utf8_swar(u32 x, Utf8Flags& pf) {
-    const u32 s1 = x << 1, s2 = x << 2, s3 = x << 3, s4 = x << 4, s5 = x << 5, s6 = x << 6, s7 = x << 7;
+// The part of the rules that text without "special" bytes needs: continuation expected XOR continuation found, plus the
+// two bytes that are never valid as 2-byte leads (C0, C1).  The other rules only ever fire on or right behind a byte from
+// {E0, ED, F0..FF} (overlong 3- and 4-byte forms, surrogates, > U+10FFFF, F8+).  A 1-KiB wave chunk without any — Latin,
+// Greek, Cyrillic, Arabic, Hebrew, CJK text; not Devanagari / Thai (E0), Hangul (ED) or emoji (F0) — is checked with the basic
+// rule alone: ~28 VALU per dword instead of ~55; everything computed to find that out is used by the full rules as well.
+struct Utf8Basic {
+    u32 ge_c0, ge_e0, ge_f0, cont;  // bit 7 of every byte
+    u32 c0c1;  // bit 7 of the LOWEST byte that is C0 or C1 is exact (bytes above one may be flagged too: same dword, the
+               // minimum offset wins)
+    u32 is_e0, is_ed;  // 11100000, 11101101: with ge_f0, the bytes that call for the narrowed rules
+};
+__device__ __forceinline__ Utf8Basic utf8_basic(u32 x) {
+    const u32 s1 = x << 1, s2 = x << 2, s3 = x << 3;
+    Utf8Basic f;
+    f.ge_c0 = x & s1;
+    f.ge_e0 = f.ge_c0 & s2;
+    f.ge_f0 = f.ge_e0 & s3;
+    f.cont = x & ~s1;
+    const u32 c = (x & 0xFEFEFEFEu) ^ 0xC0C0C0C0u;
+    f.c0c1 = (c - 0x01010101u) & ~c;
+    const u32 s4 = x << 4, s5 = x << 5, s6 = x << 6, s7 = x << 7;
+    const u32 e_lead = f.ge_e0 & ~s3;
+    f.is_e0 = (e_lead & ~s4) & (~s5 & ~s6 & ~s7);
+    f.is_ed = (e_lead & s4) & (s5 & ~s6 & s7);
+    return f;
+}
+__device__ __forceinline__ u32 utf8_has_special(const Utf8Basic& f) { return (f.is_e0 | f.is_ed | f.ge_f0) & 0x80808080u; }
+__device__ __forceinline__ u32 utf8_basic_errors(const Utf8Basic& f, const Utf8Basic& pf) {
+    const u32 must = prev_bytes(f.ge_c0, pf.ge_c0, 1) | prev_bytes(f.ge_e0, pf.ge_e0, 2) | prev_bytes(f.ge_f0, pf.ge_f0, 3);
+    return ((must ^ f.cont) | f.c0c1) & 0x80808080u;
+}
+
+// all rules on dword x (its basic flags in b); returns its error flags given the flags of the dword before it
+__device__ __forceinline__ u32 utf8_swar(u32 x, const Utf8Basic& b, Utf8Flags& pf) {
+    const u32 s2 = x << 2, s3 = x << 3, s4 = x << 4, s5 = x << 5, s6 = x << 6, s7 = x << 7;
     Utf8Flags f;
-    f.ge_c0 = x & s1;                 // 11xxxxxx
-    f.ge_e0 = f.ge_c0 & s2;           // 111xxxxx
-    f.ge_f0 = f.ge_e0 & s3;           // 1111xxxx
+    f.ge_c0 = b.ge_c0;                // 11xxxxxx
+    f.ge_e0 = b.ge_e0;                // 111xxxxx
+    f.ge_f0 = b.ge_f0;                // 1111xxxx
     const u32 ge_f8 = f.ge_f0 & s4;   // 11111xxx: never valid
-    const u32 cont = x & ~s1;         // 10xxxxxx
-    const u32 c0c1 = (f.ge_c0 & ~s2 & ~s3) & (~s4 & ~s5 & ~s6);  // 1100000x: overlong 2-byte forms
     const u32 f4xx = f.ge_f0 & ~s4 & s5;                         // 111101xx
     const u32 f5_7 = f4xx & (s6 | s7);                           // F5, F6, F7: > U+10FFFF
     const u32 low3_zero = ~s5 & ~s6 & ~s7;
-    f.is_e0 = (f.ge_e0 & ~s3 & ~s4) & low3_zero;                 // 11100000
-    f.is_ed = (f.ge_e0 & ~s3 & s4) & (s5 & ~s6 & s7);            // 11101101
+    f.is_e0 = b.is_e0;                                           // 11100000
+    f.is_ed = b.is_ed;                                           // 11101101
     f.is_f0 = f.ge_f0 & ~s4 & low3_zero;                         // 11110000
     f.is_f4 = f4xx & ~s6 & ~s7;                                  // 11110100
     const u32 must = prev_bytes(f.ge_c0, pf.ge_c0, 1) | prev_bytes(f.ge_e0, pf.ge_e0, 2) |
@@ -74,7 +105,7 @@ __device__ __forceinline__ u32 utf8_swar(u32 x, Utf8Flags& pf) {
     const u32 second = (prev_bytes(f.is_e0, pf.is_e0, 1) & ~s2) | (prev_bytes(f.is_ed, pf.is_ed, 1) & s2) |
                        (prev_bytes(f.is_f0, pf.is_f0, 1) & ~s2 & ~s3) | (prev_bytes(f.is_f4, pf.is_f4, 1) & (s2 | s3));
     pf = f;
-    return ((must ^ cont) | ge_f8 | c0c1 | f5_7 | second) & 0x80808080u;
+    return ((must ^ b.cont) | ge_f8 | b.c0c1 | f5_7 | second) & 0x80808080u;
 }
 
 // the aligned dword at abase[q, q + 4) with bytes outside [lo, hi) zeroed
@@ -140,11 +171,26 @@ __global__ __launch_bounds__(256) void utf8_scan_kernel(Utf8Range r, u64 n_chunk
             u32 w0 = (u32)__shfl_up((int)v[j][3], 1);
             const u32 edge = j == 0 ? halo : (u32)__builtin_amdgcn_readlane((int)v[j > 0 ? j - 1 : 0][3], 63);
             if (lane == 0) w0 = edge;
-            Utf8Flags pf = {0, 0, 0, 0, 0, 0, 0};
-            (void)utf8_swar(w0, pf);  // only its flags matter
             u32 e[4];
+            Utf8Basic bf[4];
+            const Utf8Basic b0 = utf8_basic(w0);
+            u32 special = utf8_has_special(b0);
 #pragma unroll
-            for (int d = 0; d < 4; ++d) e[d] = utf8_swar(v[j][d], pf);
+            for (int d = 0; d < 4; ++d) {
+                bf[d] = utf8_basic(v[j][d]);
+                special |= utf8_has_special(bf[d]);
+            }
+            if (__ballot(special != 0u) == 0ull) {
+                // no byte of this 1-KiB chunk (nor of the dword before any lane's 16 bytes) calls for the narrowed rules
+                e[0] = utf8_basic_errors(bf[0], b0);
+#pragma unroll
+                for (int d = 1; d < 4; ++d) e[d] = utf8_basic_errors(bf[d], bf[d - 1]);
+            } else {
+                Utf8Flags pf = {0, 0, 0, 0, 0, 0, 0};
+                (void)utf8_swar(w0, b0, pf);  // only its flags matter
+#pragma unroll
+                for (int d = 0; d < 4; ++d) e[d] = utf8_swar(v[j][d], bf[d], pf);
+            }
             if ((e[0] | e[1] | e[2] | e[3]) != 0u) {
                 const u32 d = e[0] ? 0u : e[1] ? 1u : e[2] ? 2u : 3u;
                 const u32 ed = e[0] ? e[0] : e[1] ? e[1] : e[2] ? e[2] : e[3];

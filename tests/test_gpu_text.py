@@ -29,10 +29,16 @@ def gpu_utf8(ctx, torch, host: np.ndarray, misalign=0, poison=0xFF):
     return ctx.utf8_validate_device(dbuf.data_ptr() + misalign, n)
 
 
-def test_utf8_sequences_at_every_boundary(ctx, torch_cuda, oracle):
+@pytest.mark.parametrize("filler", ["a", "é", "世"])
+def test_utf8_sequences_at_every_boundary(ctx, torch_cuda, oracle, filler):
     # each sequence, valid or not, ending at / straddling 16-byte chunk, 1-KiB wave-load and 4-KiB
-    # wave-iteration boundaries, and at the very start / end of the buffer; two poisons around it
+    # wave-iteration boundaries, and at the very start / end of the buffer; two poisons around it.
+    # The text around it is ASCII, 2-byte or 3-byte characters: a 1-KiB chunk of the latter two takes the kernel's
+    # basic-rule path unless the inserted sequence brings one of the bytes the narrowed rules are about (the insert
+    # also cuts characters of the filler in two: the oracle says where the first error then is)
     n = 3 * 4096 + 100
+    clen = len(filler.encode())
+    fill = np.frombuffer((filler * (n // clen + 1)).encode(), dtype=np.uint8)[:n]
     for mis in (0, 5, 15, 77, 127):
         for seq in BAD_AND_GOOD:
             s = np.frombuffer(seq, dtype=np.uint8)
@@ -41,11 +47,14 @@ def test_utf8_sequences_at_every_boundary(ctx, torch_cuda, oracle):
                     at = edge + shift - mis
                     if at < 0 or at + s.size > n:
                         continue
-                    d = np.full(n, ord("a"), dtype=np.uint8)
-                    d[at: at + s.size] = s
-                    want = oracle.utf8_first_invalid(d)
-                    for poison in (0xFF, 0x80):
-                        assert gpu_utf8(ctx, torch_cuda, d, mis, poison) == want, (mis, seq, edge, shift, poison)
+                    # as it falls, and moved back to a character boundary of the filler (the inserted sequence is then
+                    # the first thing that can be wrong)
+                    for pos in {at, at - at % clen}:
+                        d = fill.copy()
+                        d[pos: pos + s.size] = s
+                        want = oracle.utf8_first_invalid(d)
+                        for poison in (0xFF, 0x80):
+                            assert gpu_utf8(ctx, torch_cuda, d, mis, poison) == want, (mis, seq, edge, shift, pos, poison)
 
 
 def test_utf8_small_and_empty(ctx, torch_cuda, oracle):
