@@ -55,8 +55,9 @@ __device__ __forceinline__ u32 prev_bytes(u32 cur, u32 prev, int n) {
 // The part of the rules that text without "special" bytes needs: continuation expected XOR continuation found, plus the
 // two bytes that are never valid as 2-byte leads (C0, C1).  The other rules only ever fire on or right behind a byte from
 // {E0, ED, F0..FF} (overlong 3- and 4-byte forms, surrogates, > U+10FFFF, F8+).  A 1-KiB wave chunk without any — Latin,
-// Greek, Cyrillic, Arabic, Hebrew, CJK text; not Devanagari / Thai (E0), Hangul (ED) or emoji (F0) — is checked with the basic
-// rule alone: ~28 VALU per dword instead of ~55; everything computed to find that out is used by the full rules as well.
+// Greek, Cyrillic, Arabic, Hebrew, CJK text — is checked with the basic rule alone: ~28 VALU per dword instead of ~55; one with
+// E0 / ED leads but no byte >= F0 (Devanagari, Thai, Hangul) adds those two leads' second-byte test (~5 more); only a chunk with
+// F0..FF bytes (emoji, or garbage) runs everything.  What is computed to find that out is used by the full rules as well.
 struct Utf8Basic {
     u32 ge_c0, ge_e0, ge_f0, cont;  // bit 7 of every byte
     u32 c0c1;  // bit 7 of the LOWEST byte that is C0 or C1 is exact (bytes above one may be flagged too: same dword, the
@@ -78,7 +79,12 @@ __device__ __forceinline__ Utf8Basic utf8_basic(u32 x) {
     f.is_ed = (e_lead & s4) & (s5 & ~s6 & s7);
     return f;
 }
-__device__ __forceinline__ u32 utf8_has_special(const Utf8Basic& f) { return (f.is_e0 | f.is_ed | f.ge_f0) & 0x80808080u; }
+// middle tier: E0 / ED leads but no byte >= F0 in the chunk (Thai, Devanagari, Hangul text): the basic rule plus those two
+// leads' narrowed second byte (E0 -> A0..BF: bit 5 set; ED -> 80..9F: bit 5 clear)
+__device__ __forceinline__ u32 utf8_e0ed_errors(u32 x, const Utf8Basic& f, const Utf8Basic& pf) {
+    const u32 s2 = x << 2;
+    return ((prev_bytes(f.is_e0, pf.is_e0, 1) & ~s2) | (prev_bytes(f.is_ed, pf.is_ed, 1) & s2)) & 0x80808080u;
+}
 __device__ __forceinline__ u32 utf8_basic_errors(const Utf8Basic& f, const Utf8Basic& pf) {
     const u32 must = prev_bytes(f.ge_c0, pf.ge_c0, 1) | prev_bytes(f.ge_e0, pf.ge_e0, 2) | prev_bytes(f.ge_f0, pf.ge_f0, 3);
     return ((must ^ f.cont) | f.c0c1) & 0x80808080u;
@@ -174,17 +180,23 @@ __global__ __launch_bounds__(256) void utf8_scan_kernel(Utf8Range r, u64 n_chunk
             u32 e[4];
             Utf8Basic bf[4];
             const Utf8Basic b0 = utf8_basic(w0);
-            u32 special = utf8_has_special(b0);
+            u32 sp_f = b0.ge_f0, sp_e = b0.is_e0 | b0.is_ed;
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 bf[d] = utf8_basic(v[j][d]);
-                special |= utf8_has_special(bf[d]);
+                sp_f |= bf[d].ge_f0;
+                sp_e |= bf[d].is_e0 | bf[d].is_ed;
             }
-            if (__ballot(special != 0u) == 0ull) {
-                // no byte of this 1-KiB chunk (nor of the dword before any lane's 16 bytes) calls for the narrowed rules
+            if (__ballot((sp_f & 0x80808080u) != 0u) == 0ull) {
+                // no byte >= F0 in this 1-KiB chunk (nor in the dword before any lane's 16 bytes): the basic rule ...
                 e[0] = utf8_basic_errors(bf[0], b0);
 #pragma unroll
                 for (int d = 1; d < 4; ++d) e[d] = utf8_basic_errors(bf[d], bf[d - 1]);
+                if (__ballot((sp_e & 0x80808080u) != 0u) != 0ull) {  // ... and, with E0 / ED leads about, their second byte
+                    e[0] |= utf8_e0ed_errors(v[j][0], bf[0], b0);
+#pragma unroll
+                    for (int d = 1; d < 4; ++d) e[d] |= utf8_e0ed_errors(v[j][d], bf[d], bf[d - 1]);
+                }
             } else {
                 Utf8Flags pf = {0, 0, 0, 0, 0, 0, 0};
                 (void)utf8_swar(w0, b0, pf);  // only its flags matter

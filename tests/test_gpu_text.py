@@ -29,13 +29,13 @@ def gpu_utf8(ctx, torch, host: np.ndarray, misalign=0, poison=0xFF):
     return ctx.utf8_validate_device(dbuf.data_ptr() + misalign, n)
 
 
-@pytest.mark.parametrize("filler", ["a", "é", "世"])
+@pytest.mark.parametrize("filler", ["a", "é", "世", "ก", "한", "\U0001F600"])   # ASCII; C3; E4; E0; ED; F0 leads
 def test_utf8_sequences_at_every_boundary(ctx, torch_cuda, oracle, filler):
     # each sequence, valid or not, ending at / straddling 16-byte chunk, 1-KiB wave-load and 4-KiB
     # wave-iteration boundaries, and at the very start / end of the buffer; two poisons around it.
-    # The text around it is ASCII, 2-byte or 3-byte characters: a 1-KiB chunk of the latter two takes the kernel's
-    # basic-rule path unless the inserted sequence brings one of the bytes the narrowed rules are about (the insert
-    # also cuts characters of the filler in two: the oracle says where the first error then is)
+    # The text around it is ASCII, 2-, 3- or 4-byte characters: a 1-KiB chunk takes the kernel's basic-rule path, the
+    # one with the E0 / ED second-byte test, or the full rules, by the filler's lead and by what the inserted sequence
+    # brings (the insert also cuts characters of the filler in two: the oracle says where the first error then is)
     n = 3 * 4096 + 100
     clen = len(filler.encode())
     fill = np.frombuffer((filler * (n // clen + 1)).encode(), dtype=np.uint8)[:n]
