@@ -1360,8 +1360,17 @@ __device__ __forceinline__ u32 batch_item_of(const u32* first_tiles, u32 n_items
     return idx;
 }
 
+#ifdef CSVSIMD_WG_END_TRACE
+// dev builds only: per workgroup {first instruction, last ticket drawn, exit} in s_memrealtime ticks + tiles it counted
+__device__ u64 g_wg_trace[2048][4];
+#endif
 template <bool EMIT, int DBG = 0, int DIALECT = 0, bool BATCH = false, bool DENSE = false>
 __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
+#ifdef CSVSIMD_WG_END_TRACE
+    const u64 wg_t0 = __builtin_amdgcn_s_memrealtime();
+    u64 wg_tlast = 0;
+    u32 wg_tiles = 0;
+#endif
     __shared__ u32 s_tile;
     __shared__ u32 s_wdesc[kWaves][3];
     __shared__ u32 s_pin;
@@ -1494,6 +1503,9 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
         const u32 tile = (u32)__builtin_amdgcn_readfirstlane((int)s_tile);
         CSVSIMD_TRACE(0, tile)
         const bool have_cur = tile < args.num_tiles;
+#ifdef CSVSIMD_WG_END_TRACE
+        if (have_cur) { ++wg_tiles; wg_tlast = __builtin_amdgcn_s_memrealtime(); }
+#endif
         if (hold_token && !have_cur) {  // nothing to count: the partner workgroup need not wait for this one
             if (w == 0 && lane == 0) __hip_atomic_store(my_token, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             hold_token = false;
@@ -1802,6 +1814,14 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
 #undef s_lookback_win
     // ---- this workgroup is done; the last one to get here completes the launch --------------------
     if (w != 0) return;
+#ifdef CSVSIMD_WG_END_TRACE
+    if (blockIdx.x < 2048 && (threadIdx.x & 63u) == 0) {
+        g_wg_trace[blockIdx.x][0] = wg_t0;
+        g_wg_trace[blockIdx.x][1] = wg_tlast;
+        g_wg_trace[blockIdx.x][2] = __builtin_amdgcn_s_memrealtime();
+        g_wg_trace[blockIdx.x][3] = wg_tiles;
+    }
+#endif
     finish_launch<DIALECT, (DBG & 4) != 0, BATCH>(args, epoch_v & kEpochMask, inq_in,
                                            wg_tot, err,
                                            // the lane id again, from the execution mask: `lane` as derived from threadIdx.x
@@ -1809,6 +1829,13 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
                                            __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
 }
 
+#if defined(CSVSIMD_WG_END_TRACE) && !defined(CSVSIMD_DENSE_TU)
+}  // namespace csvsimd
+extern "C" int csvsimd_dev_wg_trace(uint64_t* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(csvsimd::g_wg_trace), sizeof(uint64_t) * 2048 * 4);
+}
+namespace csvsimd {
+#endif
 // KernelArgs of one launch over L's buffer (everything but the dialect's hashed tables)
 static void fill_kernel_args(const Stage1Launch& L, KernelArgs& a) {
     const uintptr_t addr = (uintptr_t)L.dbuf;
