@@ -10,6 +10,7 @@
 #include <emmintrin.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
@@ -17,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -144,77 +146,139 @@ public:
         }
     }
     ~CopyPool() { shutdown(); }
-    // synchronous: returns when all n bytes are in place
-    void copy(void* dst, const void* src, size_t n) { run_sliced(Job{(char*)dst, (const char*)src, n, 0, false, nullptr}, 1); }
-    // synchronous: dst[i] = base + src[i] for i < n
-    void expand(uint64_t* dst, const uint32_t* src, size_t n, uint64_t base) {
-        run_sliced(Job{(char*)dst, (const char*)src, n, base, true, nullptr}, 4);
+    // synchronous: returns when all n bytes are in place.  min_slice: the smallest piece worth handing to another thread
+    // (a large chunk of a long file: 2 MiB; a file of a few MiB, where the copy IS the call's critical path: 256 KiB)
+    void copy(void* dst, const void* src, size_t n, size_t min_slice = kMinSlice) {
+        run_sliced(Job{(char*)dst, (const char*)src, n, 0, kCopy, -1, nullptr}, 1, min_slice);
     }
+    // synchronous: dst[i] = base + src[i] for i < n
+    void expand(uint64_t* dst, const uint32_t* src, size_t n, uint64_t base, size_t min_slice = kMinSlice) {
+        run_sliced(Job{(char*)dst, (const char*)src, n, base, kWiden, -1, nullptr}, 4, min_slice);
+    }
+    // synchronous: n bytes of the file at offset off -> dst (pread by slices: the kernel copies page-cache pages straight into
+    // the pinned slot, no mapping of the file is touched).  false: a read failed or the file ended early (errno kept).
+    bool read_file(void* dst, int fd, uint64_t off, size_t n, size_t min_slice = kMinSlice) {
+        return run_sliced(Job{(char*)dst, nullptr, n, off, kPread, fd, nullptr}, 1, min_slice);
+    }
+    // From here to the matching quiet(): idle workers poll for slices instead of sleeping on the condition variable — a
+    // sleeping worker takes 20-60 us to start on a slice (futex wake + a core leaving its idle state), which is the whole
+    // copy time of a few MiB.  Held for the duration of ONE ingest call (RAII: Busy); nests.
+    void busy() { spinners_.fetch_add(1, std::memory_order_acq_rel); cv_work_.notify_all(); }
+    void quiet() { spinners_.fetch_sub(1, std::memory_order_acq_rel); }
+    struct Busy {
+        CopyPool* p;
+        explicit Busy(CopyPool* pool) : p(pool) { if (p) p->busy(); }
+        ~Busy() { if (p) p->quiet(); }
+        Busy(const Busy&) = delete;
+        Busy& operator=(const Busy&) = delete;
+    };
+    static constexpr size_t kMinSlice = 2u << 20;  // source bytes (512 KiB slices of a 4-MiB chunk of a LONG file: measured, no gain)
 
 private:
+    enum Kind : int { kCopy, kWiden, kPread };
+    struct Call {   // lives on the issuing call's frame until every slice has been executed
+        size_t left = 0;  // slices still out (guarded by m_)
+        bool ok = true;   // (guarded by m_)
+        int err = 0;
+    };
     struct Job {
         char* dst;
         const char* src;
-        size_t n;  // bytes (copy) or entries (expand)
-        uint64_t base;
-        bool widen;
-        size_t* left;  // the issuing call's count of slices still out (guarded by m_)
+        size_t n;  // bytes (copy, pread) or entries (expand)
+        uint64_t base;  // expand: added to every offset; pread: file offset
+        Kind kind;
+        int fd;
+        Call* call;
     };
-    static void execute(const Job& j) {
-        if (j.widen) expand_streaming((uint64_t*)j.dst, (const uint32_t*)j.src, j.n, j.base);
-        else copy_streaming(j.dst, j.src, j.n);
+    static bool execute(const Job& j, int* err) {
+        switch (j.kind) {
+            case kWiden: expand_streaming((uint64_t*)j.dst, (const uint32_t*)j.src, j.n, j.base); return true;
+            case kCopy: copy_streaming(j.dst, j.src, j.n); return true;
+            case kPread:
+                for (size_t done = 0; done < j.n;) {
+                    const ssize_t r = pread(j.fd, j.dst + done, j.n - done, (off_t)(j.base + done));
+                    if (r < 0 && errno == EINTR) continue;
+                    if (r <= 0) { *err = r < 0 ? errno : EIO; return false; }  // r == 0: the file got shorter under us
+                    done += (size_t)r;
+                }
+                return true;
+        }
+        return true;
     }
     // unit = source bytes per item of n
-    void run_sliced(Job whole, size_t unit) {
-        constexpr size_t kMinSlice = 2u << 20;  // source bytes (512 KiB slices — eight threads on a 4-MiB chunk — measured: no gain)
+    bool run_sliced(Job whole, size_t unit, size_t min_slice) {
         const size_t bytes = whole.n * unit;
-        const size_t parts = std::min<size_t>(threads_.size() + 1, std::max<size_t>(1, bytes / kMinSlice));
+        const size_t parts = std::min<size_t>(threads_.size() + 1, std::max<size_t>(1, bytes / std::max<size_t>(min_slice, 4096)));
+        Call call;
         if (parts <= 1) {
-            execute(whole);
-            return;
+            const bool ok = execute(whole, &call.err);
+            if (!ok) errno = call.err;
+            return ok;
         }
         const size_t slice = (((whole.n / parts) + 4095) & ~(size_t)4095);  // items; a multiple of 4096 keeps every slice aligned
-        const size_t dst_unit = whole.widen ? 8 : 1, src_unit = whole.widen ? 4 : 1;
-        size_t left = 0;  // lives on this frame until every slice of this call has been executed (the wait below)
+        const size_t dst_unit = whole.kind == kWiden ? 8 : 1, src_unit = whole.kind == kWiden ? 4 : 1;
         {
             std::lock_guard<std::mutex> g(m_);
             if (jobs_.capacity() < jobs_.size() + parts) jobs_.reserve(jobs_.size() + parts);  // before anything is published
             for (size_t off = slice; off < whole.n; off += slice) {
-                jobs_.push_back(Job{whole.dst + off * dst_unit, whole.src + off * src_unit, std::min(slice, whole.n - off),
-                                    whole.base, whole.widen, &left});
-                ++left;
+                Job j = whole;
+                j.dst = whole.dst + off * dst_unit;
+                j.n = std::min(slice, whole.n - off);
+                if (whole.kind == kPread) j.base = whole.base + off;
+                else j.src = whole.src + off * src_unit;
+                j.call = &call;
+                jobs_.push_back(j);
+                ++call.left;
             }
+            pending_.store(jobs_.size(), std::memory_order_release);
         }
-        cv_work_.notify_all();
+        if (spinners_.load(std::memory_order_acquire) == 0) cv_work_.notify_all();  // (pollers see pending_)
         Job first = whole;
         first.n = std::min(slice, whole.n);
-        execute(first);  // the calling thread takes the first slice
+        int err = 0;
+        bool ok = execute(first, &err);  // the calling thread takes the first slice
         std::unique_lock<std::mutex> g(m_);
+        if (!ok) { call.ok = false; call.err = err; }
         // ... and, rather than sleep while slices of its own call are still queued, more of them
-        while (left != 0) {
+        while (call.left != 0) {
             bool mine = false;
             Job j{};
             for (size_t q = jobs_.size(); q-- > 0;)
-                if (jobs_[q].left == &left) {
+                if (jobs_[q].call == &call) {
                     j = jobs_[q];
                     jobs_.erase(jobs_.begin() + (std::ptrdiff_t)q);
+                    pending_.store(jobs_.size(), std::memory_order_release);
                     mine = true;
                     break;
                 }
             if (!mine) {
-                cv_done_.wait(g, [&left] { return left == 0; });
+                if (spinners_.load(std::memory_order_acquire)) {  // the last slices are a few microseconds away: poll
+                    g.unlock();
+                    for (;;) {
+                        for (int i = 0; i < 64; ++i) _mm_pause();
+                        std::lock_guard<std::mutex> g2(m_);
+                        if (call.left == 0) break;
+                    }
+                    g.lock();
+                } else {
+                    cv_done_.wait(g, [&call] { return call.left == 0; });
+                }
                 break;
             }
             g.unlock();
-            execute(j);
+            ok = execute(j, &err);
             g.lock();
-            --left;
+            if (!ok) { call.ok = false; call.err = err; }
+            --call.left;
         }
+        if (!call.ok) errno = call.err;
+        return call.ok;
     }
     void shutdown() {
         {
             std::lock_guard<std::mutex> g(m_);
             stop_ = true;
+            stop_flag_.store(true, std::memory_order_release);
         }
         cv_work_.notify_all();
         for (auto& t : threads_)
@@ -225,15 +289,29 @@ private:
             Job j;
             {
                 std::unique_lock<std::mutex> g(m_);
-                cv_work_.wait(g, [this] { return stop_ || !jobs_.empty(); });
+                while (!stop_ && jobs_.empty()) {
+                    if (spinners_.load(std::memory_order_acquire)) {
+                        // an ingest call is running: poll (without the lock) until a slice shows up or the call ends
+                        g.unlock();
+                        while (spinners_.load(std::memory_order_acquire) && pending_.load(std::memory_order_acquire) == 0 &&
+                               !stop_flag_.load(std::memory_order_acquire))
+                            for (int i = 0; i < 32; ++i) _mm_pause();
+                        g.lock();
+                    } else {
+                        cv_work_.wait(g);
+                    }
+                }
                 if (jobs_.empty()) return;  // stop requested and nothing left
                 j = jobs_.front();          // oldest first: the call that has waited longest
                 jobs_.erase(jobs_.begin());
+                pending_.store(jobs_.size(), std::memory_order_release);
             }
-            execute(j);
+            int err = 0;
+            const bool ok = execute(j, &err);
             {
                 std::lock_guard<std::mutex> g(m_);
-                if (--*j.left == 0) cv_done_.notify_all();
+                if (!ok) { j.call->ok = false; j.call->err = err; }
+                if (--j.call->left == 0) cv_done_.notify_all();
             }
         }
     }
@@ -241,7 +319,62 @@ private:
     std::mutex m_;
     std::condition_variable cv_work_, cv_done_;
     std::vector<Job> jobs_;
+    std::atomic<size_t> pending_{0};     // jobs_.size(), readable without the lock (pollers)
+    std::atomic<int> spinners_{0};       // ingest calls in progress: workers poll instead of sleeping
+    std::atomic<bool> stop_flag_{false};
     bool stop_ = false;
+};
+
+// A thread a context keeps for one role of the ingest pipeline (stager, expander, tape prefaulter): started when a call
+// first needs it, then handed one task per call.  Round 4 created and joined two std::threads per call (~60-100 us, a
+// third of a 4-MiB call).
+class TaskThread {
+public:
+    TaskThread() : th_([this] { run(); }) {}
+    ~TaskThread() {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        if (th_.joinable()) th_.join();
+    }
+    TaskThread(const TaskThread&) = delete;
+    TaskThread& operator=(const TaskThread&) = delete;
+    // the task must not throw; everything it references has to stay alive until wait() has returned
+    void post(std::function<void()> f) {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            task_ = std::move(f);
+            busy_ = true;
+        }
+        cv_.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [this] { return !busy_; });
+    }
+
+private:
+    void run() {
+        std::unique_lock<std::mutex> g(m_);
+        for (;;) {
+            cv_.wait(g, [this] { return stop_ || busy_; });
+            if (!busy_) return;
+            std::function<void()> f = std::move(task_);
+            g.unlock();
+            f();
+            f = nullptr;
+            g.lock();
+            busy_ = false;
+            cv_.notify_all();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::function<void()> task_;
+    bool busy_ = false, stop_ = false;
+    std::thread th_;  // last: started when everything above exists
 };
 
 int ingest_workers() {
