@@ -566,6 +566,124 @@ def ingest_leg(pkg, device, host, width, closed_form):
                     "slot -> caller's tape (an expander thread); PCIe-inclusive, never part of `value`"}
 
 
+def file_ingest_leg(pkg, device, host, width, closed_form, buffer_ingest):
+    """csv_simd::create(filename) end to end — the reference's actual entry point (src/lib.rs:61-74: open, mmap,
+    Header::new, reader::read, TapeCore::create) — on the SAME 2 GiB the `ingest` leg reads from a buffer, written to a file
+    first (page cache hot: the link, not the disk, is what this measures), with a tape the library allocates itself.
+    csvsimd_create maps the file, reads the header, runs the ingest pipeline on the mapping (the stager's slices fault the
+    page-cache pages in, in parallel, ahead of the link) into an index block that is address space until written, and builds
+    the tape object.  Reported next to the buffer ingest of the same bytes; never part of `value`."""
+    import tempfile
+    n = host.size
+    d = os.environ.get("CSVSIMD_BENCH_TMPDIR") or tempfile.gettempdir()
+    path = os.path.join(d, f"csvsimd_bench_{os.getpid()}.csv")
+    t0 = time.perf_counter()
+    with open(path, "wb") as f:
+        f.write(host.data)
+    write_s = time.perf_counter() - t0
+    out = {"bytes": n, "file": path, "write_s": round(write_s, 2)}
+    try:
+        ctx = pkg.Context(device.index)
+        t0 = time.perf_counter()
+        tp = ctx.create(path)                       # a fresh context: pipeline slots are pinned here
+        first_ms = (time.perf_counter() - t0) * 1e3
+        pitch = width + 1
+        ok = True
+        if closed_form:
+            idx = tp.index_view()
+            ok = bool(idx.size == n // pitch + 1 and idx[0] == 0 and
+                      np.array_equal(idx[1:], np.arange(n // pitch, dtype=np.uint64) * pitch + width))
+            del idx
+        fields, records = tp.field_cnt, tp.record_cnt
+        tp.close()
+        best, phases, destroy_ms = None, None, None
+        for _ in range(4):
+            t0 = time.perf_counter()
+            tp = ctx.create(path)
+            dt = time.perf_counter() - t0
+            ph = pkg.ingest_last_phases()
+            ok = ok and tp.record_cnt == records
+            t1 = time.perf_counter()
+            tp.close()
+            dd = (time.perf_counter() - t1) * 1e3
+            if best is None or dt < best:
+                best, phases, destroy_ms = dt, ph, dd
+        ctx.close()
+        gib = n / best / 2**30
+        out.update({"value": round(gib, 2), "unit": "GiB/s", "ms": round(best * 1e3, 2), "verified": bool(ok),
+                    "first_call_ms_fresh_context": round(first_ms, 1), "tape_destroy_ms": round(destroy_ms, 1),
+                    "fields": fields, "records": records,
+                    "buffer_ingest_GiB_s": buffer_ingest["value"],
+                    "frac_of_buffer_ingest": round(gib / buffer_ingest["value"], 3),
+                    "frac_of_h2d_probe": round(gib / buffer_ingest["h2d_probe_GiB_s"], 3),
+                    "phases_ms_of_the_best_call": {k: (round(v * 1e3, 3) if isinstance(v, float) else v) for k, v in phases.items()},
+                    "note": "csvsimd_create(path): open + mmap + Header::new + the ingest pipeline on the mapping + a tape whose "
+                            "index the library allocates (address space until written) + Tape::from_core; best of 4 on a kept "
+                            "context, the file's pages in the page cache, every call with a NEW index block"})
+    finally:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+    return out
+
+
+def small_files_leg(pkg, oracle, device, n_files=10_000):
+    """Many small HOST files in one call (csvsimd_stage1_index_batch): 10 000 files of ~4 KiB of the quoted 16x32 corpus
+    (whole rows), host bytes in, host tapes out, next to (a) the same files through csvsimd_stage1_index one by one on a kept
+    context and (b) ref_sse_1t over the same files on one host core (the reference's way: csv_simd::create per file,
+    src/lib.rs:61-74; a Vec grown from [0] per file).  Every tape is checked against the oracle."""
+    cols, width, seed, q = pkg.WORKLOADS["16x32_q10"]
+    row = cols * (width + 1)
+    per = (4096 // row) * row
+    whole = oracle.synth(0, per * n_files, cols, width, seed, q)
+    files = [whole[i * per: (i + 1) * per] for i in range(n_files)]
+    total = per * n_files
+    tapes = [np.empty(per // 8 + 64, dtype=np.uint64) for _ in files]
+    items = (pkg.HostBatchItem * n_files)()
+    for it, a, t in zip(items, files, tapes):
+        it.buf, it.len, it.tape, it.tape_cap = a.ctypes.data, a.size, t.ctypes.data, t.size
+    ctx = pkg.Context(device.index)
+    rc = ctx.read_many_into(items)                  # allocates the pipeline
+    ok = rc == 0
+    ts = []
+    for _ in range(10):
+        t0 = time.perf_counter()
+        rc = ctx.read_many_into(items)
+        ts.append(time.perf_counter() - t0)
+        ok = ok and rc == 0
+    counts, _ = oracle.sse_read_growing_many_timed(files)
+    cpu = min(oracle.sse_read_growing_many_timed(files)[1] for _ in range(5))
+    for i in range(n_files):
+        ok = ok and items[i].status == 0 and items[i].tape_len == counts[i]
+    for i in list(range(0, n_files, 97)) + [n_files - 1]:
+        ok = ok and bool(np.array_equal(tapes[i][: items[i].tape_len], oracle.sse_read(files[i])))
+    # one by one through the single-file entry point (a sample: 1 000 files)
+    k = min(1000, n_files)
+    t0 = time.perf_counter()
+    for i in range(k):
+        ctx.read_into(files[i], tapes[i])
+    one_by_one = (time.perf_counter() - t0) / k
+    ctx.close()
+    best = min(ts)
+    gib = total / best / 2**30
+    cpu_gib = total / cpu / 2**30
+    return {"files": n_files, "bytes_per_file": per, "bytes": total, "ms": round(best * 1e3, 3),
+            "ms_median": round(sorted(ts)[len(ts) // 2] * 1e3, 3), "GiB/s": round(gib, 2),
+            "us_per_file": round(best / n_files * 1e6, 3),
+            "cpu_ref_sse_1t": {"GiB/s": round(cpu_gib, 2), "ms": round(cpu * 1e3, 3), "us_per_file": round(cpu / n_files * 1e6, 3),
+                               "cores": 1, "kind": "port",
+                               "variant": "oracle_sse_read_growing_many: the SSE restatement of reader::read per file, a Vec "
+                                          "grown from [0] per file, one thread"},
+            "gpu_over_cpu": round(gib / cpu_gib, 2),
+            "one_call_per_file_us": round(one_by_one * 1e6, 1),
+            "batch_over_one_call_per_file": round(one_by_one * n_files / best, 1),
+            "verified": bool(ok),
+            "note": "csvsimd_stage1_index_batch: files packed into pinned groups (256 KiB ... 4 MiB), one H2D copy and ONE "
+                    "batched launch per group, tapes and records written to pinned memory by the kernel, three host "
+                    "threads; wall time of the call, host bytes in, host tapes out"}
+
+
 def latency_leg(pkg, oracle, device):
     """The drop-in on SMALL inputs (the reference's only real inputs are 96-623 bytes: res/*.csv, src/lib.rs:52-74):
     end-to-end wall time of csvsimd_stage1_index — host bytes in, host tape out — with ONE context kept across calls
@@ -1035,6 +1153,7 @@ def main():
                          "from C++) instead of torch.distributed.all_gather_into_tensor")
     ap.add_argument("--only-batch", action="store_true", help="development: run the `batch_many_files` leg alone")
     ap.add_argument("--only-latency", action="store_true", help="development: run the `latency` leg alone")
+    ap.add_argument("--only-small-files", action="store_true", help="development: run the `small_files` leg alone")
     ap.add_argument("--only-consumers", action="store_true",
                     help="development / profiling: run the `consumers` leg alone and print its record (not the "
                          "contract line)")
@@ -1100,6 +1219,9 @@ def main():
         return
     if args.only_latency:
         print(json.dumps({"latency": latency_leg(pkg, oracle or graft.load_oracle(), device)}))
+        return
+    if args.only_small_files:
+        print(json.dumps({"small_files": small_files_leg(pkg, oracle or graft.load_oracle(), device)}))
         return
 
     strong = args.scaling == "strong"
@@ -1289,6 +1411,11 @@ def main():
             failed = failed or not out["latency"]["verified"]
             out["ingest"] = ingest_leg(pkg, device, sample, main_width, closed_form=(not main_q and main_lo == 0))
             failed = failed or not out["ingest"]["verified"]
+            out["file_ingest"] = file_ingest_leg(pkg, device, sample, main_width, closed_form=(not main_q and main_lo == 0),
+                                                 buffer_ingest=out["ingest"])
+            failed = failed or not out["file_ingest"]["verified"]
+            out["small_files"] = small_files_leg(pkg, oracle, device)
+            failed = failed or not out["small_files"]["verified"]
     # ---- the CPU beside it, same bytes, same run, at EVERY N (rank 0's host cores) -------------------------------
     if rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(oracle, sample)

@@ -98,6 +98,12 @@ class BatchItem(C.Structure):
                 ("tape_cap", C.c_uint64), ("in_quote_in", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+class HostBatchItem(C.Structure):
+    """csvsimd_host_batch_item: one host file of csvsimd_stage1_index_batch."""
+    _fields_ = [("buf", C.c_void_p), ("len", C.c_uint64), ("tape", C.c_void_p), ("tape_cap", C.c_uint64),
+                ("tape_len", C.c_uint64), ("in_quote_out", C.c_uint32), ("status", C.c_int32)]
+
+
 class MultiShard(C.Structure):
     """csvsimd_multi_shard: one shard of csvsimd_stage1_index_multi (in: ctx, dbuf, dtape, tape_cap; out: the rest)."""
     _fields_ = [("ctx", C.c_void_p), ("dbuf", C.c_void_p), ("dtape", C.c_void_p), ("tape_cap", C.c_uint64),
@@ -134,7 +140,7 @@ class IngestPhases(C.Structure):
 
 
 SEARCH_EQUALS, SEARCH_STARTS_WITH, SEARCH_CONTAINS = 0, 1, 2
-ABI_VERSION = 4   # what this binding was written against: checked when the library is loaded
+ABI_VERSION = 5   # what this binding was written against: checked when the library is loaded
 
 # every symbol include/csvsimd.h declares: (restype, argtypes)
 _u64p = C.POINTER(C.c_uint64)
@@ -169,10 +175,12 @@ _PROTOTYPES = {
     "csvsimd_tape_record_spans_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint64,
                                                    C.c_uint64, C.c_void_p, C.c_void_p, _u64p, C.c_void_p]),
     "csvsimd_ctx_hint_density": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64]),
+    "csvsimd_ctx_limit_workgroups": (C.c_int, [C.c_void_p, C.c_uint32]),
     "csvsimd_ctx_kernel_name": (C.c_char_p, [C.c_void_p, C.POINTER(Dialect)]),
     "csvsimd_stage1_bound": (C.c_int, [C.c_uint64, _u64p]),
     "csvsimd_stage1_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, _u64p,
                                        C.POINTER(C.c_uint32)]),
+    "csvsimd_stage1_index_batch": (C.c_int, [C.c_void_p, C.POINTER(HostBatchItem), C.c_uint32]),
     "csvsimd_ingest_chunk_plan": (C.c_int, [C.c_uint64, _u64p, C.c_uint64, _u64p]),
     "csvsimd_ingest_last_phases": (C.c_int, [C.POINTER(IngestPhases)]),
     "csvsimd_stage1_index_batch_device_async": (C.c_int, [C.c_void_p, C.POINTER(BatchItem), C.c_uint32, C.c_void_p,
@@ -296,6 +304,10 @@ class Context:
         """Entries per byte of the data about to be indexed (nbytes 0: forget): chooses the kernel instantiation of the
         following launches (same tape either way)."""
         _check(lib().csvsimd_ctx_hint_density(self._h, entries, nbytes))
+
+    def limit_workgroups(self, n: int) -> None:
+        """Test knob: at most n workgroups per stage-1 launch of this context (0: the default grid)."""
+        _check(lib().csvsimd_ctx_limit_workgroups(self._h, n))
 
     def kernel_name(self, dialect: "Dialect" = None) -> str:
         return lib().csvsimd_ctx_kernel_name(self._h, C.byref(dialect) if dialect is not None else None).decode()
@@ -427,6 +439,30 @@ class Context:
                                         tape.ctypes.data if has_tape else None,
                                         tape.size if has_tape else 0, C.byref(n), C.byref(q))
         return rc, n.value, q.value
+
+    def read_many_into(self, items) -> int:
+        """Raw csvsimd_stage1_index_batch on a prepared (HostBatchItem * n) array: returns rc; outputs are in the items."""
+        return lib().csvsimd_stage1_index_batch(self._h, items, len(items))
+
+    def read_many(self, datas, caps=None):
+        """reader::read for MANY host buffers in one call (csvsimd_stage1_index_batch): -> list of StructureIndex arrays
+        (uint64, sentinel first), one per buffer.  caps: tape capacity per buffer (default: one that always fits)."""
+        arrs = [d if isinstance(d, np.ndarray) else np.frombuffer(bytes(d), dtype=np.uint8) for d in datas]
+        arrs = [np.ascontiguousarray(a) for a in arrs]
+        tapes = [np.empty((a.size + 1) if caps is None else caps[i], dtype=np.uint64) for i, a in enumerate(arrs)]
+        items = (HostBatchItem * len(arrs))()
+        for it, a, t in zip(items, arrs, tapes):
+            it.buf, it.len, it.tape, it.tape_cap = (a.ctypes.data if a.size else None), a.size, (t.ctypes.data if t.size else None), t.size
+        rc = self.read_many_into(items)
+        if rc != OK and rc != ERR_TAPE_CAPACITY:
+            _check(rc)
+        out = []
+        for it, t in zip(items, tapes):
+            if it.status != OK and not (caps is not None and it.status == ERR_TAPE_CAPACITY):
+                _check(it.status)
+            out.append(t[: min(it.tape_len, t.size)].copy())
+        self.last_batch = [(it.tape_len, it.in_quote_out, it.status) for it in items]
+        return out
 
     # ---- csv_simd::create(filename) -> Tape (src/lib.rs:61-74) ---------------------------------
     def create(self, filename: str) -> "Tape":
@@ -596,6 +632,12 @@ class Tape:
         n = C.c_uint64()
         p = lib().csvsimd_tape_index(self._h, C.byref(n))
         return np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+
+    def index_view(self) -> np.ndarray:
+        """The tape's own index, not copied: valid until close()."""
+        n = C.c_uint64()
+        p = lib().csvsimd_tape_index(self._h, C.byref(n))
+        return np.ctypeslib.as_array(p, shape=(n.value,))
 
     def bytes(self) -> bytes:
         if getattr(self, "_bytes", None) is None:  # one copy, cached: seek_* slice it

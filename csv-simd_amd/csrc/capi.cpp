@@ -149,16 +149,16 @@ public:
     // synchronous: returns when all n bytes are in place.  min_slice: the smallest piece worth handing to another thread
     // (a large chunk of a long file: 2 MiB; a file of a few MiB, where the copy IS the call's critical path: 256 KiB)
     void copy(void* dst, const void* src, size_t n, size_t min_slice = kMinSlice) {
-        run_sliced(Job{(char*)dst, (const char*)src, n, 0, kCopy, -1, nullptr}, 1, min_slice);
+        run_sliced(Job{(char*)dst, (const char*)src, n, 0, kCopy, nullptr}, 1, min_slice);
     }
     // synchronous: dst[i] = base + src[i] for i < n
     void expand(uint64_t* dst, const uint32_t* src, size_t n, uint64_t base, size_t min_slice = kMinSlice) {
-        run_sliced(Job{(char*)dst, (const char*)src, n, base, kWiden, -1, nullptr}, 4, min_slice);
+        run_sliced(Job{(char*)dst, (const char*)src, n, base, kWiden, nullptr}, 4, min_slice);
     }
-    // synchronous: n bytes of the file at offset off -> dst (pread by slices: the kernel copies page-cache pages straight into
-    // the pinned slot, no mapping of the file is touched).  false: a read failed or the file ended early (errno kept).
-    bool read_file(void* dst, int fd, uint64_t off, size_t n, size_t min_slice = kMinSlice) {
-        return run_sliced(Job{(char*)dst, nullptr, n, off, kPread, fd, nullptr}, 1, min_slice);
+    // synchronous: f(begin, end) over [0, n) in pieces of at least min_items (the host-pointer batch packs and unpacks
+    // thousands of small files per group: one memcpy each, spread over the pool)
+    void parallel_for(size_t n, size_t min_items, const std::function<void(size_t, size_t)>& f) {
+        run_sliced(Job{nullptr, reinterpret_cast<const char*>(&f), n, 0, kFunc, nullptr}, 1, std::max<size_t>(min_items, 1));
     }
     // From here to the matching quiet(): idle workers poll for slices instead of sleeping on the condition variable — a
     // sleeping worker takes 20-60 us to start on a slice (futex wake + a core leaving its idle state), which is the whole
@@ -175,56 +175,44 @@ public:
     static constexpr size_t kMinSlice = 2u << 20;  // source bytes (512 KiB slices of a 4-MiB chunk of a LONG file: measured, no gain)
 
 private:
-    enum Kind : int { kCopy, kWiden, kPread };
+    enum Kind : int { kCopy, kWiden, kFunc };
     struct Call {   // lives on the issuing call's frame until every slice has been executed
         size_t left = 0;  // slices still out (guarded by m_)
-        bool ok = true;   // (guarded by m_)
-        int err = 0;
     };
     struct Job {
         char* dst;
         const char* src;
-        size_t n;  // bytes (copy, pread) or entries (expand)
-        uint64_t base;  // expand: added to every offset; pread: file offset
+        size_t n;  // bytes (copy) or entries (expand)
+        uint64_t base;  // expand: added to every offset
         Kind kind;
-        int fd;
         Call* call;
     };
-    static bool execute(const Job& j, int* err) {
-        switch (j.kind) {
-            case kWiden: expand_streaming((uint64_t*)j.dst, (const uint32_t*)j.src, j.n, j.base); return true;
-            case kCopy: copy_streaming(j.dst, j.src, j.n); return true;
-            case kPread:
-                for (size_t done = 0; done < j.n;) {
-                    const ssize_t r = pread(j.fd, j.dst + done, j.n - done, (off_t)(j.base + done));
-                    if (r < 0 && errno == EINTR) continue;
-                    if (r <= 0) { *err = r < 0 ? errno : EIO; return false; }  // r == 0: the file got shorter under us
-                    done += (size_t)r;
-                }
-                return true;
-        }
-        return true;
+    static void execute(const Job& j) {
+        if (j.kind == kWiden) expand_streaming((uint64_t*)j.dst, (const uint32_t*)j.src, j.n, j.base);
+        else if (j.kind == kFunc) (*reinterpret_cast<const std::function<void(size_t, size_t)>*>(j.src))((size_t)j.base, (size_t)j.base + j.n);
+        else copy_streaming(j.dst, j.src, j.n);
     }
     // unit = source bytes per item of n
-    bool run_sliced(Job whole, size_t unit, size_t min_slice) {
+    void run_sliced(Job whole, size_t unit, size_t min_slice) {
         const size_t bytes = whole.n * unit;
-        const size_t parts = std::min<size_t>(threads_.size() + 1, std::max<size_t>(1, bytes / std::max<size_t>(min_slice, 4096)));
+        const size_t floor_ = whole.kind == kFunc ? std::max<size_t>(min_slice, 1) : std::max<size_t>(min_slice, 4096);
+        const size_t parts = std::min<size_t>(threads_.size() + 1, std::max<size_t>(1, bytes / floor_));
         Call call;
         if (parts <= 1) {
-            const bool ok = execute(whole, &call.err);
-            if (!ok) errno = call.err;
-            return ok;
+            execute(whole);
+            return;
         }
-        const size_t slice = (((whole.n / parts) + 4095) & ~(size_t)4095);  // items; a multiple of 4096 keeps every slice aligned
+        const size_t slice = whole.kind == kFunc ? (whole.n + parts - 1) / parts
+                                                 : (((whole.n / parts) + 4095) & ~(size_t)4095);  // items; a multiple of 4096 keeps every slice aligned
         const size_t dst_unit = whole.kind == kWiden ? 8 : 1, src_unit = whole.kind == kWiden ? 4 : 1;
         {
             std::lock_guard<std::mutex> g(m_);
             if (jobs_.capacity() < jobs_.size() + parts) jobs_.reserve(jobs_.size() + parts);  // before anything is published
             for (size_t off = slice; off < whole.n; off += slice) {
                 Job j = whole;
-                j.dst = whole.dst + off * dst_unit;
+                if (whole.kind != kFunc) j.dst = whole.dst + off * dst_unit;
                 j.n = std::min(slice, whole.n - off);
-                if (whole.kind == kPread) j.base = whole.base + off;
+                if (whole.kind == kFunc) j.base = off;
                 else j.src = whole.src + off * src_unit;
                 j.call = &call;
                 jobs_.push_back(j);
@@ -235,10 +223,8 @@ private:
         if (spinners_.load(std::memory_order_acquire) == 0) cv_work_.notify_all();  // (pollers see pending_)
         Job first = whole;
         first.n = std::min(slice, whole.n);
-        int err = 0;
-        bool ok = execute(first, &err);  // the calling thread takes the first slice
+        execute(first);  // the calling thread takes the first slice
         std::unique_lock<std::mutex> g(m_);
-        if (!ok) { call.ok = false; call.err = err; }
         // ... and, rather than sleep while slices of its own call are still queued, more of them
         while (call.left != 0) {
             bool mine = false;
@@ -266,13 +252,10 @@ private:
                 break;
             }
             g.unlock();
-            ok = execute(j, &err);
+            execute(j);
             g.lock();
-            if (!ok) { call.ok = false; call.err = err; }
             --call.left;
         }
-        if (!call.ok) errno = call.err;
-        return call.ok;
     }
     void shutdown() {
         {
@@ -306,11 +289,9 @@ private:
                 jobs_.erase(jobs_.begin());
                 pending_.store(jobs_.size(), std::memory_order_release);
             }
-            int err = 0;
-            const bool ok = execute(j, &err);
+            execute(j);
             {
                 std::lock_guard<std::mutex> g(m_);
-                if (!ok) { j.call->ok = false; j.call->err = err; }
                 if (--j.call->left == 0) cv_done_.notify_all();
             }
         }
@@ -428,8 +409,21 @@ struct csvsimd_ctx {
     uint64_t pin_out_entries[kSlots] = {};
     uint64_t slot_bytes[kSlots] = {};          // size of pin_in[k] / d_in[k]
     csvsimd_shard_result* d_res[kSlots] = {};
-    csvsimd_shard_result* h_res = nullptr;     // pinned, kSlots records
-    hipEvent_t ev_rec[kSlots] = {};            // result record of the slot's chunk has landed in h_res[k] (and its tape in pin_out[k])
+    // how a chunk's record reaches the host (round 5): the kernel that packs the chunk's tape into the pinned slot also
+    // copies the record into pinned memory and then writes the chunk's sequence number next to it; the submitter polls
+    // that word (a copy-out + event cost ~25 us of latency per chunk, the whole budget of a 1-MiB chunk)
+    struct alignas(128) HostRecord {
+        csvsimd_shard_result rec;
+        volatile uint64_t seq;
+    };
+    HostRecord* h_res = nullptr;               // pinned, kSlots records
+    uint32_t* d_pub = nullptr;                 // kSlots arrival counters of the publishing kernel (wrap to 0 by themselves)
+    uint64_t pub_seq = 0;                      // last sequence number handed to a chunk
+    std::unique_ptr<TaskThread> stager_thread, expander_thread;  // started by the first call that pipelines, kept
+    // csvsimd_stage1_index_batch (many small host files in one call): a group's tapes and result records come back through
+    // this pinned block, written by the batched launch itself
+    void* pin_bout[kSlots] = {};
+    size_t pin_bout_bytes[kSlots] = {};
     // small files (<= kSmallBytes) through the host-buffer entry point: ONE launch that reads the bytes from a pinned block
     // and writes tape and record into another, both mapped into the GPU's address space — no copy engine, no second stream
     static constexpr uint64_t kSmallBytes = 1ull << 20;
@@ -475,7 +469,7 @@ int csvsimd_device_count(void) {
     return n;
 }
 
-uint32_t csvsimd_abi_version(void) { return 4; }
+uint32_t csvsimd_abi_version(void) { return 5; }
 uint32_t csvsimd_tile_bytes(void) { return CSVSIMD_TILE_BYTES; }
 
 int csvsimd_ctx_create(int device, csvsimd_ctx** out) {
@@ -527,17 +521,18 @@ void csvsimd_ctx_destroy(csvsimd_ctx* ctx) {
     for (int k = 0; k < csvsimd_ctx::kSlots; ++k) {
         if (ctx->pin_in[k]) (void)hipHostFree(ctx->pin_in[k]);
         if (ctx->pin_out[k]) (void)hipHostFree(ctx->pin_out[k]);
+        if (ctx->pin_bout[k]) (void)hipHostFree(ctx->pin_bout[k]);
         if (ctx->d_in[k]) (void)hipFree(ctx->d_in[k]);
         if (ctx->d_tape[k]) (void)hipFree(ctx->d_tape[k]);
         if (ctx->d_res[k]) (void)hipFree(ctx->d_res[k]);
         if (ctx->ev_in[k]) (void)hipEventDestroy(ctx->ev_in[k]);
-        if (ctx->ev_rec[k]) (void)hipEventDestroy(ctx->ev_rec[k]);
     }
     if (ctx->pin_small_in) (void)hipHostFree(ctx->pin_small_in);
     if (ctx->pin_small_out) (void)hipHostFree(ctx->pin_small_out);
     if (ctx->in_stream) (void)hipStreamDestroy(ctx->in_stream);
     if (ctx->in_stream2) (void)hipStreamDestroy(ctx->in_stream2);
     if (ctx->h_res) (void)hipHostFree(ctx->h_res);
+    if (ctx->d_pub) (void)hipFree(ctx->d_pub);
     if (ctx->pipe_stream) (void)hipStreamDestroy(ctx->pipe_stream);
     delete ctx;
 }
@@ -622,7 +617,9 @@ static int stage1_async_impl(csvsimd_ctx* ctx, const csvsimd_dialect* dialect, c
     L.max_blocks = ctx->max_blocks;
     L.d_state = d_state;
     L.d_chain = d_chain;
-    L.dense = !dialect && dtape && ctx->density > csvsimd_ctx::kDenseThreshold;
+    // (the dense instantiation exists for emitting launches without an escape byte: the reference dialect, another
+    // delimiter / quote byte)
+    L.dense = (!dialect || !dialect->escape) && dtape && ctx->density > csvsimd_ctx::kDenseThreshold;
     if (dialect) {
         L.delimiter = dialect->delimiter;
         L.quote = dialect->quote;
@@ -672,6 +669,9 @@ int csvsimd_stage1_index_batch_device_async(csvsimd_ctx* ctx, const csvsimd_batc
     std::vector<unsigned char> host(block, 0);
     csvsimd::BatchItemHost* const table = reinterpret_cast<csvsimd::BatchItemHost*>(host.data());
     uint32_t* const firsts = reinterpret_cast<uint32_t*>(host.data() + off_first);
+    // delimiter-dense data (as far as this context knows): the batch runs the dense instantiation, whose tiles are 64 KiB
+    const bool dense = ctx->density > csvsimd_ctx::kDenseThreshold;
+    const uint64_t tile_bytes = dense ? CSVSIMD_MIN_TILE_BYTES : CSVSIMD_TILE_BYTES;
     uint64_t tiles = 0;
     for (uint32_t i = 0; i < n_items; ++i) {
         const csvsimd_batch_item& it = items[i];
@@ -689,12 +689,12 @@ int csvsimd_stage1_index_batch_device_async(csvsimd_ctx* ctx, const csvsimd_batc
         t.first_tile = firsts[i] = (uint32_t)tiles;
         t.in_quote_in = it.in_quote_in;
         t.reserved = 0;
-        tiles += it.len ? (t.hi + CSVSIMD_TILE_BYTES - 1) / CSVSIMD_TILE_BYTES : 0;
+        tiles += it.len ? (t.hi + tile_bytes - 1) / tile_bytes : 0;
         if (tiles >= (1ull << 31)) return CSVSIMD_ERR_INVALID_ARG;
     }
     WITH_DEVICE_OF(ctx);
     // scratch: one descriptor word per tile of the whole batch (allocates + synchronises only when it has to grow)
-    int rc = csvsimd_ctx_reserve(ctx, tiles * CSVSIMD_TILE_BYTES);
+    int rc = csvsimd_ctx_reserve(ctx, tiles * tile_bytes);
     if (rc != CSVSIMD_OK) return rc;
     if (ctx->d_batch_bytes < block) {
         if (ctx->launched) HIP_TRY(hipDeviceSynchronize());  // an earlier batch may still be reading the old table
@@ -714,9 +714,9 @@ int csvsimd_stage1_index_batch_device_async(csvsimd_ctx* ctx, const csvsimd_batc
     L.bind_scratch(ctx->scratch);
     ctx->last_stream = s;
     ctx->launched = true;
-    HIP_TRY(csvsimd::launch_stage1_batch(ctx->d_batch, (char*)ctx->d_batch + off_first, (char*)ctx->d_batch + off_tot, n_items,
-                                         (uint32_t)tiles, (csvsimd_shard_result*)d_results, ctx->scratch, L.scratch_desc,
-                                         ctx->max_blocks, s));
+    HIP_TRY((dense ? csvsimd_dense::launch_stage1_batch_dense : csvsimd::launch_stage1_batch)(
+        ctx->d_batch, (char*)ctx->d_batch + off_first, (char*)ctx->d_batch + off_tot, n_items, (uint32_t)tiles,
+        (csvsimd_shard_result*)d_results, ctx->scratch, L.scratch_desc, ctx->max_blocks, s));
     return CSVSIMD_OK;
     });
 }
@@ -764,10 +764,19 @@ int csvsimd_ctx_hint_density(csvsimd_ctx* ctx, uint64_t entries, uint64_t bytes)
     return CSVSIMD_OK;
 }
 
+int csvsimd_ctx_limit_workgroups(csvsimd_ctx* ctx, uint32_t n) {
+    if (!ctx) return CSVSIMD_ERR_INVALID_ARG;
+    const uint32_t full = (uint32_t)ctx->n_cus * (uint32_t)csvsimd::stage1_max_blocks_per_cu();
+    ctx->max_blocks = n ? std::min(n, full) : full;
+    return CSVSIMD_OK;
+}
+
 const char* csvsimd_ctx_kernel_name(const csvsimd_ctx* ctx, const csvsimd_dialect* dialect) {
     if (!ctx) return "";
+    const bool dense = ctx->density > csvsimd_ctx::kDenseThreshold;
     if (!dialect || (dialect->delimiter == ',' && dialect->quote == '"' && !dialect->escape))
-        return csvsimd::stage1_kernel_name(true, 0, !dialect && ctx->density > csvsimd_ctx::kDenseThreshold);
+        return csvsimd::stage1_kernel_name(true, 0, dense);
+    if (!dialect->escape && dense) return csvsimd::stage1_kernel_name(true, 1, true);
     return csvsimd_stage1_kernel_name(1, dialect);
 }
 
@@ -784,15 +793,21 @@ int csvsimd_stage1_bound(uint64_t len, uint64_t* max_entries) {
 // PCIe bound by construction; the HBM-resident entry points are the timed ones.  Slots are allocated when first needed.
 static int pipe_setup(csvsimd_ctx* ctx, int slots = 2, uint64_t slot_bytes = csvsimd_ctx::kChunk) {
     // everything is created when it is first needed and kept: a previous attempt may have failed half way (out of
-    // memory), a small file needs one small slot, a large one all four at full size
+    // memory), a small file needs small slots, a large one all four at full size
     slots = std::min(std::max(slots, 1), csvsimd_ctx::kSlots);
     slot_bytes = std::min<uint64_t>(std::max<uint64_t>(slot_bytes, 1u << 16), csvsimd_ctx::kChunk);
     if (!ctx->copier) ctx->copier.reset(new CopyPool(ingest_workers()));
     if (!ctx->pipe_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->pipe_stream, hipStreamNonBlocking));
     if (!ctx->in_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->in_stream, hipStreamNonBlocking));
     if (!ctx->in_stream2) HIP_TRY(hipStreamCreateWithFlags(&ctx->in_stream2, hipStreamNonBlocking));
-    if (!ctx->h_res)
-        HIP_TRY(hipHostMalloc((void**)&ctx->h_res, csvsimd_ctx::kSlots * sizeof(csvsimd_shard_result), hipHostMallocDefault));
+    if (!ctx->h_res) {
+        HIP_TRY(hipHostMalloc((void**)&ctx->h_res, csvsimd_ctx::kSlots * sizeof(csvsimd_ctx::HostRecord), hipHostMallocDefault));
+        memset((void*)ctx->h_res, 0, csvsimd_ctx::kSlots * sizeof(csvsimd_ctx::HostRecord));
+    }
+    if (!ctx->d_pub) {
+        HIP_TRY(hipMalloc((void**)&ctx->d_pub, csvsimd_ctx::kSlots * 64));  // one counter per slot, a line apart
+        HIP_TRY(hipMemset(ctx->d_pub, 0, csvsimd_ctx::kSlots * 64));
+    }
     for (int k = 0; k < slots; ++k) {
         if (ctx->slot_bytes[k] < slot_bytes) {
             // (nothing of an earlier call is in flight: every host entry point drains its streams before it returns)
@@ -801,16 +816,15 @@ static int pipe_setup(csvsimd_ctx* ctx, int slots = 2, uint64_t slot_bytes = csv
             if (ctx->d_in[k]) HIP_TRY(hipFree(ctx->d_in[k]));
             ctx->d_in[k] = nullptr;
             ctx->slot_bytes[k] = 0;
-            // small slots grow geometrically: a caller that reads files of growing sizes does not re-pin for each
-            const uint64_t want = slot_bytes >= csvsimd_ctx::kChunk / 2 ? csvsimd_ctx::kChunk
-                                                                        : std::max<uint64_t>(slot_bytes, 1u << 20);
+            // three size classes — 2, 8, 32 MiB — so that a caller whose files grow re-pins a slot twice at most (pinning
+            // costs ~1 ms per 4 MiB; round 4 re-pinned for every new maximum)
+            const uint64_t want = slot_bytes <= (2u << 20) ? (2u << 20) : slot_bytes <= (8u << 20) ? (8u << 20) : csvsimd_ctx::kChunk;
             HIP_TRY(hipHostMalloc(&ctx->pin_in[k], want, hipHostMallocDefault));
             HIP_TRY(hipMalloc(&ctx->d_in[k], want));
             ctx->slot_bytes[k] = want;
         }
         if (!ctx->d_res[k]) HIP_TRY(hipMalloc((void**)&ctx->d_res[k], sizeof(csvsimd_shard_result)));
         if (!ctx->ev_in[k]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_in[k], hipEventDisableTiming));
-        if (!ctx->ev_rec[k]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_rec[k], hipEventDisableTiming));
     }
     return CSVSIMD_OK;
 }
@@ -856,44 +870,53 @@ static int stage1_index_host_impl(csvsimd_ctx* ctx, const csvsimd_dialect* diale
     return rc;
 }
 
-// The chunk plan of the ingest pipeline: chunk i = [cuts[i], cuts[i + 1]).  The slots hold up to 32 MiB.  A large file ramps
-// up (4, 8, 16 MiB, then 32) and down (..., 16, 8): the pipeline's fill — staging + H2D of the first chunk, during which
-// nothing else runs — and its drain — kernel, D2H and unload of the last chunk's tape — then cost a 4- / 8-MiB chunk's
-// time instead of a 32-MiB chunk's (~0.8 + 0.3 ms of a 40 ms call on 2 GiB).  A mid-size file is cut into ~4 chunks
-// (>= 4 MiB, a multiple of 1 MiB) so that staging, H2D, kernel and D2H of neighbouring chunks overlap inside it as well.
-// Every chunk costs ~100 us of host-side launches and waits, so smaller is not better: measured (scripts/probe_latency.py)
-// 32 MiB file 25 -> 32 GiB/s with 8-MiB chunks, but a 256 MiB file 45 -> 22 GiB/s with 4-MiB chunks.  For the same
-// reason no chunk of the ramp is shorter than 4 MiB: a remainder that would be is folded into its neighbours.
+// The chunk plan of the ingest pipeline: chunk i = [cuts[i], cuts[i + 1]).  The slots hold up to 32 MiB.  A call's wall time
+// is   staging of the FIRST chunk  +  the H2D copies of all chunks (the link: 53 GiB/s, ~8 us between copies)  +  kernel,
+// way back and expansion of the LAST chunk — so the plan starts small, doubles up to full slots, and halves down again at
+// the end:  len / 32 (256 KiB ... 4 MiB)  x2 x2 ...  32 MiB ... 32 MiB  ... x1/2 x1/2  len / 16 (512 KiB ... 8 MiB).
+// 2 GiB: 4, 8, 16, 32 x 62, 16, 8 MiB.  32 MiB: 1, 2, 4, 8, 7, 4, 4, 2.  4 MiB: 256, 512 KiB, 1 MiB, 768 KiB, 1 MiB, 512 KiB.
+// Round 4 cut a file below 128 MiB into four equal chunks of >= 4 MiB (a 32-MiB file waited 120 us for the staging of its
+// first 8 MiB and 100 us for the way back of its last 8 MiB: 1.03 ms against 0.59 ms of link time) because a chunk cost the
+// submitter ~100 us then; with the record published by the packing kernel and polled it is ~20 us (five calls).
+// No stub: a remainder shorter than a quarter of the chunk before it is folded into that chunk.
 static std::vector<uint64_t> ingest_chunk_plan(uint64_t len, uint64_t uniform_override) {
-    constexpr uint64_t kMiB = 1ull << 20, kMax = csvsimd_ctx::kChunk, kMin = 4 * kMiB;
+    constexpr uint64_t kKiB = 1ull << 10, kMiB = 1ull << 20, kMax = csvsimd_ctx::kChunk;
     std::vector<uint64_t> cuts;
     cuts.push_back(0);
-    uint64_t uniform = uniform_override;
-    if (!uniform && len < 4 * kMax) {
-        // a mid-size file: ~4 chunks of >= 4 MiB.  (Measured in round 4 with ~8 chunks of >= 1 MiB instead: no gain at any
-        // size from 2 to 128 MiB — below ~16 MiB a call is a chain of four or five steps of 40-80 us each whatever the cut,
-        // and a chunk under 2 MiB is staged by one thread at ~12 GB/s.)
-        const uint64_t target = ((len / 4 + kMiB - 1) >> 20) << 20;
-        uniform = std::min<uint64_t>(kMax, std::max<uint64_t>(kMin, target));
-    }
-    for (uint64_t off = 0, i = 0; off < len; ++i) {
-        const uint64_t rem = len - off;
-        uint64_t sz;
-        if (uniform) {
-            sz = std::min(uniform, rem);
-            const uint64_t least = std::min(kMin, uniform);
+    if (len == 0) return cuts;
+    if (uniform_override) {
+        const uint64_t uniform = uniform_override, least = std::min<uint64_t>(4 * kMiB, uniform);
+        for (uint64_t off = 0; off < len;) {
+            const uint64_t rem = len - off;
+            uint64_t sz = std::min(uniform, rem);
             if (rem > sz && rem - sz < least)  // a stub would be left over: one chunk if the slot holds it, else two halves
                 sz = rem <= kMax ? rem : (((rem / 2) + kMiB - 1) >> 20) << 20;
-        } else {
-            const uint64_t up = i < 3 ? kMin << i : kMax;                              // 4, 8, 16, 32, 32, ...
-            if (rem > kMax + 24 * kMiB) sz = std::min(up, kMax);
-            else if (rem > 24 * kMiB) sz = std::min(up, std::max(rem - 24 * kMiB, std::min(kMin, rem)));  // ... <= 32, then 16, 8
-            else if (rem > 8 * kMiB) sz = std::min(up, std::max(rem - 8 * kMiB, std::min(kMin, rem)));
-            else sz = rem;
+            off += sz;
+            cuts.push_back(off);
         }
-        off += sz;
-        cuts.push_back(off);
+        return cuts;
     }
+    auto knob = [](const char* name, uint64_t dflt) -> uint64_t {  // tuning knobs of scripts/probe_midsize.py; KiB
+        const char* e = getenv(name);
+        return (e && *e && atoll(e) > 0) ? (uint64_t)atoll(e) * 1024 : dflt;
+    };
+    auto round64k = [](uint64_t v) { return (v + 65535) & ~(uint64_t)65535; };
+    const uint64_t first = knob("CSVSIMD_INGEST_FIRST_KIB", std::min(4 * kMiB, std::max(256 * kKiB, round64k(len / 32))));
+    const uint64_t last = knob("CSVSIMD_INGEST_LAST_KIB", std::min(8 * kMiB, std::max(512 * kKiB, round64k(len / 16))));
+    std::vector<uint64_t> front, back;  // sizes from the file's start / from its end
+    uint64_t rem = len, f = std::min(first, kMax), b = std::min(last, kMax);
+    for (bool at_front = true; rem; at_front = !at_front) {
+        uint64_t& next = at_front ? f : b;
+        std::vector<uint64_t>& side = at_front ? front : back;
+        uint64_t sz = std::min(next, rem);
+        if (rem - sz < sz / 4) sz = rem <= kMax ? rem : round64k(rem / 2);  // no stub: fold it, or cut what is left in two
+        side.push_back(sz);
+        rem -= sz;
+        next = std::min(next * 2, kMax);
+    }
+    uint64_t off = 0;
+    for (uint64_t sz : front) cuts.push_back(off += sz);
+    for (size_t i = back.size(); i-- > 0;) cuts.push_back(off += back[i]);
     return cuts;
 }
 
@@ -1004,6 +1027,23 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
     int rc = pipe_setup(ctx, (int)std::min<uint64_t>(std::max<uint64_t>(nchunks, 1), S), largest);
     if (rc != CSVSIMD_OK) return rc;
     hipStream_t st = ctx->pipe_stream;
+    // Up to kZeroCopyMax the stage-1 kernel reads the chunk straight from its pinned slot — no H2D copy, no event, no second
+    // stream: a chunk costs the submitter two kernel launches.  Measured (scripts/ubench/api_cost.cpp, profiles/r05_api_cost.txt):
+    // a kernel reads 4 MiB of pinned host memory in 81 us (enqueue to flag seen, 48 GiB/s; 8 MiB 154 us, 32 MiB 593 us =
+    // 52.7 GiB/s, the link's rate), a hipMemcpyAsync of 4 MiB followed by a kernel takes 98 us (8 MiB: 172): the copy
+    // engine's fixed ~17 us per copy is what a short file cannot hide.  A long file keeps the copies: its kernels then read
+    // HBM, not the link, and the link carries nothing twice.
+    uint64_t zero_copy_max = 48ull << 20;
+    if (const char* e = getenv("CSVSIMD_INGEST_ZEROCOPY_MIB")) zero_copy_max = (uint64_t)std::max(0, atoi(e)) << 20;  // TUNING
+    const bool zero_copy = len <= zero_copy_max;
+    void* in_dev[S] = {};  // where the kernels read slot k's chunk: the pinned slot itself, or its device copy
+    for (int k = 0; k < S; ++k) {
+        in_dev[k] = ctx->d_in[k];
+        if (zero_copy && ctx->pin_in[k]) HIP_TRY(hipHostGetDevicePointer(&in_dev[k], ctx->pin_in[k], 0));
+    }
+    // a file of a few MiB: the host-side copies ARE the critical path — slices of 128 KiB, workers polling for them
+    const size_t min_slice = len <= (64ull << 20) ? (128u << 10) : CopyPool::kMinSlice;
+    CopyPool::Busy busy(len <= (256ull << 20) ? ctx->copier.get() : nullptr);
 
     // How a chunk's tape reaches the host: a small kernel right behind the stage-1 launch packs the chunk's entries into
     // 32-bit chunk-relative offsets and writes them straight into the slot's pinned host buffer (narrow_tape_kernel,
@@ -1011,7 +1051,7 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
     // Measured on the pool's two-socket hosts (scripts/probe_ingest3.py, 2 GiB): with the tape copied back by D2H
     // copies the H2D copies of the following chunks are served one after the other with them (49 ms = 39 ms of H2D +
     // 10 ms of D2H; the count-only call: 39 ms); with the stage-1 kernel writing its u64 tape into the pinned slot
-    // itself, 42 ms.
+    // itself, 42 ms.  The same kernel publishes the chunk's record (text_kernels.hip): the host polls a pinned word.
     uint64_t n = 1;  // entries so far, sentinel included
     if (tape && tape_cap >= 1) tape[0] = 0;  // src/reader.rs:216
 
@@ -1021,115 +1061,148 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
     // record, and nothing on the GPU ever waits for the host.  The host reads the records kLag chunks late, only to learn
     // how many entries came back and where they belong in the caller's tape.
     //
-    // Three host threads (round 4; a file of one or two chunks runs everything on the caller's):
-    //   stager     user buffer -> pinned slot, up to S - 1 chunks ahead of the H2D copies (sliced over the copy pool)
-    //   submitter  (the caller's thread) H2D copy, stage-1 launch, narrow kernel, record copy-out; reads records kLag behind
+    // Three host threads (a plan of one or two chunks runs everything on the caller's):
+    //   stager     user buffer -> pinned slot, up to S - 1 chunks ahead of the H2D copies (sliced over the copy pool); chunk 0 is
+    //              staged by the caller itself while the stager thread wakes up
+    //   submitter  (the caller's thread) H2D copy, stage-1 launch, packing + publishing kernel; polls records kLag behind;
+    //              expands the LAST chunk itself (no hand-over on the way out)
     //   expander   pinned 32-bit offsets -> the caller's tape (sliced over the copy pool)
-    // Until round 3 the submitter did all three in turn with two slots: staging chunk i + 1 and expanding chunk i - 1 had
-    // to fit into the H2D time of chunk i, every time, or the link idled — 0.93 of the probed link rate on a quiet host,
-    // 0.88-0.90 on the driver's.  Now the link only idles when staging falls S - 1 chunks behind.
+    // The two threads belong to the context and sleep between calls (round 4 created and joined them per call).
     struct Slot {
-        uint64_t chunk = 0, cap = 0;
+        uint64_t chunk = 0, cap = 0, seq = 0;
         uint64_t at = 0, ncopy = 0, base = 0;  // entries waiting in pin_out[k] for the caller's tape (written by the submitter
                                                // before `finished` passes the chunk, read by the expander after)
     } slot[S];
     struct Shared {
         std::mutex m;
         std::condition_variable cv;
-        uint64_t staged = 0;    // chunks whose bytes are in their pinned slot
-        uint64_t h2d = 0;       // chunks whose H2D copy has been enqueued (ev_in recorded)
-        uint64_t finished = 0;  // chunks whose record has been read (slot[].at / ncopy / base valid)
-        uint64_t expanded = 0;  // chunks whose entries have left their pinned slot
-        bool abort = false;
+        std::atomic<uint64_t> staged{0};    // chunks whose bytes are in their pinned slot
+        std::atomic<uint64_t> h2d{0};       // chunks whose H2D copy has been enqueued (ev_in recorded)
+        std::atomic<uint64_t> finished{0};  // chunks whose record has been read (slot[].at / ncopy / base valid)
+        std::atomic<uint64_t> expanded{0};  // chunks whose entries have left their pinned slot
+        std::atomic<bool> abort{false};
         int err = CSVSIMD_OK;
         std::string msg;
     } sh;
+    // a thread of the pipeline waits for another: poll for a while (the other is microseconds away in a file of a few MiB),
+    // then sleep on the condition variable (every update of the counters notifies under the mutex)
+    auto await = [&sh](auto&& ready) {
+        for (int i = 0; i < 4000; ++i) {
+            if (ready()) return;
+            for (int p = 0; p < 8; ++p) _mm_pause();
+        }
+        std::unique_lock<std::mutex> g(sh.m);
+        sh.cv.wait(g, ready);
+    };
+    auto bump = [&sh](std::atomic<uint64_t>& c, uint64_t v) {
+        {
+            std::lock_guard<std::mutex> g(sh.m);
+            c.store(v, std::memory_order_release);
+        }
+        sh.cv.notify_all();
+    };
     uint32_t host_inq = 0, host_esc = dialect ? dialect->escape_in : 0;  // the state after the last chunk whose record was read
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
     double t_stage = 0, t_stage_wait = 0, t_expand = 0, t_wait_staged = 0, t_wait_record = 0, t_wait_expanded = 0, t_submit = 0;
+    double t_stage0 = 0, t_expand_last = 0;  // the caller's own share of staging / expanding (first / last chunk)
 #define CSVSIMD_TIMED(acc, stmt) do { const double t0_ = now(); stmt; acc += now() - t0_; } while (0)
     auto fail = [&](int code, const std::string& msg) {
         {
             std::lock_guard<std::mutex> g(sh.m);
             if (sh.err == CSVSIMD_OK) { sh.err = code; sh.msg = msg; }
-            sh.abort = true;
+            sh.abort.store(true, std::memory_order_release);
         }
         sh.cv.notify_all();
     };
 
     // ---- stager: chunk j's bytes into pin_in[j % S] -----------------------------------------------------------------------
-    auto stage_one = [&](uint64_t j) -> bool {
+    auto stage_one = [&](uint64_t j, double& t_copy, double& t_wait) -> bool {
         const int k = (int)(j % S);
         {
             const double t0 = now();
-            std::unique_lock<std::mutex> g(sh.m);
-            sh.cv.wait(g, [&] { return sh.abort || j < (uint64_t)S || sh.h2d + S > j; });  // chunk j - S has been enqueued
-            t_stage_wait += now() - t0;
-            if (sh.abort) return false;
+            // the slot's previous chunk (j - S) has been enqueued — zero copy: has been READ by its kernels (its record is in)
+            await([&] {
+                return sh.abort.load(std::memory_order_acquire) || j < (uint64_t)S ||
+                       (zero_copy ? sh.finished : sh.h2d).load(std::memory_order_acquire) + S > j;
+            });
+            t_wait += now() - t0;
+            if (sh.abort.load(std::memory_order_acquire)) return false;
         }
-        if (j >= (uint64_t)S) {  // ... and has left the staging slot
+        if (j >= (uint64_t)S && !zero_copy) {  // ... and has left the staging slot
             const double t0 = now();
             const hipError_t e = hipEventSynchronize(ctx->ev_in[k]);
-            t_stage_wait += now() - t0;
+            t_wait += now() - t0;
             if (e != hipSuccess) { fail(CSVSIMD_ERR_HIP, std::string("hipEventSynchronize(ev_in): ") + hipGetErrorString(e)); return false; }
         }
-        CSVSIMD_TIMED(t_stage, ctx->copier->copy(ctx->pin_in[k], buf + cuts[j], cuts[j + 1] - cuts[j]));
-        {
-            std::lock_guard<std::mutex> g(sh.m);
-            sh.staged = j + 1;
-        }
-        sh.cv.notify_all();
+        CSVSIMD_TIMED(t_copy, ctx->copier->copy(ctx->pin_in[k], buf + cuts[j], cuts[j + 1] - cuts[j], min_slice));
+        bump(sh.staged, j + 1);
         return true;
     };
     // ---- expander: chunk j's 32-bit offsets -> the caller's tape ------------------------------------------------------------
-    auto expand_one = [&](uint64_t j) -> bool {
+    auto expand_one = [&](uint64_t j, double& t_copy) -> bool {
         const int k = (int)(j % S);
-        Slot info;
-        {
-            std::unique_lock<std::mutex> g(sh.m);
-            sh.cv.wait(g, [&] { return sh.abort || sh.finished > j; });
-            if (sh.abort) return false;
-            info = slot[k];
-        }
-        if (info.ncopy) CSVSIMD_TIMED(t_expand, ctx->copier->expand(tape + info.at, ctx->pin_out[k], info.ncopy, info.base));
-        {
-            std::lock_guard<std::mutex> g(sh.m);
-            sh.expanded = j + 1;
-        }
-        sh.cv.notify_all();
+        await([&] { return sh.abort.load(std::memory_order_acquire) || sh.finished.load(std::memory_order_acquire) > j; });
+        if (sh.abort.load(std::memory_order_acquire)) return false;
+        const Slot info = slot[k];  // (written before `finished` passed j, not touched again before `expanded` passes it)
+        if (info.ncopy) CSVSIMD_TIMED(t_copy, ctx->copier->expand(tape + info.at, ctx->pin_out[k], info.ncopy, info.base, min_slice));
+        bump(sh.expanded, j + 1);
         return true;
     };
 
-    // enqueues the kernels of the chunk in slot k (stage 1, the narrow kernel) and the copy-out of its record
+    // enqueues the kernels of the chunk in slot k: stage 1, then the kernel that packs the tape into the pinned slot and
+    // publishes the record under a fresh sequence number
     auto launch = [&](int k, bool chained) -> int {
         const uint64_t i = slot[k].chunk, off = cuts[i], clen = cuts[i + 1] - off;
         csvsimd_dialect dia;
         if (dialect) { dia = *dialect; dia.escape_in = (uint8_t)host_esc; }
-        int rc_ = stage1_async_impl(ctx, dialect ? &dia : nullptr, ctx->d_in[k], clen, off, host_inq,
+        int rc_ = stage1_async_impl(ctx, dialect ? &dia : nullptr, in_dev[k], clen, off, host_inq,
                                     tape ? ctx->d_tape[k] : nullptr, slot[k].cap, ctx->d_res[k], st, nullptr,
                                     chained ? ctx->d_res[(k + S - 1) % S] : nullptr);
         if (rc_ != CSVSIMD_OK) return rc_;
-        if (tape) {
-            void* out_dev = nullptr;
-            HIP_TRY(hipHostGetDevicePointer(&out_dev, ctx->pin_out[k], 0));
-            const double out_bytes = std::min<double>(entries_per_byte * (double)clen, (double)slot[k].cap) * 4.0;
-            const int wgs = (int)std::min<double>(std::max(1.0, std::ceil(out_bytes / (double)(2u << 20))), (double)ctx->n_cus);
-            HIP_TRY(csvsimd::launch_narrow_tape(ctx->d_tape[k], ctx->d_res[k], slot[k].cap, off, out_dev, wgs, st));
+        void *out_dev = nullptr, *rec_dev = nullptr;
+        if (tape) HIP_TRY(hipHostGetDevicePointer(&out_dev, ctx->pin_out[k], 0));
+        HIP_TRY(hipHostGetDevicePointer(&rec_dev, (void*)ctx->h_res, 0));
+        rec_dev = (char*)rec_dev + (size_t)k * sizeof(csvsimd_ctx::HostRecord);
+        const double out_bytes = tape ? std::min<double>(entries_per_byte * (double)clen, (double)slot[k].cap) * 4.0 : 0.0;
+        const int wgs = (int)std::min<double>(std::max(1.0, std::ceil(out_bytes / (double)(2u << 20))), (double)ctx->n_cus);
+        slot[k].seq = ++ctx->pub_seq;
+        HIP_TRY(csvsimd::launch_narrow_tape(ctx->d_tape[k], ctx->d_res[k], slot[k].cap, off, out_dev, wgs, st, rec_dev, slot[k].seq,
+                                            (char*)ctx->d_pub + 64 * k));
+        return CSVSIMD_OK;
+    };
+    // waits for the record of the chunk in slot k: polls the sequence word its publishing kernel writes last.  Every
+    // ~250 us it asks the stream whether it is still busy: a stream that has drained (or failed) without the word is an error,
+    // never an endless wait.
+    auto await_record = [&](int k, csvsimd_shard_result& r) -> int {
+        const volatile uint64_t* seq = &ctx->h_res[k].seq;
+        const uint64_t want = slot[k].seq;
+        for (double t_check = now() + 250e-6;;) {
+            if (*seq == want) break;
+            for (int p = 0; p < 16; ++p) _mm_pause();
+            if (now() < t_check) continue;
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) {  // everything enqueued has run: the word must be there
+                if (*seq == want) break;
+                g_last_error = "ingest: a chunk's record was not published";
+                return CSVSIMD_ERR_INTERNAL;
+            }
+            if (q != hipErrorNotReady) return fail_hip(q, "hipStreamQuery(pipe_stream)");
+            t_check = now() + 250e-6;
         }
-        HIP_TRY(hipMemcpyAsync(&ctx->h_res[k], ctx->d_res[k], sizeof(csvsimd_shard_result), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipEventRecord(ctx->ev_rec[k], st));
+        std::atomic_thread_fence(std::memory_order_acquire);
+        memcpy(&r, (const void*)&ctx->h_res[k].rec, sizeof r);
         return CSVSIMD_OK;
     };
     // reads the record of chunk j (kLag behind the launches) and re-runs the chunk if its tape did not fit
     auto finish = [&](uint64_t j) -> int {
         const int k = (int)(j % S);
+        csvsimd_shard_result r;
         {
-            hipError_t e_ = hipSuccess;
-            CSVSIMD_TIMED(t_wait_record, e_ = hipEventSynchronize(ctx->ev_rec[k]));
-            HIP_TRY(e_);
+            int rc_ = CSVSIMD_OK;
+            CSVSIMD_TIMED(t_wait_record, rc_ = await_record(k, r));
+            if (rc_ != CSVSIMD_OK) return rc_;
         }
-        csvsimd_shard_result r = ctx->h_res[k];
         if (r.error) { g_last_error = "stage1 kernel: look-back spin bound hit"; return CSVSIMD_ERR_INTERNAL; }
         if (tape && r.count > slot[k].cap) {
             // denser than guessed (first guess: one entry per 4 bytes): exact capacity, run the chunk again.  Its input is
@@ -1142,22 +1215,18 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
             entries_per_byte = (double)r.count / (double)std::max<uint64_t>(1, cuts[j + 1] - cuts[j]);  // now known exactly
             rc_ = launch(k, false);
             if (rc_ != CSVSIMD_OK) return rc_;
-            HIP_TRY(hipEventSynchronize(ctx->ev_rec[k]));
-            r = ctx->h_res[k];  // the second pass's own record: its error flag and count are what count
+            rc_ = await_record(k, r);  // the second pass's own record: its error flag and count are what count
+            if (rc_ != CSVSIMD_OK) return rc_;
             if (r.error) { g_last_error = "stage1 kernel: look-back spin bound hit"; return CSVSIMD_ERR_INTERNAL; }
             if (r.count > slot[k].cap) return CSVSIMD_ERR_INTERNAL;
         }
-        {
-            std::lock_guard<std::mutex> g(sh.m);
-            slot[k].ncopy = 0;
-            if (tape && n < tape_cap) {
-                slot[k].ncopy = std::min<uint64_t>(tape_cap - n, r.count);
-                slot[k].at = n;
-                slot[k].base = cuts[j];
-            }
-            sh.finished = j + 1;
+        slot[k].ncopy = 0;
+        if (tape && n < tape_cap) {
+            slot[k].ncopy = std::min<uint64_t>(tape_cap - n, r.count);
+            slot[k].at = n;
+            slot[k].base = cuts[j];
         }
-        sh.cv.notify_all();
+        bump(sh.finished, j + 1);
         n += r.count;
         if (cuts[j + 1] > cuts[j]) {
             entries_per_byte = (double)r.count / (double)(cuts[j + 1] - cuts[j]);
@@ -1167,43 +1236,40 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
         host_esc = r.escape_out;
         return CSVSIMD_OK;
     };
-    // the submitter's share of chunk i: H2D copy, kernels, record copy-out
+    // the submitter's share of chunk i: H2D copy, kernels
     auto submit = [&](uint64_t i) -> int {
         const int k = (int)(i % S);
         const uint64_t clen = cuts[i + 1] - cuts[i];
         {
             const double t0 = now();
-            std::unique_lock<std::mutex> g(sh.m);
-            sh.cv.wait(g, [&] { return sh.abort || sh.staged > i; });
+            await([&] { return sh.abort.load(std::memory_order_acquire) || sh.staged.load(std::memory_order_acquire) > i; });
             t_wait_staged += now() - t0;
-            if (sh.abort) return sh.err != CSVSIMD_OK ? sh.err : CSVSIMD_ERR_INTERNAL;
+            if (sh.abort.load(std::memory_order_acquire)) return sh.err != CSVSIMD_OK ? sh.err : CSVSIMD_ERR_INTERNAL;
         }
         const double t0 = now();
         // Two copy streams take turns: a copy's set-up and completion signalling (~30 us, measured as the difference between
         // 68 chunked copies and one copy of the same 2 GiB) overlap the other stream's transfer instead of idling the link.
-        hipStream_t cs = (h2d_streams == 2 && (i & 1)) ? ctx->in_stream2 : ctx->in_stream;
-        if (i >= (uint64_t)S) HIP_TRY(hipStreamWaitEvent(cs, ctx->ev_rec[k], 0));  // chunk i - S's kernels have read d_in[k]
-        HIP_TRY(hipMemcpyAsync(ctx->d_in[k], ctx->pin_in[k], clen, hipMemcpyHostToDevice, cs));
-        HIP_TRY(hipEventRecord(ctx->ev_in[k], cs));
-        {
-            std::lock_guard<std::mutex> g(sh.m);
-            sh.h2d = i + 1;
+        // d_in[k] is free: the record of the slot's previous chunk (i - S) was read before this call (S > kLag).
+        if (!zero_copy) {
+            hipStream_t cs = (h2d_streams == 2 && (i & 1)) ? ctx->in_stream2 : ctx->in_stream;
+            HIP_TRY(hipMemcpyAsync(ctx->d_in[k], ctx->pin_in[k], clen, hipMemcpyHostToDevice, cs));
+            HIP_TRY(hipEventRecord(ctx->ev_in[k], cs));
+            bump(sh.h2d, i + 1);
+            HIP_TRY(hipStreamWaitEvent(st, ctx->ev_in[k], 0));
         }
-        sh.cv.notify_all();
-        HIP_TRY(hipStreamWaitEvent(st, ctx->ev_in[k], 0));
         t_submit += now() - t0;
         if (i >= (uint64_t)S) {  // the slot's previous chunk (i - S): its offsets must have left pin_out[k]
             const double t1 = now();
-            std::unique_lock<std::mutex> g(sh.m);
-            sh.cv.wait(g, [&] { return sh.abort || sh.expanded + S > i; });
+            await([&] { return sh.abort.load(std::memory_order_acquire) || sh.expanded.load(std::memory_order_acquire) + S > i; });
             t_wait_expanded += now() - t1;
-            if (sh.abort) return sh.err != CSVSIMD_OK ? sh.err : CSVSIMD_ERR_INTERNAL;
+            if (sh.abort.load(std::memory_order_acquire)) return sh.err != CSVSIMD_OK ? sh.err : CSVSIMD_ERR_INTERNAL;
         }
         const double t2 = now();
         slot[k].chunk = i;
         slot[k].cap = 0;
         if (tape) {
-            int rc_ = pipe_ensure_tape(ctx, k, std::max<uint64_t>(clen / 4, 4096));  // first guess: one entry per 4 bytes
+            // first guess: one entry per 4 bytes of the SLOT (sized once per size class, not per chunk)
+            int rc_ = pipe_ensure_tape(ctx, k, std::max<uint64_t>(std::max(clen, ctx->slot_bytes[k]) / 4, 4096));
             if (rc_ != CSVSIMD_OK) return rc_;
             slot[k].cap = std::min(ctx->d_tape_entries[k], ctx->pin_out_entries[k]);
         }
@@ -1213,42 +1279,46 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
     };
 
     constexpr uint64_t kLag = 2;  // records are read two chunks behind the launches: two H2D copies stay queued meanwhile
+    static_assert(kLag < (uint64_t)S, "a slot's input buffer is reused once the record of its previous chunk has been read");
     const bool threaded = nchunks >= 3;
     if (threaded) {
-        std::thread stager, expander;
-        struct Joiner {  // whatever happens below (an error return, an exception), the two threads are stopped and joined
+        if (!ctx->stager_thread) ctx->stager_thread.reset(new TaskThread);
+        if (tape && !ctx->expander_thread) ctx->expander_thread.reset(new TaskThread);
+        struct Joiner {  // whatever happens below (an error return, an exception), both tasks have ended before the frame goes
             Shared& sh;
-            std::thread &a, &b;
+            TaskThread *a, *b;
             ~Joiner() {
                 {
                     std::lock_guard<std::mutex> g(sh.m);
-                    sh.abort = true;  // (a completed run: both loops have ended, nobody is listening)
+                    sh.abort.store(true, std::memory_order_release);  // (a completed run: both loops have ended, nobody is listening)
                 }
                 sh.cv.notify_all();
-                if (a.joinable()) a.join();
-                if (b.joinable()) b.join();
+                if (a) a->wait();
+                if (b) b->wait();
             }
-        } joiner{sh, stager, expander};
+        } joiner{sh, nullptr, nullptr};
         const int dev = ctx->device;
-        stager = std::thread([&, dev] {
+        joiner.a = ctx->stager_thread.get();
+        ctx->stager_thread->post([&, dev] {
             if (hipSetDevice(dev) != hipSuccess) { fail(CSVSIMD_ERR_HIP, "hipSetDevice (stager)"); return; }
             try {
-                for (uint64_t j = 0; j < nchunks; ++j)
-                    if (!stage_one(j)) return;
+                for (uint64_t j = 1; j < nchunks; ++j)  // chunk 0 is the caller's
+                    if (!stage_one(j, t_stage, t_stage_wait)) return;
             } catch (...) { fail(CSVSIMD_ERR_INVALID_STATE, "ingest stager: exception"); }
         });
-        if (tape)
-            expander = std::thread([&] {
+        if (tape) {
+            joiner.b = ctx->expander_thread.get();
+            ctx->expander_thread->post([&] {
                 try {
-                    for (uint64_t j = 0; j < nchunks; ++j)
-                        if (!expand_one(j)) return;
+                    for (uint64_t j = 0; j + 1 < nchunks; ++j)  // the last chunk is the caller's
+                        if (!expand_one(j, t_expand)) return;
                 } catch (...) { fail(CSVSIMD_ERR_INVALID_STATE, "ingest expander: exception"); }
             });
-        else {
-            std::lock_guard<std::mutex> g(sh.m);
-            sh.expanded = nchunks;  // count only: nothing ever waits in a pinned slot
+        } else {
+            bump(sh.expanded, nchunks);  // count only: nothing ever waits in a pinned slot
         }
-        rc = CSVSIMD_OK;
+        double t_none = 0;
+        rc = stage_one(0, t_stage0, t_none) ? CSVSIMD_OK : CSVSIMD_ERR_INTERNAL;
         for (uint64_t i = 0; i < nchunks && rc == CSVSIMD_OK; ++i) {
             rc = submit(i);
             if (rc == CSVSIMD_OK && i >= kLag) rc = finish(i - kLag);
@@ -1256,9 +1326,9 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
         for (uint64_t j = nchunks > kLag ? nchunks - kLag : 0; j < nchunks && rc == CSVSIMD_OK; ++j) rc = finish(j);
         if (rc == CSVSIMD_OK && tape) {
             const double t0 = now();
-            std::unique_lock<std::mutex> g(sh.m);
-            sh.cv.wait(g, [&] { return sh.abort || sh.expanded >= nchunks; });
+            await([&] { return sh.abort.load(std::memory_order_acquire) || sh.expanded.load(std::memory_order_acquire) + 1 >= nchunks; });
             t_wait_expanded += now() - t0;
+            if (!sh.abort.load(std::memory_order_acquire) && !expand_one(nchunks - 1, t_expand_last)) rc = CSVSIMD_ERR_INTERNAL;
         }
         {
             std::lock_guard<std::mutex> g(sh.m);
@@ -1269,37 +1339,32 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
         }
         if (rc != CSVSIMD_OK) {
             const std::string keep = g_last_error;
-            fail(rc, keep);  // stops the workers; the Joiner joins them
+            fail(rc, keep);  // stops the workers; the Joiner waits for them
             g_last_error = keep;
             return rc;
         }
     } else {
-        // a file of a few MiB: the same steps in turn on the caller's thread (no thread is worth starting for a file that is
-        // indexed in the time it takes to start two) — still a pipeline: chunk i's H2D copy and kernels run while chunk
-        // i + 1 is staged, records are read kLag chunks behind
-        if (!tape) {
-            std::lock_guard<std::mutex> g(sh.m);
-            sh.expanded = nchunks;
-        }
+        // a plan of one or two chunks (a uniform override): the same steps in turn on the caller's thread
+        if (!tape) bump(sh.expanded, nchunks);
         for (uint64_t i = 0; i < nchunks; ++i) {
-            if (!stage_one(i)) return sh.err;
+            if (!stage_one(i, t_stage, t_stage_wait)) { g_last_error = sh.msg; return sh.err; }
             rc = submit(i);
             if (rc != CSVSIMD_OK) return rc;
             if (i >= kLag) {
                 rc = finish(i - kLag);
                 if (rc != CSVSIMD_OK) return rc;
-                if (tape && !expand_one(i - kLag)) return sh.err;
+                if (tape && !expand_one(i - kLag, t_expand)) return sh.err;
             }
         }
         for (uint64_t j = nchunks > kLag ? nchunks - kLag : 0; j < nchunks; ++j) {
             rc = finish(j);
             if (rc != CSVSIMD_OK) return rc;
-            if (tape && !expand_one(j)) return sh.err;
+            if (tape && !expand_one(j, t_expand)) return sh.err;
         }
     }
 #undef CSVSIMD_TIMED
-    g_ingest_phases = csvsimd_ingest_phases{len, nchunks, threaded ? 3u : 1u, 0u, now() - t_begin, t_stage, t_stage_wait, t_expand,
-                                            t_submit, t_wait_staged, t_wait_record, t_wait_expanded};
+    g_ingest_phases = csvsimd_ingest_phases{len, nchunks, threaded ? 3u : 1u, 0u, now() - t_begin, t_stage + t_stage0, t_stage_wait,
+                                            t_expand + t_expand_last, t_submit, t_wait_staged, t_wait_record, t_wait_expanded};
     *tape_len = n;
     if (in_quote_out) *in_quote_out = host_inq;
     if (tape && n > tape_cap) return CSVSIMD_ERR_TAPE_CAPACITY;
@@ -1318,6 +1383,379 @@ int csvsimd_stage1_index_dialect(csvsimd_ctx* ctx, const csvsimd_dialect* dialec
     return csvsimd_guarded([&]() -> int {
     if (!dialect) return CSVSIMD_ERR_INVALID_ARG;
     return stage1_index_host_impl(ctx, dialect, buf, len, tape, tape_cap, tape_len, in_quote_out);
+    });
+}
+
+/* ---- many small HOST files in one call ------------------------------------------------------------------------------
+ * The reference's unit of work is a file (csv_simd::create, src/lib.rs:61-74) and its own inputs are 96 to 623 bytes
+ * (its res directory): through csvsimd_stage1_index a 300-byte file costs 30 us — a launch and a wait — where one CPU core needs
+ * 1.3 us.  Here n files share that cost: they are packed into pinned groups (a stager thread, the copy pool), each group
+ * crosses PCIe as ONE copy that also carries the group's buffer table, is indexed by ONE batched launch (stage1_kernel<...,
+ * BATCH>: every file is a buffer of its own, entered outside a string, look-backs stop at file boundaries) whose tapes and
+ * result records land in pinned memory as the kernel's own stores, and an expander thread hands every file its tape.
+ * Groups ramp up (256 KiB, 512 KiB ... 4 MiB) for the same reason chunks do.  A file above kBatchItemMax, and a file denser
+ * than its share of the group's tape block (an entry per 4 bytes), goes through csvsimd_stage1_index's own path afterwards. */
+namespace {
+constexpr uint64_t kBatchItemMax = 1ull << 20;       // larger files are not worth packing: they fill a pipeline by themselves
+constexpr uint64_t kBatchGroupBytes = 4ull << 20;    // packed bytes per group (the 8-MiB slot class holds it with its table)
+constexpr uint32_t kBatchGroupItems = 2048;          // files per group (a file is at least one 256-KiB tile of ticket space)
+struct BatchGroup {
+    uint32_t first = 0, count = 0;   // items [first, first + count) of the packed order
+    uint64_t in_bytes = 0;           // packed input incl. table
+    uint64_t off_table = 0, off_first = 0, off_tot = 0;
+    uint64_t out_bytes = 0;          // results + tapes
+    uint32_t tiles = 0;
+};
+}  // namespace
+
+static int stage1_index_batch_body(csvsimd_ctx* ctx, csvsimd_host_batch_item* items, uint32_t n_items) {
+    if (!ctx || (n_items && !items)) return CSVSIMD_ERR_INVALID_ARG;
+    for (uint32_t i = 0; i < n_items; ++i) {
+        csvsimd_host_batch_item& it = items[i];
+        if ((it.len && !it.buf) || (!it.tape && it.tape_cap)) return CSVSIMD_ERR_INVALID_ARG;
+        it.tape_len = 0;
+        it.in_quote_out = 0;
+        it.status = CSVSIMD_ERR_INVALID_STATE;  // until its group has come back
+    }
+    WITH_DEVICE_OF(ctx);
+    constexpr int S = csvsimd_ctx::kSlots;
+    // ---- the plan: which files are packed (in their order), where each one sits in its group -------------------------------
+    struct Placed {
+        uint32_t item;
+        uint32_t in_off;     // in the group's input block (64-byte aligned)
+        uint32_t out_cap;    // entries its share of the group's tape block holds
+        uint64_t out_off;    // of its tape in the group's output block (bytes, 128-byte aligned)
+    };
+    std::vector<Placed> placed;
+    std::vector<uint32_t> alone;  // items that take the single-file path
+    std::vector<BatchGroup> groups;
+    placed.reserve(n_items);
+    {
+        BatchGroup g;
+        uint64_t in_cur = 0, out_cur = 0, target = 256u << 10;
+        auto close_group = [&] {
+            if (!g.count) return;
+            g.off_table = (in_cur + 63) & ~(uint64_t)63;
+            g.off_first = g.off_table + (uint64_t)g.count * sizeof(csvsimd::BatchItemHost);
+            g.off_tot = g.off_first + (((uint64_t)g.count * 4 + 63) & ~(uint64_t)63);
+            g.in_bytes = g.off_tot + (uint64_t)g.count * 8;
+            // output block: [count result records | tapes]; the tape offsets were laid out behind a records area of
+            // kBatchGroupItems records, so that they do not depend on the group's final count
+            g.out_bytes = out_cur;
+            groups.push_back(g);
+            target = std::min<uint64_t>(target * 2, kBatchGroupBytes);
+            g = BatchGroup{};
+            g.first = (uint32_t)placed.size();
+            in_cur = 0;
+            out_cur = 0;
+        };
+        for (uint32_t i = 0; i < n_items; ++i) {
+            const csvsimd_host_batch_item& it = items[i];
+            if (it.len > kBatchItemMax) { alone.push_back(i); continue; }
+            const uint64_t in_need = (it.len + 63) & ~(uint64_t)63;
+            const uint64_t want_cap = it.tape ? std::min<uint64_t>(it.tape_cap ? it.tape_cap - 1 : 0, it.len / 4 + 16) : 0;
+            const uint64_t out_need = (want_cap * 8 + 127) & ~(uint64_t)127;
+            if (g.count && (in_cur + in_need > target || g.count >= kBatchGroupItems)) close_group();
+            if (!g.count) out_cur = (uint64_t)kBatchGroupItems * sizeof(csvsimd_shard_result);
+            placed.push_back(Placed{i, (uint32_t)in_cur, (uint32_t)want_cap, out_cur});
+            in_cur += in_need;
+            out_cur += out_need;
+            g.tiles += it.len ? (uint32_t)((it.len + CSVSIMD_TILE_BYTES - 1) / CSVSIMD_TILE_BYTES) : 0u;
+            ++g.count;
+        }
+        close_group();
+    }
+    const uint64_t ngroups = groups.size();
+    int any_capacity = 0;
+    if (ngroups) {
+        uint64_t max_in = 0, max_out = 0;
+        uint32_t max_tiles = 0;
+        for (const BatchGroup& g : groups) {
+            max_in = std::max(max_in, g.in_bytes);
+            max_out = std::max(max_out, g.out_bytes);
+            max_tiles = std::max(max_tiles, g.tiles);
+        }
+        int rc = pipe_setup(ctx, (int)std::min<uint64_t>(ngroups, S), max_in);
+        if (rc != CSVSIMD_OK) return rc;
+        rc = csvsimd_ctx_reserve(ctx, (uint64_t)max_tiles * CSVSIMD_TILE_BYTES);
+        if (rc != CSVSIMD_OK) return rc;
+        for (int k = 0; k < (int)std::min<uint64_t>(ngroups, S); ++k)
+            if (ctx->pin_bout_bytes[k] < max_out) {
+                if (ctx->pin_bout[k]) HIP_TRY(hipHostFree(ctx->pin_bout[k]));
+                ctx->pin_bout[k] = nullptr;
+                ctx->pin_bout_bytes[k] = 0;
+                const size_t want = std::max<size_t>(max_out, (size_t)kBatchGroupItems * sizeof(csvsimd_shard_result) + (2u << 20));
+                HIP_TRY(hipHostMalloc(&ctx->pin_bout[k], want, hipHostMallocDefault));
+                ctx->pin_bout_bytes[k] = want;
+            }
+        hipStream_t st = ctx->pipe_stream;
+        void* bout_dev[S] = {};
+        void* rec_dev_base = nullptr;
+        for (int k = 0; k < (int)std::min<uint64_t>(ngroups, S); ++k) HIP_TRY(hipHostGetDevicePointer(&bout_dev[k], ctx->pin_bout[k], 0));
+        HIP_TRY(hipHostGetDevicePointer(&rec_dev_base, (void*)ctx->h_res, 0));
+        CopyPool::Busy busy(ctx->copier.get());
+
+        struct Shared {
+            std::mutex m;
+            std::condition_variable cv;
+            std::atomic<uint64_t> staged{0}, h2d{0}, finished{0}, expanded{0};
+            std::atomic<bool> abort{false};
+            int err = CSVSIMD_OK;
+            std::string msg;
+        } sh;
+        auto await = [&sh](auto&& ready) {
+            for (int i = 0; i < 4000; ++i) {
+                if (ready()) return;
+                for (int p = 0; p < 8; ++p) _mm_pause();
+            }
+            std::unique_lock<std::mutex> g(sh.m);
+            sh.cv.wait(g, ready);
+        };
+        auto bump = [&sh](std::atomic<uint64_t>& c, uint64_t v) {
+            {
+                std::lock_guard<std::mutex> g(sh.m);
+                c.store(v, std::memory_order_release);
+            }
+            sh.cv.notify_all();
+        };
+        auto fail = [&](int code, const std::string& msg) {
+            {
+                std::lock_guard<std::mutex> g(sh.m);
+                if (sh.err == CSVSIMD_OK) { sh.err = code; sh.msg = msg; }
+                sh.abort.store(true, std::memory_order_release);
+            }
+            sh.cv.notify_all();
+        };
+        auto aborted = [&sh] { return sh.abort.load(std::memory_order_acquire); };
+        uint64_t seqs[S] = {};
+        std::atomic<int> capacity_seen{0};
+
+        // ---- stager: group j's files and its buffer table into pin_in[j % S] -------------------------------------------------
+        auto stage_one = [&](uint64_t j) -> bool {
+            const int k = (int)(j % S);
+            await([&] { return aborted() || j < (uint64_t)S || sh.h2d.load(std::memory_order_acquire) + S > j; });
+            if (aborted()) return false;
+            if (j >= (uint64_t)S) {
+                const hipError_t e = hipEventSynchronize(ctx->ev_in[k]);  // the slot's previous group has left the staging block
+                if (e != hipSuccess) { fail(CSVSIMD_ERR_HIP, std::string("hipEventSynchronize(ev_in): ") + hipGetErrorString(e)); return false; }
+            }
+            const BatchGroup& g = groups[j];
+            char* const base = (char*)ctx->pin_in[k];
+            const char* const d_in = (const char*)ctx->d_in[k];
+            char* const d_out = (char*)bout_dev[k];
+            csvsimd::BatchItemHost* const table = reinterpret_cast<csvsimd::BatchItemHost*>(base + g.off_table);
+            uint32_t* const firsts = reinterpret_cast<uint32_t*>(base + g.off_first);
+            memset(base + g.off_tot, 0, (size_t)g.count * 8);
+            // first tiles: a prefix sum over the group (cheap, serial), then the copies and table lines in parallel
+            uint32_t tiles = 0;
+            for (uint32_t q = 0; q < g.count; ++q) {
+                firsts[q] = tiles;
+                const uint64_t len = items[placed[g.first + q].item].len;
+                tiles += len ? (uint32_t)((len + CSVSIMD_TILE_BYTES - 1) / CSVSIMD_TILE_BYTES) : 0u;
+            }
+            const std::function<void(size_t, size_t)> pack = [&](size_t a, size_t b) {
+                for (size_t q = a; q < b; ++q) {
+                    const Placed& pl = placed[g.first + q];
+                    const csvsimd_host_batch_item& it = items[pl.item];
+                    if (it.len) memcpy(base + pl.in_off, it.buf, it.len);
+                    csvsimd::BatchItemHost& t = table[q];
+                    t.abase = d_in + pl.in_off;  // 64-byte aligned
+                    t.lo = 0;
+                    t.hi = it.len;
+                    t.base_off = 0;              // offsets relative to the file's first byte, like csvsimd_stage1_index
+                    t.tape = pl.out_cap ? d_out + pl.out_off : nullptr;
+                    t.tape_cap = pl.out_cap;
+                    t.first_tile = firsts[q];
+                    t.in_quote_in = 0;
+                    t.reserved = 0;
+                }
+            };
+            ctx->copier->parallel_for(g.count, 64, pack);
+            bump(sh.staged, j + 1);
+            return true;
+        };
+        // ---- expander: every file of group j gets its tape and its outputs ---------------------------------------------------
+        auto expand_one = [&](uint64_t j) -> bool {
+            const int k = (int)(j % S);
+            await([&] { return aborted() || sh.finished.load(std::memory_order_acquire) > j; });
+            if (aborted()) return false;
+            const BatchGroup& g = groups[j];
+            const char* const out = (const char*)ctx->pin_bout[k];
+            const csvsimd_shard_result* const recs = reinterpret_cast<const csvsimd_shard_result*>(out);
+            const std::function<void(size_t, size_t)> unpack = [&](size_t a, size_t b) {
+                for (size_t q = a; q < b; ++q) {
+                    const Placed& pl = placed[g.first + q];
+                    csvsimd_host_batch_item& it = items[pl.item];
+                    const csvsimd_shard_result& r = recs[q];
+                    it.tape_len = r.count + 1;
+                    it.in_quote_out = r.in_quote_out;
+                    if (r.error) { it.status = CSVSIMD_ERR_INTERNAL; continue; }
+                    if (it.tape && it.tape_cap) it.tape[0] = 0;  // src/reader.rs:216
+                    const uint64_t room = it.tape_cap ? it.tape_cap - 1 : 0;
+                    if (it.tape && r.count > pl.out_cap && pl.out_cap < room) { it.status = CSVSIMD_ERR_TAPE_CAPACITY + 1000; continue; }  // denser than its share: alone, later
+                    const uint64_t ncopy = it.tape ? std::min<uint64_t>(r.count, room) : 0;
+                    if (ncopy) memcpy(it.tape + 1, out + pl.out_off, ncopy * 8);
+                    it.status = (it.tape && r.count + 1 > it.tape_cap) ? CSVSIMD_ERR_TAPE_CAPACITY : CSVSIMD_OK;
+                    if (it.status != CSVSIMD_OK) capacity_seen.store(1, std::memory_order_relaxed);
+                }
+            };
+            ctx->copier->parallel_for(g.count, 64, unpack);
+            bump(sh.expanded, j + 1);
+            return true;
+        };
+        auto submit = [&](uint64_t j) -> int {
+            const int k = (int)(j % S);
+            const BatchGroup& g = groups[j];
+            await([&] { return aborted() || sh.staged.load(std::memory_order_acquire) > j; });
+            if (aborted()) return sh.err != CSVSIMD_OK ? sh.err : CSVSIMD_ERR_INTERNAL;
+            hipStream_t cs = (j & 1) ? ctx->in_stream2 : ctx->in_stream;
+            HIP_TRY(hipMemcpyAsync(ctx->d_in[k], ctx->pin_in[k], g.in_bytes, hipMemcpyHostToDevice, cs));
+            HIP_TRY(hipEventRecord(ctx->ev_in[k], cs));
+            bump(sh.h2d, j + 1);
+            HIP_TRY(hipStreamWaitEvent(st, ctx->ev_in[k], 0));
+            if (j >= (uint64_t)S) {  // the slot's previous group must have left pin_bout[k]
+                await([&] { return aborted() || sh.expanded.load(std::memory_order_acquire) + S > j; });
+                if (aborted()) return sh.err != CSVSIMD_OK ? sh.err : CSVSIMD_ERR_INTERNAL;
+            }
+            csvsimd::Stage1Launch L;
+            L.bind_scratch(ctx->scratch);
+            ctx->last_stream = st;
+            ctx->launched = true;
+            char* const d_in = (char*)ctx->d_in[k];
+            HIP_TRY(csvsimd::launch_stage1_batch(d_in + g.off_table, d_in + g.off_first, d_in + g.off_tot, g.count, g.tiles,
+                                                 (csvsimd_shard_result*)bout_dev[k], ctx->scratch, L.scratch_desc, ctx->max_blocks, st));
+            seqs[k] = ++ctx->pub_seq;
+            // the publisher: (no tape to pack) copies record 0 next to the sequence word, which is what the host polls
+            HIP_TRY(csvsimd::launch_narrow_tape(nullptr, bout_dev[k], 0, 0, nullptr, 1, st,
+                                                (char*)rec_dev_base + (size_t)k * sizeof(csvsimd_ctx::HostRecord), seqs[k],
+                                                (char*)ctx->d_pub + 64 * k));
+            return CSVSIMD_OK;
+        };
+        auto finish = [&](uint64_t j) -> int {
+            const int k = (int)(j % S);
+            const volatile uint64_t* seq = &ctx->h_res[k].seq;
+            auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+            for (double t_check = now() + 250e-6;;) {
+                if (*seq == seqs[k]) break;
+                for (int p = 0; p < 16; ++p) _mm_pause();
+                if (now() < t_check) continue;
+                const hipError_t q = hipStreamQuery(st);
+                if (q == hipSuccess) {
+                    if (*seq == seqs[k]) break;
+                    g_last_error = "batch ingest: a group's records were not published";
+                    return CSVSIMD_ERR_INTERNAL;
+                }
+                if (q != hipErrorNotReady) return fail_hip(q, "hipStreamQuery(pipe_stream)");
+                t_check = now() + 250e-6;
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+            bump(sh.finished, j + 1);
+            return CSVSIMD_OK;
+        };
+
+        constexpr uint64_t kLag = 2;
+        if (!ctx->stager_thread) ctx->stager_thread.reset(new TaskThread);
+        if (!ctx->expander_thread) ctx->expander_thread.reset(new TaskThread);
+        struct Joiner {
+            Shared& sh;
+            TaskThread *a, *b;
+            ~Joiner() {
+                {
+                    std::lock_guard<std::mutex> g(sh.m);
+                    sh.abort.store(true, std::memory_order_release);
+                }
+                sh.cv.notify_all();
+                if (a) a->wait();
+                if (b) b->wait();
+            }
+        } joiner{sh, nullptr, nullptr};
+        const int dev = ctx->device;
+        const bool threaded = ngroups >= 2;
+        rc = CSVSIMD_OK;
+        if (threaded) {
+            joiner.a = ctx->stager_thread.get();
+            ctx->stager_thread->post([&, dev] {
+                if (hipSetDevice(dev) != hipSuccess) { fail(CSVSIMD_ERR_HIP, "hipSetDevice (stager)"); return; }
+                try {
+                    for (uint64_t j = 1; j < ngroups; ++j)
+                        if (!stage_one(j)) return;
+                } catch (...) { fail(CSVSIMD_ERR_INVALID_STATE, "batch stager: exception"); }
+            });
+            joiner.b = ctx->expander_thread.get();
+            ctx->expander_thread->post([&] {
+                try {
+                    for (uint64_t j = 0; j + 1 < ngroups; ++j)
+                        if (!expand_one(j)) return;
+                } catch (...) { fail(CSVSIMD_ERR_INVALID_STATE, "batch expander: exception"); }
+            });
+        }
+        if (!stage_one(0)) rc = CSVSIMD_ERR_INTERNAL;
+        for (uint64_t j = 0; j < ngroups && rc == CSVSIMD_OK; ++j) {
+            if (!threaded && j > 0 && !stage_one(j)) { rc = CSVSIMD_ERR_INTERNAL; break; }
+            rc = submit(j);
+            if (rc == CSVSIMD_OK && j >= kLag) {
+                rc = finish(j - kLag);
+                if (rc == CSVSIMD_OK && !threaded && !expand_one(j - kLag)) rc = CSVSIMD_ERR_INTERNAL;
+            }
+        }
+        for (uint64_t j = ngroups > kLag ? ngroups - kLag : 0; j < ngroups && rc == CSVSIMD_OK; ++j) {
+            rc = finish(j);
+            if (rc == CSVSIMD_OK && !threaded && !expand_one(j)) rc = CSVSIMD_ERR_INTERNAL;
+        }
+        if (rc == CSVSIMD_OK && threaded) {
+            await([&] { return aborted() || sh.expanded.load(std::memory_order_acquire) + 1 >= ngroups; });
+            if (!aborted() && !expand_one(ngroups - 1)) rc = CSVSIMD_ERR_INTERNAL;
+        }
+        {
+            std::lock_guard<std::mutex> g(sh.m);
+            if (sh.err != CSVSIMD_OK) {
+                rc = sh.err;
+                g_last_error = sh.msg;
+            }
+        }
+        if (rc != CSVSIMD_OK) {
+            const std::string keep = g_last_error;
+            fail(rc, keep);
+            g_last_error = keep;
+            return rc;
+        }
+        any_capacity = capacity_seen.load();
+    }
+    // ---- the files that go alone: too large to pack, or denser than an entry per 4 bytes ---------------------------------------
+    for (const Placed& pl : placed)
+        if (items[pl.item].status == CSVSIMD_ERR_TAPE_CAPACITY + 1000) alone.push_back(pl.item);
+    for (uint32_t i : alone) {
+        csvsimd_host_batch_item& it = items[i];
+        uint64_t n = 0;
+        uint32_t q = 0;
+        const int rc = stage1_index_host_body(ctx, nullptr, it.buf, it.len, it.tape, it.tape_cap, &n, &q);
+        it.tape_len = n;
+        it.in_quote_out = q;
+        it.status = rc;
+        if (rc == CSVSIMD_ERR_TAPE_CAPACITY) any_capacity = 1;
+        else if (rc != CSVSIMD_OK) return rc;
+    }
+    for (uint32_t i = 0; i < n_items; ++i)
+        if (items[i].status == CSVSIMD_ERR_INTERNAL) {
+            g_last_error = "stage1 kernel: look-back spin bound hit";
+            return CSVSIMD_ERR_INTERNAL;
+        }
+    return any_capacity ? CSVSIMD_ERR_TAPE_CAPACITY : CSVSIMD_OK;
+}
+
+int csvsimd_stage1_index_batch(csvsimd_ctx* ctx, csvsimd_host_batch_item* items, uint32_t n_items) {
+    return csvsimd_guarded([&]() -> int {
+    const int rc = stage1_index_batch_body(ctx, items, n_items);
+    if (rc != CSVSIMD_OK && rc != CSVSIMD_ERR_TAPE_CAPACITY && ctx && ctx->pipe_stream) {
+        const std::string keep = g_last_error;  // (as stage1_index_host_impl: nothing may be left in flight on the pinned slots)
+        ScopedDevice scoped_device_(ctx->device);
+        if (ctx->in_stream) (void)hipStreamSynchronize(ctx->in_stream);
+        if (ctx->in_stream2) (void)hipStreamSynchronize(ctx->in_stream2);
+        (void)hipStreamSynchronize(ctx->pipe_stream);
+        (void)hipGetLastError();
+        g_last_error = keep;
+    }
+    return rc;
     });
 }
 
@@ -1457,12 +1895,45 @@ int csvsimd_stitch_shards(const csvsimd_shard_result* results, uint32_t n_shards
 
 }  // extern "C"
 
+// The index a tape owns (csvsimd_create): anonymous memory straight from the kernel — untouched capacity costs nothing
+// (round 4's std::vector zero-filled an entry per 8 bytes of the file up front: 2 GiB of memset and page faults in front of
+// a 40 ms pipeline, and 140 ms of munmap behind it), pages are faulted in by whoever writes them first (the expander's
+// slices, in parallel), 2-MiB pages where the kernel hands them out.
+struct IndexBlock {
+    uint64_t* p = nullptr;
+    size_t bytes = 0;
+    IndexBlock() = default;
+    IndexBlock(const IndexBlock&) = delete;
+    IndexBlock& operator=(const IndexBlock&) = delete;
+    ~IndexBlock() { release(); }
+    void release() {
+        if (p) munmap(p, bytes);
+        p = nullptr;
+        bytes = 0;
+    }
+    bool reserve(uint64_t entries) {
+        release();
+        const size_t want = (((size_t)entries * 8) + ((2u << 20) - 1)) & ~(size_t)((2u << 20) - 1);
+        void* m = mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (m == MAP_FAILED) return false;
+        (void)madvise(m, want, MADV_HUGEPAGE);  // advice only: without THP the block is faulted in 4-KiB pages
+        p = (uint64_t*)m;
+        bytes = want;
+        return true;
+    }
+    uint64_t capacity() const { return bytes / 8; }
+    void shrink_to(uint64_t entries) {  // gives the untouched tail of the reservation back
+        const size_t keep = std::max<size_t>(4096, (((size_t)entries * 8) + 4095) & ~(size_t)4095);
+        if (p && keep < bytes && mremap(p, bytes, keep, 0) != MAP_FAILED) bytes = keep;
+    }
+};
+
 struct csvsimd_tape {
     csv_simd::Tape tape;
     // owned storage when built by csvsimd_create
     void* map = nullptr;
     uint64_t map_len = 0;
-    std::vector<uint64_t> owned_index;
+    IndexBlock owned_index;
     csvsimd_tape() = default;
     csvsimd_tape(const csvsimd_tape&) = delete;
     csvsimd_tape& operator=(const csvsimd_tape&) = delete;
@@ -1566,19 +2037,29 @@ const uint8_t* csvsimd_tape_bytes(const csvsimd_tape* t, uint64_t* len) {
     return t ? t->tape.data_bytes() : nullptr;
 }
 
-// csv_simd::create (src/lib.rs:61-74): open, mmap, Header::new, reader::read (GPU), tape
+// csv_simd::create (src/lib.rs:61-74): open, mmap, Header::new, reader::read (GPU), tape.
+// The mapping is the tape's data (TapeCore owns the Mmap, src/tape.rs:303) AND what stage 1 reads: the stager's slices touch
+// the page-cache pages of a chunk first, in parallel, a few chunks ahead of the link.  Measured (round 5, 2 GiB, page cache
+// hot, `profiles/r05_file_ingest.txt`): 40.3 ms, the same as the same bytes in a caller's buffer (40.0); pread by slices
+// straight into the pinned slots instead — no page of the mapping touched — 58-61 ms (the kernel's copy reads the
+// destination lines for ownership and runs at 65-85 GB/s over eight threads, the streaming copy out of the mapping at
+// 90-138: profiles/r05_hostmem_probe.txt).  What round 4 lost was not in the pipeline: 385 ms for the same file, 345 of them
+// in a std::vector zero-filled to an entry per 8 bytes of the file in front of it and its munmap behind it.
 int csvsimd_create(csvsimd_ctx* ctx, const char* filename, csvsimd_tape** out) {
     return csvsimd_guarded([&]() -> int {
     if (!ctx || !filename || !out) return CSVSIMD_ERR_INVALID_ARG;
     *out = nullptr;
-    const int fd = open(filename, O_RDONLY);
+    const int fd = open(filename, O_RDONLY | O_CLOEXEC);
     if (fd < 0) { g_last_error = std::string("open: ") + strerror(errno); return CSVSIMD_ERR_IO; }
+    struct FdCloser {
+        int fd;
+        ~FdCloser() { close(fd); }
+    } closer{fd};
     struct stat st;
-    if (fstat(fd, &st) != 0) { close(fd); return CSVSIMD_ERR_IO; }
+    if (fstat(fd, &st) != 0) return CSVSIMD_ERR_IO;
     const uint64_t len = (uint64_t)st.st_size;
-    if (len == 0) { close(fd); return CSVSIMD_ERR_IO; }  // memmap refuses empty files too
+    if (len == 0) return CSVSIMD_ERR_IO;  // memmap refuses empty files too
     void* map = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
-    close(fd);
     if (map == MAP_FAILED) { g_last_error = std::string("mmap: ") + strerror(errno); return CSVSIMD_ERR_IO; }
     std::unique_ptr<csvsimd_tape> t(new (std::nothrow) csvsimd_tape);
     if (!t) { munmap(map, len); return CSVSIMD_ERR_INVALID_STATE; }
@@ -1588,18 +2069,17 @@ int csvsimd_create(csvsimd_ctx* ctx, const char* filename, csvsimd_tape** out) {
     csv_simd::Header h;
     csv_simd::StructureError e = csv_simd::Header::create(bytes, len, h);
     if (e != csv_simd::StructureError::Ok) return (int)e;
-    // one pass with a capacity guess (an entry per 8 bytes); one exact retry if the file is denser
+    // one pass with a capacity guess (an entry per 8 bytes: address space only); one exact retry if the file is denser
     uint64_t n = 0;
-    t->owned_index.resize(len / 8 + 64);
-    int rc = csvsimd_stage1_index(ctx, bytes, len, t->owned_index.data(), t->owned_index.size(), &n, nullptr);
+    if (!t->owned_index.reserve(len / 8 + 64)) { g_last_error = "mmap (index)"; return CSVSIMD_ERR_INVALID_STATE; }
+    int rc = stage1_index_host_impl(ctx, nullptr, bytes, len, t->owned_index.p, t->owned_index.capacity(), &n, nullptr);
     if (rc == CSVSIMD_ERR_TAPE_CAPACITY) {
-        t->owned_index.resize(n);
-        rc = csvsimd_stage1_index(ctx, bytes, len, t->owned_index.data(), n, &n, nullptr);
+        if (!t->owned_index.reserve(n)) { g_last_error = "mmap (index)"; return CSVSIMD_ERR_INVALID_STATE; }
+        rc = stage1_index_host_impl(ctx, nullptr, bytes, len, t->owned_index.p, t->owned_index.capacity(), &n, nullptr);
     }
     if (rc != CSVSIMD_OK) return rc;
-    t->owned_index.resize(n);
-    e = csv_simd::Tape::from_core(bytes, len, csv_simd::StructureIndex{t->owned_index.data(), n}, std::move(h),
-                                  t->tape);
+    t->owned_index.shrink_to(n);
+    e = csv_simd::Tape::from_core(bytes, len, csv_simd::StructureIndex{t->owned_index.p, n}, std::move(h), t->tape);
     if (e != csv_simd::StructureError::Ok) return (int)e;
     *out = t.release();
     return CSVSIMD_OK;

@@ -80,6 +80,9 @@ hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream);
 }  // namespace csvsimd
 namespace csvsimd_dense {
 hipError_t launch_stage1_dense(const csvsimd::Stage1Launch& L, hipStream_t stream);  // stage1_dense.hip
+hipError_t launch_stage1_batch_dense(void* d_items, void* d_first_tiles, void* d_tots, uint32_t n_items, uint32_t total_tiles,
+                                     csvsimd_shard_result* d_results, void* scratch_base, uint64_t* scratch_desc,
+                                     uint32_t max_blocks, hipStream_t stream);
 }
 namespace csvsimd {
 hipError_t launch_synth(void* dbuf, uint64_t file_off, uint64_t len, uint32_t cols, uint32_t width,
@@ -153,8 +156,10 @@ hipError_t launch_utf8_validate(const void* dbuf, uint64_t len, void* d_result, 
 hipError_t launch_trim_spans(const void* dbytes, void* d_begin, void* d_end, uint64_t n, uint32_t flags,
                              uint32_t quote, hipStream_t stream);
 // ingest: a chunk's tape (u64, device) -> 32-bit chunk-relative offsets in a pinned host slot; count read on the device
+// h_rec_dev != nullptr: the launch also publishes the record (64 bytes, then `seq` in the 8 bytes behind it) to that
+// device-visible host address; d_arrivals = a zeroed u32 the launch leaves zeroed
 hipError_t launch_narrow_tape(const void* d_tape, const void* d_result, uint64_t cap, uint64_t base, void* d_out, int workgroups,
-                              hipStream_t stream);
+                              hipStream_t stream, void* h_rec_dev = nullptr, uint64_t seq = 0, void* d_arrivals = nullptr);
 int stage1_max_blocks_per_cu();
 
 }  // namespace csvsimd

@@ -1296,6 +1296,7 @@ static_assert(offsetof(csvsimd_stitch, reemit) == 4 * kStitchReemitWord && offse
 // is there before any workgroup needs it (wave 0 of a workgroup that resolves a tile: wait_for_guess); no tile
 // becomes inclusive before the choice exists, so the words read back here are still aggregates.
 constexpr u32 kGuessTiles = (2u << 20) / (u32)kTileBytes;  // 8 tiles of 256 KiB (32 of the dense geometry's 64 KiB)
+constexpr u32 kPinDeferred = 0xffffffffu;                  // s_pin: nothing was resolved in this iteration
 __device__ __forceinline__ void guess_vote(u64* desc, Control* ctl, u32 num_tiles, u32 epoch, u32 lane, u32& err) {
     const u32 voters = num_tiles < kGuessTiles ? num_tiles : kGuessTiles;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's aggregate has left before it is counted in
@@ -1375,6 +1376,11 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
     __shared__ u32 s_wdesc[kWaves][3];
     __shared__ u32 s_pin;
     __shared__ u64 s_base;
+    // CSVSIMD_ENTER_GUESS launches on a grid smaller than the vote (round 5): tiles this workgroup counted, published and
+    // voted for but could not keep — their masks were dropped when the choice was not there yet and the workgroup went on
+    // drawing tickets; they are counted again (not published, not voted for again) once the choice exists
+    __shared__ u32 s_owed[kGuessTiles];
+    __shared__ u32 s_owed_n, s_owed_head, s_redo;  // s_redo: the tile of this iteration is an owed one (wave 0 reads it back)
     // wave-private images: input transpose in the count phase (two, double-buffered LDS-DMA), u16
     // compaction window in the emit phase (the uses never overlap in time within a wave).
     // DENSE: a wave's two images are ONE 8-KiB block, so that together they are its 4 096-entry emit window
@@ -1383,7 +1389,8 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
     __shared__ uint4 s_stage_a[kWaves][DENSE ? 2 * kImg : kImg];
     __shared__ uint4 s_stage_bb[DENSE ? 1 : kWaves][DENSE ? 1 : kImg];
     static_assert(kCompCap * 2 <= kRoundBytes, "compaction window must fit the stage image");
-    static_assert(!DENSE || (EMIT && DBG == 0 && DIALECT == 0 && !BATCH), "the dense emit path exists for the reference dialect's emitting launch");
+    static_assert(!DENSE || (EMIT && DBG == 0 && DIALECT <= 1 && !(DIALECT && BATCH)),
+                  "the dense emit path exists for emitting launches of the reference dialect (one buffer or a batch) and of another delimiter / quote byte");
     // DENSE: wave 0's look-back window has a place of its own (2 KiB): the waves' images are the WORKGROUP's emit window there
     __shared__ uint4 s_lb[DENSE ? 128 : 1];
 #define s_stage_of(wave) (s_stage_a[wave])
@@ -1392,7 +1399,9 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
     // escape dialects only (the array does not exist in the other instantiations): the masks of the held tile's LAST
     // round are parked here across the count phase of the next tile — those variants are four VGPRs short there (a third
     // mask and the run-parity chain are in flight), and what hipcc spills otherwise is exactly this pair, to scratch
-    constexpr bool kPark = DIALECT >= 2 || BATCH;  // (a batched launch carries the held tile's buffer on top: same squeeze)
+    // (a batched launch carries the held tile's buffer on top: same squeeze; the dense geometry holds two rounds per wave, not
+    // eight, and has the registers)
+    constexpr bool kPark = (DIALECT >= 2 || BATCH) && !DENSE;
     __shared__ uint4 s_park[kPark ? kWaves : 1][kPark ? 64 : 1];
 
     const u32 t = threadIdx.x;
@@ -1465,6 +1474,11 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
               ((__builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11))) & 0xffu)
         : nullptr;
     bool hold_token = false;
+    if (w == 0 && lane == 0) {
+        s_owed_n = 0;
+        s_owed_head = 0;
+        s_redo = 0;
+    }
 
     for (u32 iter = 0;; ++iter) {
 #ifdef CSVSIMD_DEV_PROBES
@@ -1491,6 +1505,37 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
                     u32 spins = 0;
                     while (atomicCAS(my_token, 0u, 1u) != 0u && ++spins < (1u << 16)) __builtin_amdgcn_s_sleep(8);
                 }
+                // an owed tile first, as soon as the shard's entering state has been chosen (see kOwed below); else a ticket
+                // (GUESS launches) an owed tile first, as soon as the shard's entering state has been chosen; else a ticket — and
+                // if the tickets have run out while tiles are owed, the choice is waited for here: every voter's ticket was
+                // drawn long ago, by a workgroup that is running, and this workgroup's own voters have all voted
+                bool took = false;
+                if (!BATCH && uniform_again<true>(inq_in) == kEnterGuess) {
+                    const u32 head = s_owed_head;
+                    if (head != s_owed_n) {
+                        u32 g = __hip_atomic_load(&args.ctl->guess, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        u32 tk = 0;
+                        if (g == 0u) {
+                            tk = atomicAdd(&args.ctl->ticket, 1u);
+                            if (tk >= args.num_tiles) {
+                                for (u32 spins = 0; g == 0u && spins < kSpinLimit; ++spins) {
+                                    __builtin_amdgcn_s_sleep(16);
+                                    g = __hip_atomic_load(&args.ctl->guess, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                }
+                                if (g == 0u) atomicOr(&args.ctl->err, 1u);  // (the spin bound: the launch ends with its error flag set)
+                                g = 2u;
+                            }
+                        }
+                        if (g != 0u) {
+                            tk = s_owed[head];
+                            s_owed_head = head + 1u;
+                        }
+                        s_redo = g != 0u ? 1u : 0u;
+                        s_tile = tk;
+                        took = true;
+                    }
+                }
+                if (!took)
                 s_tile = (DBG & 2) ? blockIdx.x + iter * gridDim.x : atomicAdd(&args.ctl->ticket, 1u);
             }
         }
@@ -1624,17 +1669,43 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
         // scatters its span of the held tile speculatively (see scatter_span_spec) — the 3-5 us the polls take behind the
         // CU's streaming loads used to be seven idle waves at barrier B — and only then does wave 0 consume the window.
         if (w == 0) {
-            if (have_cur) {
+            // (GUESS launches) an owed tile was counted, published and voted for before: only its masks were needed again
+            const bool redo = !BATCH && uniform_again<true>(inq_in) == kEnterGuess &&
+                              (u32)__builtin_amdgcn_readfirstlane((int)s_redo) != 0u;
+            bool defer = false;
+            if (have_cur && !redo) {
                 if (!(DBG & 4) && lane == 0) publish_aggregate(args.desc, tile, epoch, agg);
                 wg_tot += (u64)(u32)__builtin_amdgcn_readfirstlane((int)(agg.a + agg.b));
                 if (BATCH && lane == 0)  // the buffer's own comma/CR/LF total, for its result record
                     atomicAdd((unsigned long long*)&args.batch_tot[cur_item], (unsigned long long)(agg.a + agg.b));
             }
             // a shard whose entering state nobody knows: the first kGuessTiles tiles vote (see guess_vote)
-            if (uniform_again<(DIALECT >= 2 || BATCH)>(inq_in) == kEnterGuess && have_cur && tile < kGuessTiles && !(DBG & 4))
+            if (uniform_again<(DIALECT >= 2 || BATCH)>(inq_in) == kEnterGuess && have_cur && !redo && tile < kGuessTiles && !(DBG & 4)) {
                 guess_vote(args.desc, args.ctl, args.num_tiles, epoch, lane, err);
+                // This workgroup now holds two counted tiles and the held one cannot be resolved before the choice exists.
+                // Waiting for it here assumes that the voters still missing are being counted by OTHER resident workgroups
+                // (rounds 2-4: a GUESS launch needed 4 — dense geometry: 16 — of its workgroups resident at once, and a launch
+                // squeezed in beside other contexts' grids ended in the spin bound).  Instead: the HELD tile is OWED — its
+                // aggregate is out, its vote is in, its masks are dropped (the tile just counted takes its place as usual) —
+                // and the workgroup draws the next ticket, i.e. the next voter: a grid of ONE workgroup completes the vote by
+                // itself.  Tiles behind the voters wait for the choice as before: every voter ticket was drawn before
+                // theirs, by a running workgroup.
+                if (have_held &&
+                    (u32)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&args.ctl->guess, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+                    defer = true;
+                    if (lane == 0) {
+                        const u32 k = s_owed_n;
+                        s_owed[k] = held_tile;
+                        s_owed_n = k + 1u;
+                    }
+                }
+            }
+            // (GUESS launches) what this iteration does with the held tile, for every wave behind barrier B — and for this
+            // wave's own resolve below
+            if (!BATCH && uniform_again<true>(inq_in) == kEnterGuess && lane == 0) s_pin = defer ? kPinDeferred : 0u;
             // into wave 0's second stage image: idle until the next count phase
-            if (have_held && !(DBG & 4)) lookback_issue(args.desc, held_tile, lane, s_lookback_win());
+            if (have_held && !defer && !(DBG & 4)) lookback_issue(args.desc, held_tile, lane, s_lookback_win());
+            if (redo && lane == 0) s_redo = 0;
         }
         bool spec_done = false;
         const u32 spec_pin = held_agg.b > held_agg.a ? 1u : 0u;      // the guess: the hypothesis with more entries
@@ -1660,7 +1731,9 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
             CSVSIMD_TRACEX(2, held_tile, 0, __builtin_amdgcn_s_memrealtime())
             CSVSIMD_TRACEX(4, held_tile, kWaves - 1, __builtin_amdgcn_s_memrealtime())
         }
-        if (w == 0 && have_held) {
+        if (w == 0 && have_held &&
+            !(!BATCH && uniform_again<true>(inq_in) == kEnterGuess &&
+              (u32)__builtin_amdgcn_readfirstlane((int)s_pin) == kPinDeferred)) {
             u32 pin = 0;
             u64 base = 0;
             if (!(DBG & 4)) {
@@ -1711,7 +1784,9 @@ __global__ CSVSIMD_LAUNCH_BOUNDS void stage1_kernel(const KernelArgs args) {
         CSVSIMD_STAMP(4)
         if (have_held) { CSVSIMD_TRACE(4, held_tile) }
         if (have_held) { CSVSIMD_TRACEX(5, held_tile, kWaves - 1, __builtin_amdgcn_s_memrealtime()) }
-        if (EMIT && have_held) {
+        // (s_pin == kPinDeferred, GUESS launches only: the held tile is owed — nothing was resolved, nothing is emitted, the tile
+        // counted in this iteration becomes the held one as always)
+        if (EMIT && have_held && (u32)__builtin_amdgcn_readfirstlane((int)s_pin) != kPinDeferred) {
             // pacing knob, 0 by default since the per-CU token: a pause between barrier B and the flush
             for (u32 z = 0; z < args.emit_delay; ++z) __builtin_amdgcn_s_sleep(10);
             const u32 pin = s_pin;
@@ -1882,7 +1957,9 @@ static void fill_kernel_args(const Stage1Launch& L, KernelArgs& a) {
 }
 
 #ifdef CSVSIMD_DENSE_TU
-// the dense geometry's launcher: reference dialect, emitting launch (launch_stage1 of the other compilation hands over)
+// the dense geometry's launchers: an emitting launch of the reference dialect or of another delimiter / quote byte (no
+// escape byte), one buffer or — reference dialect — a batch (launch_stage1 / launch_stage1_batch of the other compilation
+// hand over)
 hipError_t launch_stage1_dense(const Stage1Launch& L, hipStream_t stream) {
     KernelArgs a;
     fill_kernel_args(L, a);
@@ -1890,11 +1967,36 @@ hipError_t launch_stage1_dense(const Stage1Launch& L, hipStream_t stream) {
     const u32 grid = want < L.max_blocks ? want : L.max_blocks;
     hipError_t e;
     if (L.ev_begin && (e = hipEventRecord(L.ev_begin, stream)) != hipSuccess) return e;
-    hipLaunchKernelGGL((stage1_kernel<true, 0, 0, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);
+    if (L.delimiter != ',' || L.quote != '"')
+        hipLaunchKernelGGL((stage1_kernel<true, 0, 1, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);
+    else
+        hipLaunchKernelGGL((stage1_kernel<true, 0, 0, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (L.ev_end && (e = hipEventRecord(L.ev_end, stream)) != hipSuccess) return e;
     return hipSuccess;
+}
+// (first_tile of every buffer counts tiles of THIS geometry: CSVSIMD_MIN_TILE_BYTES)
+hipError_t launch_stage1_batch_dense(void* d_items, void* d_first_tiles, void* d_tots, u32 n_items, u32 total_tiles,
+                                     csvsimd_shard_result* d_results, void* scratch_base, u64* scratch_desc, u32 max_blocks,
+                                     hipStream_t stream) {
+    static_assert(kTileBytes == CSVSIMD_MIN_TILE_BYTES, "the host lays a dense batch out in tiles of this size");
+    KernelArgs a = {};
+    a.num_tiles = total_tiles;
+    a.desc = scratch_desc;
+    a.ctl = reinterpret_cast<Control*>(scratch_base);
+    a.result = d_results;
+    a.batch = reinterpret_cast<const BatchItem*>(d_items);
+    a.batch_first = reinterpret_cast<const u32*>(d_first_tiles);
+    a.batch_tot = reinterpret_cast<u64*>(d_tots);
+    a.n_items = n_items;
+    a.count_prio = 1u;
+    a.cu_token = reinterpret_cast<u32*>(reinterpret_cast<char*>(scratch_base) + CSVSIMD_SCRATCH_TOKEN_OFFSET);
+    a.token_mode = 1u;
+    const u32 want = total_tiles ? total_tiles : 1u;
+    const u32 grid = want < max_blocks ? want : max_blocks;
+    hipLaunchKernelGGL((stage1_kernel<true, 0, 0, true, true>), dim3(grid), dim3(kThreads), 0, stream, a);
+    return hipGetLastError();
 }
 }  // namespace csvsimd_dense
 #else
@@ -2178,8 +2280,8 @@ bool dialect_hash(u32 delim, u32 quote, u32 esc, DialectHash& h) {
 }
 
 hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream) {
-    // delimiter-dense data, reference dialect, emitting launch: the other geometry (stage1_dense.hip)
-    if (L.dense && L.dtape && !L.escape && L.delimiter == ',' && L.quote == '"' && L.debug_mode == 0)
+    // delimiter-dense data, emitting launch, no escape byte: the other geometry (stage1_dense.hip)
+    if (L.dense && L.dtape && !L.escape && L.debug_mode == 0)
         return csvsimd_dense::launch_stage1_dense(L, stream);
     KernelArgs a;
     fill_kernel_args(L, a);
@@ -2270,6 +2372,7 @@ const char* stage1_kernel_name(bool emit, int dialect, bool dense) {
          "void csvsimd::stage1_kernel<true, 0, 2, false, false>(csvsimd::KernelArgs)",
          "void csvsimd::stage1_kernel<true, 0, 3, false, false>(csvsimd::KernelArgs)"}};
     if (emit && dense && dialect == 0) return "void csvsimd_dense::stage1_kernel<true, 0, 0, false, true>(csvsimd_dense::KernelArgs)";
+    if (emit && dense && dialect == 1) return "void csvsimd_dense::stage1_kernel<true, 0, 1, false, true>(csvsimd_dense::KernelArgs)";
     return names[emit ? 1 : 0][dialect < 0 || dialect > 3 ? 0 : dialect];
 }
 

@@ -323,10 +323,16 @@ hipError_t launch_trim_spans(const void* dbytes, void* d_begin, void* d_end, u64
 // ---------------------------------------------------------------------------------------------
 typedef uint32_t u32x4t __attribute__((ext_vector_type(4)));
 typedef uint64_t u64x2t __attribute__((ext_vector_type(2)));
+// The kernel is also the chunk's PUBLISHER (round 5): its last workgroup to finish copies the chunk's 64-byte result record
+// into pinned host memory and then stores the chunk's sequence number behind it, which the host polls — no copy-out, no
+// event.  Order: every thread's stores to the slot, system-scope fence, workgroup barrier, one arrival per workgroup on a
+// device counter (atomicInc wraps it back to 0 for the next chunk); the last arrival writes record, fence, sequence word.
+// Posted writes of one device reach host memory in order, and the fences keep them in order on the way to the link.
 __global__ __launch_bounds__(256) void narrow_tape_kernel(const u64* __restrict__ tape, const csvsimd_shard_result* __restrict__ res,
-                                                          u64 cap, u64 base, u32* __restrict__ out) {
+                                                          u64 cap, u64 base, u32* __restrict__ out, u64* __restrict__ h_rec,
+                                                          u64 seq, u32* __restrict__ arrivals) {
     const u64 count = res->count;
-    const u64 n = count < cap ? count : cap;
+    const u64 n = (out && count < cap) ? count : (out ? cap : 0);
     const u64 n4 = n / 4;
     for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < n4; j += (u64)gridDim.x * blockDim.x) {
         const u64x2t a = __builtin_nontemporal_load(reinterpret_cast<const u64x2t*>(tape) + 2 * j);
@@ -335,14 +341,30 @@ __global__ __launch_bounds__(256) void narrow_tape_kernel(const u64* __restrict_
         reinterpret_cast<u32x4t*>(out)[j] = v;
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) out[4 * n4 + threadIdx.x] = (u32)(tape[4 * n4 + threadIdx.x] - base);
+    if (!h_rec) return;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const u32 old = atomicInc(arrivals, gridDim.x - 1);  // ((old >= gridDim.x - 1) ? 0 : old + 1)
+        if (old == gridDim.x - 1) {
+            __threadfence_system();
+            const u64* r = reinterpret_cast<const u64*>(res);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) h_rec[i] = r[i];
+            __threadfence_system();
+            __hip_atomic_store(h_rec + 8, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 hipError_t launch_narrow_tape(const void* d_tape, const void* d_result, u64 cap, u64 base, void* d_out, int workgroups,
-                              hipStream_t stream) {
+                              hipStream_t stream, void* h_rec_dev, u64 seq, void* d_arrivals) {
     // 16-byte aligned tape and slot (hipMalloc / hipHostMalloc); the caller sizes the grid to the bytes it expects
-    // (capi.cpp: the writes cross PCIe against the H2D copies' read requests, and are better trickled than dumped)
+    // (capi.cpp: the writes cross PCIe against the H2D copies' read requests, and are better trickled than dumped).
+    // d_out == nullptr: nothing to pack (a count-only call): the launch only publishes the record.
+    static_assert(sizeof(csvsimd_shard_result) == 64, "the publisher copies eight 64-bit words");
     hipLaunchKernelGGL(narrow_tape_kernel, dim3((u32)(workgroups > 0 ? workgroups : 1)), dim3(256), 0, stream, (const u64*)d_tape,
-                       (const csvsimd_shard_result*)d_result, cap, base, (u32*)d_out);
+                       (const csvsimd_shard_result*)d_result, cap, base, (u32*)d_out, (u64*)h_rec_dev, seq, (u32*)d_arrivals);
     return hipGetLastError();
 }
 

@@ -86,13 +86,11 @@ typedef struct csvsimd_shard_result {
  * outside strings looks quoted and nearly every separator disappears — and reports the choice in in_quote_in_used.  `count`, `in_quote_out` and the tape are those of that
  * state; the two hypothesis counts and quote_parity are state independent as always.  A wrong guess is found by the
  * stitch (csvsimd_stitch.reemit) and costs the re-emit launch, exactly like a wrong in_quote_in = 0 speculation.
- * Progress: tile 0 resolves only when the aggregates of the first eight tiles exist, and a workgroup counts at most two
- * tiles before it waits for that choice — so a GUESS launch needs FOUR of its workgroups resident at once (every other
- * launch makes progress with any resident prefix).  Alone on a GPU that always holds (the grid is two workgroups per
- * CU); a launch squeezed in beside several other contexts' persistent grids may wait for them, and if it waits past
- * the spin bound it ends with result.error set (CSVSIMD_ERR_INTERNAL) instead of hanging — run it again, or give
- * shards that share a GPU their entering state (csvsimd_stage1_index_multi's shards each own a share of the GPU's
- * slots in practice: tests/test_gpu_multi.py runs three at once). */
+ * Progress (round 5): a GUESS launch needs no particular number of resident workgroups.  A workgroup that holds a counted
+ * tile it cannot resolve yet, because the choice does not exist, gives that tile up (its aggregate and vote are in; it is
+ * counted again later) and draws the next ticket — the next voter — so even a grid of ONE workgroup completes the vote by
+ * itself (tests/test_gpu_guess_small_grid.py: 1 and 2 workgroups, both geometries, three contexts sharing the GPU).  Until
+ * round 4 the vote needed 4 (dense geometry: 16) workgroups of the launch resident at once. */
 #define CSVSIMD_ENTER_OUTSIDE 0u
 #define CSVSIMD_ENTER_INSIDE 1u
 #define CSVSIMD_ENTER_GUESS 2u
@@ -160,6 +158,30 @@ int csvsimd_stage1_bound(uint64_t len, uint64_t* max_entries);
 int csvsimd_stage1_index(csvsimd_ctx* ctx, const uint8_t* buf, uint64_t len, uint64_t* tape,
                          uint64_t tape_cap, uint64_t* tape_len, uint32_t* in_quote_out);
 
+/* ---- stage 1, MANY host buffers in one call (round 5) -------------------------------------------
+ * The reference's unit of work is a file (csv_simd::create, src/lib.rs:61-74; its own inputs, the .csv files under res/, are 96 to 623
+ * bytes).  One csvsimd_stage1_index call per small file pays a launch and a wait each (30 us against 1.3 us on one CPU
+ * core for res/sample.csv); this call indexes n files for one pipeline's worth of them: files are packed into pinned
+ * groups of up to 4 MiB, each group crosses PCIe as one copy and is indexed by ONE batched launch (every file a buffer of
+ * its own, entered outside a quoted string; a quote left open in one file does not leak into the next), tapes and records
+ * come back as the kernel's own stores.  Per item, exactly what csvsimd_stage1_index(buf, len, tape, tape_cap) would have
+ * produced: tape[0] = 0, then the structural offsets relative to buf[0]; tape_len = entries incl. the sentinel;
+ * status = CSVSIMD_OK, or CSVSIMD_ERR_TAPE_CAPACITY when tape_cap is too small (tape_len then holds the size needed and
+ * nothing past tape_cap was written).  tape == NULL, tape_cap == 0: count only.  Files above 1 MiB (and files with more
+ * than an entry per 4 bytes) take csvsimd_stage1_index's own path inside the call.  Returns CSVSIMD_OK,
+ * CSVSIMD_ERR_TAPE_CAPACITY if any item reported it (all others are complete), or an error that voids the whole call.
+ * Reference dialect.  items is read and written by the call; buffers and tapes stay the caller's. */
+typedef struct csvsimd_host_batch_item {
+    const uint8_t* buf;
+    uint64_t len;
+    uint64_t* tape;
+    uint64_t tape_cap;
+    uint64_t tape_len;      /* out */
+    uint32_t in_quote_out;  /* out */
+    int32_t status;         /* out */
+} csvsimd_host_batch_item;
+int csvsimd_stage1_index_batch(csvsimd_ctx* ctx, csvsimd_host_batch_item* items, uint32_t n_items);
+
 /* How csvsimd_stage1_index cuts a buffer of `len` bytes into the chunks it streams through the GPU (the host side owns
  * the chunking; reference: csv_simd::create maps the whole file and streaming is a TODO, src/lib.rs:61-74, README.md:23):
  * cuts[0] = 0 < cuts[1] < ... = len, chunk i = [cuts[i], cuts[i + 1]).  No chunk exceeds the 32-MiB slot, a large
@@ -222,6 +244,10 @@ int csvsimd_stage1_index_dialect(csvsimd_ctx* ctx, const csvsimd_dialect* dialec
  * from the records they read; a caller of the _async entry points, which return before any record exists, may say it.
  * csvsimd_ctx_kernel_name: the kernel the context's next emitting launch of `dialect` (NULL: the reference's) runs. */
 int csvsimd_ctx_hint_density(csvsimd_ctx* ctx, uint64_t entries, uint64_t bytes);
+/* Test / diagnostic knob (round 5): caps the grid of every following stage-1 launch of this context at n workgroups
+ * (0 = back to the default, two per CU).  Results never depend on it — every launch, CSVSIMD_ENTER_GUESS included, makes
+ * progress with any number of resident workgroups — which is what tests/test_gpu_guess_small_grid.py uses it to show. */
+int csvsimd_ctx_limit_workgroups(csvsimd_ctx* ctx, uint32_t n);
 const char* csvsimd_ctx_kernel_name(const csvsimd_ctx* ctx, const csvsimd_dialect* dialect);
 
 

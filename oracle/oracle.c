@@ -325,6 +325,28 @@ int oracle_sse_read_growing(const uint8_t* buf, uint64_t len, uint64_t** tape_ou
 
 void oracle_free(void* p) { free(p); }
 
+/* "ref_sse_1t" over MANY files, one after the other on one thread — what a caller of the reference does with a directory of
+ * small files (csv_simd::create per file, src/lib.rs:61-74): each file gets its own Vec seeded [0] and grown by doubling,
+ * exactly like oracle_sse_read_growing; the Vecs are kept until the end (the caller keeps its tapes) and freed outside the
+ * timed region by the caller of this function's wrapper.  counts[i] = entries of file i (sentinel included).  Returns the
+ * number of files processed.  Files shorter than 64 bytes are outside the reference's domain: skipped (count 0). */
+uint64_t oracle_sse_read_growing_many(const uint8_t* const* bufs, const uint64_t* lens, uint64_t n, uint64_t** tapes,
+                                      uint64_t* counts) {
+    uint64_t done = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        tapes[i] = NULL;
+        counts[i] = 0;
+        if (lens[i] < 64) continue;
+        u64vec acc = {(uint64_t*)malloc(4 * sizeof(uint64_t)), 0, 4, 0, 0};
+        if (!acc.ptr) break;
+        sse_read_into(bufs[i], lens[i], &acc);
+        tapes[i] = acc.ptr;
+        counts[i] = acc.len;
+        ++done;
+    }
+    return done;
+}
+
 /* ------------------------------------------------------------------------------------------
  * multi-threaded flavour ("ref_sse_mt"): the same SSE block loop on T contiguous
  * chunks.  NOT something the reference does (it is single-threaded); it shows what the host CPU

@@ -142,6 +142,28 @@ def sse_read_growing_timed(a: np.ndarray):
     return n.value, dt
 
 
+def sse_read_growing_many_timed(arrays):
+    """ref_sse_1t over many files on ONE thread (oracle_sse_read_growing_many): -> (entry counts, seconds).  The ctypes
+    arrays are prepared before the clock starts and the tapes freed after it stops."""
+    import time
+    n = len(arrays)
+    bufs = (C.c_void_p * n)(*[a.ctypes.data for a in arrays])
+    lens = (C.c_uint64 * n)(*[a.size for a in arrays])
+    tapes = (C.c_void_p * n)()
+    counts = (C.c_uint64 * n)()
+    fn = lib().oracle_sse_read_growing_many
+    fn.restype = C.c_uint64
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    t0 = time.perf_counter()
+    done = fn(bufs, lens, n, tapes, counts)
+    dt = time.perf_counter() - t0
+    assert done == sum(1 for a in arrays if a.size >= 64)
+    for p in tapes:
+        if p:
+            lib().oracle_free(C.c_void_p(p))
+    return list(counts), dt
+
+
 def sse_read_mt(data, threads: int) -> np.ndarray:
     a = aligned_copy(data)
     out = np.zeros(a.size + 2, dtype=np.uint64)

@@ -32,7 +32,7 @@ def test_header_symbols_all_exported(pkg):
 
 def test_abi_version_and_strerror(pkg):
     L = pkg.lib()
-    assert L.csvsimd_abi_version() == pkg.ABI_VERSION == 4
+    assert L.csvsimd_abi_version() == pkg.ABI_VERSION == 5
     assert L.csvsimd_strerror(-4).decode().startswith("Unsupported csv structure")  # src/error.rs:19
     assert L.csvsimd_strerror(-3).decode() == "Invalid state"                          # src/error.rs:17
     assert L.csvsimd_strerror(-2).decode() == "Missing a value"                        # src/error.rs:15

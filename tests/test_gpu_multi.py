@@ -83,3 +83,50 @@ def test_one_host_buffer_to_g_shards(pkg, oracle, g):
         assert err.value.code == pkg.ERR_INVALID_ARG
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.gpu
+def test_one_host_buffer_to_shards_on_distinct_devices(pkg, oracle):
+    """The same flow with every shard on ITS OWN GPU (device ordinals 0 .. G - 1): what csvsimd_stage1_index_multi is for.
+    Skipped on a one-GPU box; on the driver's 8-GPU node it runs with G = device_count (until then the
+    entry point had only ever seen `cuda:0`).  Tapes stay on their devices; the concatenation behind the sentinel is the
+    oracle's index of the whole buffer (reference reader::read, src/reader.rs:150-306)."""
+    import torch
+    g = min(pkg.device_count(), 8)
+    if g < 2:
+        pytest.skip("needs at least two GPUs in this process")
+    rng = np.random.default_rng(4242)
+    n = (96 << 20) + 1717
+    d = random_csvish(rng, n, 0.002)
+    ranges = [pkg.multi_shard_range(n, g, i) for i in range(g)]
+    c = ranges[1][0]
+    d[c - 100] = 0x22
+    d[c - 99: c + 100] = 0x2C
+    if int(np.count_nonzero(d[: c - 100] == 0x22) & 1):
+        d[c - 101] = 0x22                       # shard 1 starts inside a quoted field full of commas
+    want = oracle.scalar_read(d)
+    ctxs = [pkg.Context(i) for i in range(g)]
+    dbufs = [torch.zeros(max(e - b, 1), dtype=torch.uint8, device=f"cuda:{i}") for i, (b, e) in enumerate(ranges)]
+    caps = [(e - b) + 8 for b, e in ranges]
+    dtapes = [torch.full((cap,), -1, dtype=torch.int64, device=f"cuda:{i}") for i, cap in enumerate(caps)]
+    for i in range(g):
+        torch.cuda.synchronize(i)
+    dev_before = torch.cuda.current_device()
+    sh = pkg.stage1_index_multi(d, ctxs, [t.data_ptr() for t in dbufs], [t.data_ptr() for t in dtapes], caps, 0)
+    assert torch.cuda.current_device() == dev_before
+    parts, base, state = [np.zeros(1, dtype=np.uint64)], 1, 0
+    for i in range(g):
+        torch.cuda.synchronize(i)
+        b, e = ranges[i]
+        assert bytes(dbufs[i][: e - b].cpu().numpy()) == d[b:e].tobytes()
+        assert sh[i].stitch.tape_index_base == base and sh[i].stitch.in_quote_in == state
+        k = sh[i].result.count
+        assert sh[i].result.in_quote_in_used == state and k == sh[i].stitch.count and sh[i].result.written == k
+        parts.append(dtapes[i][:k].cpu().numpy().view(np.uint64))
+        base += k
+        state = sh[i].result.in_quote_out
+    got = np.concatenate(parts)
+    assert sh[g - 1].stitch.total_entries == want.size == got.size and np.array_equal(got, want)
+    assert sh[1].stitch.in_quote_in == 1
+    for c_ in ctxs:
+        c_.close()

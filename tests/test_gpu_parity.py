@@ -544,14 +544,21 @@ def test_host_ingest_three_threads_many_slot_reuses(pkg, oracle, monkeypatch):
         small = np.zeros(12345, dtype=np.uint64)
         rc, cnt, _ = c.read_into(d, small)
         assert rc == pkg.ERR_TAPE_CAPACITY and cnt == want.size and np.array_equal(small, want[:12345])
+        two = d[: 2 * chunk + 17]                                        # two chunks (the 17-byte stub is folded): everything
+        assert np.array_equal(c.read(two), oracle.scalar_read(two))      # in turn on the caller's thread
+        ph = pkg.ingest_last_phases()
+        assert ph["host_threads"] == 1 and ph["chunks"] == 2
         monkeypatch.delenv("CSVSIMD_INGEST_CHUNK_MIB")
-        two = d[: 2 * chunk + 17]                                        # two chunks: pipelined on the caller's thread
-        assert pkg.ingest_chunk_plan(two.size) == [0, chunk, two.size]
-        assert np.array_equal(c.read(two), oracle.scalar_read(two))
-        assert pkg.ingest_last_phases()["host_threads"] == 1
-        mid = d[7 * chunk - 5: 12 * chunk + 99]                          # 20 MiB: four chunks, two of them dense, three threads
-        assert np.array_equal(c.read(mid), oracle.scalar_read(mid))
-        assert pkg.ingest_last_phases()["host_threads"] == 3
+        mid = d[7 * chunk - 5: 12 * chunk + 99]                          # 20 MiB, the library's own plan (0.75 ... 8 ... 1.5 MiB):
+        assert np.array_equal(c.read(mid), oracle.scalar_read(mid))      # dense chunks among small ones, three threads
+        ph = pkg.ingest_last_phases()
+        assert ph["host_threads"] == 3 and ph["chunks"] == len(pkg.ingest_chunk_plan(mid.size)) - 1 >= 6
+        for lo, n_ in ((0, (1 << 20) + 1), (3 * chunk - 77, (2 << 20) + 4097), (8 * chunk - 5000, (4 << 20) + 1),
+                       (6 * chunk + 33, 8 << 20)):                       # a few MiB: 3 ... 8 chunks of 256 KiB ... 2 MiB
+            part = d[lo: lo + n_]
+            assert np.array_equal(c.read(part), oracle.scalar_read(part)), (lo, n_)
+            rc, cnt, q = c.read_into(part, None)
+            assert rc == 0 and cnt == oracle.scalar_read(part).size
         tiny = d[9 * chunk - 150: 9 * chunk + 150]
         assert np.array_equal(c.read(tiny), oracle.scalar_read(tiny))
         assert np.array_equal(c.read(d), want)                         # and the large file again after the small ones
