@@ -46,10 +46,11 @@ def test_product_library_has_no_probe_hooks(pkg):
     assert not pkg.build_has_probes()
     nm = subprocess.run(["nm", "-C", so], check=True, capture_output=True, text=True).stdout
     inst = sorted(set(re.findall(r"__device_stub__stage1_kernel<(\w+), (\d+), (\d+), (\w+), (\w+)>", nm)))
-    # emit / count-only x four dialect classifications, DBG always 0; + the batched launch and the dense-emit instantiation
-    # (reference dialect, emit)
+    # emit / count-only x four dialect classifications, DBG always 0; + the batched launch; + the dense-emit instantiations
+    # (emit only: reference dialect — one buffer or a batch — and another delimiter / quote byte)
     assert inst == sorted([(e, "0", d, "false", "false") for e in ("false", "true") for d in ("0", "1", "2", "3")]
-                          + [("true", "0", "0", "true", "false"), ("true", "0", "0", "false", "true")]), inst
+                          + [("true", "0", "0", "true", "false"), ("true", "0", "0", "false", "true"),
+                             ("true", "0", "0", "true", "true"), ("true", "0", "1", "false", "true")]), inst
     raw = open(so, "rb").read()
     assert b"CSVSIMD_PROBE" not in raw and b"zero_kernel" not in raw and b"finalize_kernel" not in raw
     # what bench.py reports as the timed kernel comes from the library, and is the default instantiation
