@@ -989,6 +989,82 @@ def batch_leg(pkg, device, k=8):
             "verified": ok}
 
 
+def back_to_back_leg(pkg, device, k=8, reps=6):
+    """k consecutive 1-GiB files (the 16x32 corpus, config 2's shape), one stage-1 launch each, WITHOUT the batch API:
+    (a) one context, one stream — every launch pays its ~20 us of fill and drain alone (the 1-GiB configurations' 60 %);
+    (b) two contexts (two control blocks, two look-back scratch areas) alternating on two streams of DIFFERENT priority, i.e.
+    two hardware queues: launch i + 1 is resident-ready while launch i drains, its workgroups take the wave slots the
+    drain frees.  Times = events around reps x k launches after a settle; every tape checked against the closed form."""
+    name = "16x32_noquote"
+    cols, width, seed, q = pkg.WORKLOADS[name]
+    per = pkg.workload_len(name, 1 << 30)
+    pitch = width + 1
+    dbuf = torch.empty(k * per, dtype=torch.uint8, device=device)
+    pkg.synth_fill_device(dbuf.data_ptr(), 0, k * per, cols, width, seed, q)
+    cap = per // pitch + 64
+    tapes = [torch.empty(cap, dtype=torch.int64, device=device) for _ in range(k)]
+    dres = torch.zeros((k, 8), dtype=torch.int64, device=device)
+    ctxs = [pkg.Context(device.index), pkg.Context(device.index)]
+    for c in ctxs:
+        c.reserve(per)
+    s_main = torch.cuda.current_stream(device)
+    s_hi = torch.cuda.Stream(device=device, priority=-1)
+
+    def one_queue():
+        for i in range(k):
+            ctxs[0].stage1_index_device_async(dbuf.data_ptr() + i * per, per, 0, 0, tapes[i].data_ptr(), cap, dres[i].data_ptr(),
+                                              s_main.cuda_stream)
+
+    def two_queues():
+        for i in range(k):
+            st = s_hi if (i & 1) else s_main
+            ctxs[i & 1].stage1_index_device_async(dbuf.data_ptr() + i * per, per, 0, 0, tapes[i].data_ptr(), cap, dres[i].data_ptr(),
+                                                  st.cuda_stream)
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(device)
+        best = None
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_hi.wait_stream(s_main)
+            e0.record(s_main)
+            for _ in range(reps):
+                fn()
+            s_main.wait_stream(s_hi)
+            e1.record(s_main)
+            e1.synchronize()
+            ms = e0.elapsed_time(e1) / (reps * k)
+            best = ms if best is None else min(best, ms)
+        return best
+
+    def verify():
+        torch.cuda.synchronize(device)
+        want = torch.arange(1, per // pitch + 1, dtype=torch.int64, device=device) * pitch - 1
+        ok = True
+        for i in range(k):
+            w = dres[i].cpu().tolist()
+            ok = ok and w[0] == per // pitch and (w[4] & 0xFFFFFFFF) == 0 and torch.equal(tapes[i][: per // pitch], want)
+        return bool(ok)
+
+    ms_one = timed(one_queue)
+    ok = verify()
+    for t in tapes:
+        t.zero_()
+    ms_two = timed(two_queues)
+    ok = ok and verify()
+    for c in ctxs:
+        c.close()
+    frac = lambda ms: round(per / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+    return {"files": k, "bytes_per_file": per, "workload": name,
+            "one_context_one_queue": {"ms_per_file": round(ms_one, 4), "hbm_read_frac": frac(ms_one)},
+            "two_contexts_two_queues": {"ms_per_file": round(ms_two, 4), "hbm_read_frac": frac(ms_two)},
+            "gain": round(ms_one / ms_two, 4), "verified": ok,
+            "note": "aggregate over consecutive launches (events around %d x %d launches): what a caller indexing file after file "
+                    "sees; two contexts on two hardware queues let a launch's fill overlap its predecessor's drain" % (reps, k)}
+
+
 def dense_ceiling(sb):
     """What bare streams reach with the dense corpus's write share (1.6 B of tape per byte read), next to an
     INDEPENDENT yardstick: a plain copy — hipMemcpyDtoD and the textbook one-16-byte-element-per-thread
@@ -1154,6 +1230,7 @@ def main():
     ap.add_argument("--only-batch", action="store_true", help="development: run the `batch_many_files` leg alone")
     ap.add_argument("--only-latency", action="store_true", help="development: run the `latency` leg alone")
     ap.add_argument("--only-small-files", action="store_true", help="development: run the `small_files` leg alone")
+    ap.add_argument("--only-back-to-back", action="store_true", help="development / profiling: run the `back_to_back_1GiB` leg alone")
     ap.add_argument("--only-consumers", action="store_true",
                     help="development / profiling: run the `consumers` leg alone and print its record (not the "
                          "contract line)")
@@ -1219,6 +1296,9 @@ def main():
         return
     if args.only_latency:
         print(json.dumps({"latency": latency_leg(pkg, oracle or graft.load_oracle(), device)}))
+        return
+    if args.only_back_to_back:
+        print(json.dumps({"back_to_back_1GiB": back_to_back_leg(pkg, device)}))
         return
     if args.only_small_files:
         print(json.dumps({"small_files": small_files_leg(pkg, oracle or graft.load_oracle(), device)}))
@@ -1404,6 +1484,8 @@ def main():
             out["batch_many_files"] = batch_leg(pkg, device)
             out["batch_many_files"]["at_8_GiB_per_batch"] = batch_leg(pkg, device, k=64)
             failed = failed or not (out["batch_many_files"]["verified"] and out["batch_many_files"]["at_8_GiB_per_batch"]["verified"])
+            out["back_to_back_1GiB"] = back_to_back_leg(pkg, device)
+            failed = failed or not out["back_to_back_1GiB"]["verified"]
             out["consumers"] = consumers_leg(pkg, oracle, device)
             failed = failed or not out["consumers"]["verified"]
         if not args.no_ingest:

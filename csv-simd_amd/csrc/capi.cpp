@@ -741,6 +741,18 @@ int csvsimd_stage1_index_device(csvsimd_ctx* ctx, const void* dbuf, uint64_t len
                                 csvsimd_shard_result* result, void* hip_stream) {
     if (!ctx || !result) return CSVSIMD_ERR_INVALID_ARG;
     WITH_DEVICE_OF(ctx);
+    // A context that knows nothing about its data yet (no earlier synchronous call, no ingest, no hint) looks before it
+    // chooses the instantiation: sixteen 64-KiB windows of the buffer, bytes equal to ',', CR or LF (text_kernels.hip).
+    // ~20 us, once per context; buffers below 8 MiB are not worth it (the instantiations differ by microseconds there).
+    // The asynchronous entry point never does this (it may not synchronise): it runs the default geometry until told or
+    // until a synchronous call / an ingest on the same context has seen the data.
+    if (ctx->density < 0 && dbuf && dtape && len >= (8ull << 20)) {
+        HIP_TRY(csvsimd::launch_density_sample(dbuf, len, ',', ctx->d_small, (hipStream_t)hip_stream));
+        HIP_TRY(hipMemcpyAsync(ctx->h_small, ctx->d_small, 16, hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
+        HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
+        const uint64_t* s2 = (const uint64_t*)ctx->h_small;
+        if (s2[1]) ctx->density = (double)s2[0] / (double)s2[1];
+    }
     int rc = csvsimd_stage1_index_device_async(ctx, dbuf, len, base_off, in_quote_in, dtape, tape_cap,
                                                ctx->d_result, hip_stream);
     if (rc != CSVSIMD_OK) return rc;
@@ -1019,6 +1031,19 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
     // copies behind it stall (measured on 2 GiB of the 64-column corpus: 49.8 GiB/s with 256 workgroups, 50.4 with one,
     // 51.5 with no tape at all).  One workgroup per 2 MiB of offsets keeps up with the link many times over.
     double entries_per_byte = 1.0 / 32.0;
+    // a context that has not seen its data yet: sixteen 4-KiB windows of the caller's buffer, bytes equal to the delimiter,
+    // CR or LF — the first chunk's launch then already runs the instantiation the file's density asks for
+    if (ctx->density < 0 && len >= (8ull << 20)) {
+        const uint8_t dl = dialect ? dialect->delimiter : (uint8_t)',';
+        uint64_t hits = 0, seen = 0;
+        for (int wdw = 0; wdw < 16; ++wdw) {
+            const uint8_t* p = buf + ((len - 4096) / 15) * (uint64_t)wdw;
+            for (int i = 0; i < 4096; ++i) hits += (p[i] == dl) | (p[i] == 0x0a) | (p[i] == 0x0d);
+            seen += 4096;
+        }
+        ctx->density = (double)hits / (double)seen;
+        entries_per_byte = std::max(ctx->density, 1.0 / 256.0);
+    }
     constexpr int h2d_streams = 2;
     const std::vector<uint64_t> cuts = ingest_chunk_plan(len, uniform);  // chunk i = [cuts[i], cuts[i + 1])
     const uint64_t nchunks = cuts.size() - 1;

@@ -969,10 +969,134 @@ __global__ __launch_bounds__(256) void colsearch_kernel(const ColView c, const u
     if (trunc) atomicAdd((unsigned long long*)truncated, (unsigned long long)trunc);
 }
 
+// ---- rows of 16 or 32 bytes (round 5) ----------------------------------------------------------------------------------------
+// The kernel above reads a row eight bytes at a time, three dword loads per step and lane: on a 1-GiB column it is bound by
+// the number of load instructions, not by HBM (profiles/r05_consumers_1GiB_before.json).  Here a lane fetches its whole row
+// with one or two 16-byte loads — the NEXT batch of rows is requested before this one is searched — and searches it in
+// registers: `contains` finds the start positions whose first two bytes are the needle's by an exact zero-byte test on
+// eight positions at a time (x ^ pattern has a zero byte <=> ((x & 0x7f..) + 0x7f..) | x has bit 7 clear there), and only
+// those — one position in 65 536 on random text — are compared in full, from the row's cache line.  Same results, bit for
+// bit (tests/test_gpu_columnar.py runs both on every case).
+__device__ __forceinline__ u64 zero_bytes(u64 x) {  // bit 7 of every byte of x that is zero
+    const u64 k7 = 0x7f7f7f7f7f7f7f7full;
+    return ~(((x & k7) + k7) | x | k7);
+}
+template <u32 STRIDE>
+__global__ __launch_bounds__(256) void colsearch_small_kernel(const ColView c, const uint8_t* __restrict__ needle, u32 m, int mode,
+                                                              u64* __restrict__ bitmap, u64* __restrict__ count,
+                                                              u64* __restrict__ truncated) {
+    static_assert(STRIDE == 16 || STRIDE == 32, "rows that fit one or two 16-byte loads");
+    constexpr u32 W = STRIDE / 8;  // 64-bit words per row
+    __shared__ u64 s_needle[kColMaxNeedle / 8 + 1];
+    for (u32 k = threadIdx.x; k < kColMaxNeedle / 8 + 1; k += blockDim.x) {
+        u64 w = 0;
+        for (u32 j = 0; j < 8; ++j)
+            if (8 * k + j < m) w |= (u64)needle[8 * k + j] << (8 * j);
+        s_needle[k] = w;
+    }
+    __syncthreads();
+    const u64 n_words = (c.n_rows + 63) / 64;
+    const u32 lane = threadIdx.x & 63u;
+    u64 nd[W];  // the needle's first STRIDE bytes, masked to m
+#pragma unroll
+    for (u32 k = 0; k < W; ++k) nd[k] = s_needle[k];
+    u64 nmask[W];
+#pragma unroll
+    for (u32 k = 0; k < W; ++k) nmask[k] = m >= 8 * k + 8 ? ~0ull : (m > 8 * k ? (1ull << (8 * (m - 8 * k))) - 1ull : 0ull);
+    const u64 b0 = (nd[0] & 0xffull) * 0x0101010101010101ull, b1 = ((nd[0] >> 8) & 0xffull) * 0x0101010101010101ull;
+    u32 hits = 0, trunc = 0;
+    const u64 step = ((u64)gridDim.x * blockDim.x) >> 6;
+    u64 word = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    // the batch in flight: this lane's row and its length
+    u32x4c va = {0, 0, 0, 0}, vb = {0, 0, 0, 0};
+    u32 vlen = STRIDE;
+    auto fetch = [&](u64 wd) {
+        const u64 i = wd * 64 + lane;
+        if (wd < n_words && i < c.n_rows) {
+            const u32x4c* const p = reinterpret_cast<const u32x4c*>(c.col + i * STRIDE);
+            va = __builtin_nontemporal_load(p);
+            if (STRIDE == 32) vb = __builtin_nontemporal_load(p + 1);
+            vlen = c.len ? __builtin_nontemporal_load(c.len + i) : STRIDE;
+        }
+    };
+    fetch(word);
+    for (; word < n_words; word += step) {
+        const u32x4c ra = va, rb = vb;
+        const u32 full = vlen;
+        fetch(word + step);  // (the loads of the next batch are in flight while this one is searched)
+        const u64 i = word * 64 + lane;
+        bool match = false;
+        if (i < c.n_rows) {
+            if (full > STRIDE) ++trunc;
+            const u32 n = full < STRIDE ? full : STRIDE;
+            u64 r[W + 1];
+            r[0] = ((u64)ra.y << 32) | ra.x;
+            r[1] = ((u64)ra.w << 32) | ra.z;
+            if (STRIDE == 32) {
+                r[2] = ((u64)rb.y << 32) | rb.x;
+                r[3] = ((u64)rb.w << 32) | rb.z;
+            }
+            r[W] = 0;
+            if (mode != 2) {
+                match = m <= STRIDE && (mode == 0 ? n == m : n >= m);
+#pragma unroll
+                for (u32 k = 0; k < W; ++k) match = match && ((r[k] ^ nd[k]) & nmask[k]) == 0;
+            } else if (m == 0) {
+                match = true;
+            } else if (n >= m) {
+                const u32 last = n - m;  // last start position
+                u64 found = 0;
+#pragma unroll
+                for (u32 k = 0; k < W; ++k) {
+                    u64 cand = zero_bytes(r[k] ^ b0);
+                    if (m >= 2) cand &= zero_bytes(((r[k] >> 8) | (r[k + 1] << 56)) ^ b1);
+                    // positions 8k .. 8k + 7 that may start a match: <= last
+                    const u64 keep = last >= 8 * k + 7 ? ~0ull : (last >= 8 * k ? (1ull << (8 * (last - 8 * k + 1))) - 1ull : 0ull);
+                    cand &= keep;
+                    if (m <= 2) {
+                        found |= cand;
+                    } else {
+                        while (cand && !found) {  // rare: both leading bytes agree — the rest, from the row's cache line
+                            const u32 pos = 8 * k + ((u32)__builtin_ctzll(cand) >> 3);
+                            cand &= cand - 1;
+                            const uint8_t* const row = c.col + i * STRIDE;
+                            bool ok = true;
+                            for (u32 q = 0; 8 * q < m && ok; ++q) {
+                                const u32 left = m - 8 * q;
+                                const u64 mask = left >= 8 ? ~0ull : ((1ull << (8 * left)) - 1ull);
+                                ok = ((col_load8(row, pos + 8 * q, STRIDE) ^ s_needle[q]) & mask) == 0;
+                            }
+                            if (ok) found = 1;
+                        }
+                    }
+                }
+                match = found != 0;
+            }
+        }
+        const u64 bits = __ballot(match);
+        if (lane == 0) {
+            bitmap[word] = bits;
+            hits += (u32)__builtin_popcountll(bits);
+        }
+    }
+    if (lane == 0 && hits) atomicAdd((unsigned long long*)count, (unsigned long long)hits);
+    if (trunc) atomicAdd((unsigned long long*)truncated, (unsigned long long)trunc);
+}
+
 hipError_t launch_colsearch(const void* d_col, const void* d_len, u64 n_rows, u32 stride, const void* d_needle,
                             u32 needle_len, int mode, void* d_bitmap, void* d_count, void* d_truncated, hipStream_t stream) {
     if (n_rows == 0) return hipSuccess;
     const ColView c = {(const uint8_t*)d_col, (const u32*)d_len, n_rows, stride};
+    // rows of 16 / 32 bytes and a needle that fits the row: the register-resident search.  A persistent-sized grid (8
+    // workgroups per CU) whose waves walk the column with one batch of loads in flight each.
+    const bool small = (stride == 16 || stride == 32) && needle_len <= stride;
+    if (small && stride == 32)
+        hipLaunchKernelGGL(colsearch_small_kernel<32>, dim3(cgrid_for(n_rows, 256, 2048)), dim3(256), 0, stream, c,
+                           (const uint8_t*)d_needle, needle_len, mode, (u64*)d_bitmap, (u64*)d_count, (u64*)d_truncated);
+    else if (small)
+        hipLaunchKernelGGL(colsearch_small_kernel<16>, dim3(cgrid_for(n_rows, 256, 2048)), dim3(256), 0, stream, c,
+                           (const uint8_t*)d_needle, needle_len, mode, (u64*)d_bitmap, (u64*)d_count, (u64*)d_truncated);
+    else
     hipLaunchKernelGGL(colsearch_kernel, dim3(cgrid_for(n_rows, 256, 8192)), dim3(256), 0, stream, c,
                        (const uint8_t*)d_needle, needle_len, mode, (u64*)d_bitmap, (u64*)d_count, (u64*)d_truncated);
     return hipGetLastError();

@@ -160,6 +160,8 @@ hipError_t launch_trim_spans(const void* dbytes, void* d_begin, void* d_end, uin
 // device-visible host address; d_arrivals = a zeroed u32 the launch leaves zeroed
 hipError_t launch_narrow_tape(const void* d_tape, const void* d_result, uint64_t cap, uint64_t base, void* d_out, int workgroups,
                               hipStream_t stream, void* h_rec_dev = nullptr, uint64_t seq = 0, void* d_arrivals = nullptr);
+// 16 x 64 KiB of the buffer: d_out2[0] += bytes equal to the delimiter, CR or LF, d_out2[1] += bytes looked at (both zeroed first)
+hipError_t launch_density_sample(const void* dbuf, uint64_t len, uint32_t delimiter, void* d_out2, hipStream_t stream);
 int stage1_max_blocks_per_cu();
 
 }  // namespace csvsimd

@@ -357,6 +357,42 @@ __global__ __launch_bounds__(256) void narrow_tape_kernel(const u64* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Which instantiation for data nobody has seen yet?  Sixteen 64-KiB windows spread over the buffer, one workgroup each:
+// bytes equal to the delimiter, CR or LF (quotes ignored: an upper bound of the entries, close enough to put the data on
+// one side of 0.125 entries per byte).  1 MiB read: a few microseconds, once per context (capi.cpp: the synchronous device
+// entry point of a context that knows nothing about its data yet).
+// ---------------------------------------------------------------------------------------------
+constexpr u32 kSampleWindows = 16, kSampleBytes = 64u << 10;
+__global__ __launch_bounds__(256) void density_sample_kernel(const uint8_t* __restrict__ buf, u64 len, u32 delim4, unsigned long long* __restrict__ out) {
+    const u64 span = len > kSampleBytes ? len - kSampleBytes : 0;
+    const u64 start = ((span / (kSampleWindows - 1)) * blockIdx.x) & ~(u64)3;   // (dword loads: any 4-byte aligned start)
+    const uintptr_t mis = (uintptr_t)buf & 3u;
+    const uint8_t* const base = buf + start + (mis ? 4 - mis : 0);
+    const u64 avail = (buf + len) - base;
+    const u32 words = (u32)((avail < kSampleBytes ? avail : kSampleBytes) / 4);
+    u32 cnt = 0;
+    for (u32 i = threadIdx.x; i < words; i += blockDim.x) {
+        const u32 x = reinterpret_cast<const u32*>(base)[i];
+        // zero-byte test of x ^ pattern for the three bytes (exact per byte: (y - 0x01..) & ~y & 0x80.. over-reports only
+        // above a true zero byte, which a count used as a threshold can live with)
+        const u32 a = x ^ delim4, b = x ^ 0x0a0a0a0au, c = x ^ 0x0d0d0d0du;
+        const u32 z = (((a - 0x01010101u) & ~a) | ((b - 0x01010101u) & ~b) | ((c - 0x01010101u) & ~c)) & 0x80808080u;
+        cnt += (u32)__builtin_popcount(z);
+    }
+    for (int d = 32; d > 0; d >>= 1) cnt += (u32)__shfl_xor((int)cnt, d);
+    if ((threadIdx.x & 63u) == 0 && cnt) atomicAdd(out, (unsigned long long)cnt);
+    if (threadIdx.x == 0) atomicAdd(out + 1, (unsigned long long)words * 4ull);
+}
+
+hipError_t launch_density_sample(const void* dbuf, u64 len, u32 delimiter, void* d_out2, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(d_out2, 0, 16, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(density_sample_kernel, dim3(kSampleWindows), dim3(256), 0, stream, (const uint8_t*)dbuf, len,
+                       delimiter * 0x01010101u, (unsigned long long*)d_out2);
+    return hipGetLastError();
+}
+
 hipError_t launch_narrow_tape(const void* d_tape, const void* d_result, u64 cap, u64 base, void* d_out, int workgroups,
                               hipStream_t stream, void* h_rec_dev, u64 seq, void* d_arrivals) {
     // 16-byte aligned tape and slot (hipMalloc / hipHostMalloc); the caller sizes the grid to the bytes it expects

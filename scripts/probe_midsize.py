@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """dev tool (round 5): where a mid-size csvsimd_stage1_index call spends its time: best-of-N wall time and the phase record of
 that call, 1 ... 64 MiB, one kept context."""
-import json, os, sys, time
+import faulthandler, json, os, sys, time
 import numpy as np
+faulthandler.dump_traceback_later(int(os.environ.get("PROBE_WATCHDOG", "90")), exit=True)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as graft
@@ -13,11 +14,13 @@ cols, width, seed, q = pkg.WORKLOADS["16x32_q10"]
 sizes = [int(s) << 20 for s in (sys.argv[1].split(",") if len(sys.argv) > 1 else "1,2,4,8,16,32,64,256".split(","))]
 out = {}
 for n in sizes:
+    print("size", n, file=sys.stderr, flush=True)
     host = oracle.aligned_copy(oracle.synth(0, n, cols, width, seed, q))
     tape = np.zeros(host.size // 8 + 64, dtype=np.uint64)
     want = oracle.sse_read(host)
-    for _ in range(3):
+    for w_ in range(3):
         rc, tl, _ = ctx.read_into(host, tape)
+        print(" warm", w_, rc, tl, file=sys.stderr, flush=True)
     assert rc == 0 and tl == want.size and np.array_equal(tape[:tl], want), n
     best, ph, ts = None, None, []
     for _ in range(40 if n <= (32 << 20) else 10):

@@ -276,3 +276,48 @@ def test_synthetic_corpus_all_columns_at_once(ctx, pkg, torch_cuda):
     assert got == nrec and bool((lens == width).all())
     table = dbytes.view(rows, cols_, width + 1)[1:, :, :width]           # row-major: record, column, byte
     assert torch.equal(out, table.permute(1, 0, 2).contiguous())
+
+
+@pytest.mark.parametrize("stride", [16, 32])
+def test_columnar_search_on_16_and_32_byte_rows(ctx, pkg, torch_cuda, stride):
+    """Rows of 16 / 32 bytes take the register-resident kernel (round 5): every mode, needles of every length 0 ... stride + 1
+    at every position of a row, rows of every length 0 ... stride over a three-letter alphabet (partial matches everywhere),
+    with and without a lengths array — bit for bit what Python's ==, startswith and `in` say about the same bytes
+    (the definitions of oracle_py.column_search; the reference only states the goal: design_notes_1.md:1-4)."""
+    torch = torch_cuda
+    rng = np.random.default_rng(1600 + stride)
+    n = 20_000 + 37
+    host = np.zeros((n, stride), dtype=np.uint8)
+    lens = rng.integers(0, stride + 1, size=n).astype(np.int32)
+    lens[:200] = stride
+    body = rng.choice(np.frombuffer(b"abc", dtype=np.uint8), size=(n, stride))
+    for i in range(n):
+        host[i, : lens[i]] = body[i, : lens[i]]
+    rows = [host[i, : lens[i]].tobytes() for i in range(n)]
+    col = torch.from_numpy(host).to("cuda:0")
+    dl = torch.from_numpy(lens).to("cuda:0")
+    bm = torch.zeros((n + 63) // 64 + 1, dtype=torch.int64, device="cuda:0")
+    needles = [b"", b"a", b"ab", b"abc", b"cab", b"bbbb", b"abcabcab", b"abcabcabc"]
+    for m in (1, 2, 3, 5, 7, 8, 9, 12, 15, 16, 17, 24, 31, 32, 33):
+        if m <= stride + 1:
+            i = int(rng.integers(0, 200))
+            full = rows[i] + b"a"
+            for at in {0, 1, max(0, stride - m), max(0, (stride - m) // 2)}:
+                needles.append(full[at: at + m])
+    for needle in needles:
+        for mode, fn in ((pkg.SEARCH_EQUALS, lambda r: r == needle), (pkg.SEARCH_STARTS_WITH, lambda r: r.startswith(needle)),
+                         (pkg.SEARCH_CONTAINS, lambda r: needle in r)):
+            want = np.array([fn(r) for r in rows], dtype=bool)
+            bm.zero_()
+            got_n = pkg.columnar_search_device(ctx, col.data_ptr(), dl.data_ptr(), n, stride, needle, mode, bm.data_ptr())
+            bits = np.unpackbits(bm.cpu().numpy().view(np.uint8), bitorder="little")[:n].astype(bool)
+            assert got_n == int(want.sum()) and np.array_equal(bits, want), (stride, needle, mode)
+    # no lengths array: every row is its whole zero-padded stride (fixed-width keys)
+    padded = [host[i].tobytes() for i in range(n)]
+    for needle in (b"abc", padded[5][:7], padded[9], padded[3][stride - 3:], b"\0", b"c\0"):
+        for mode, fn in ((pkg.SEARCH_EQUALS, lambda r: r == needle), (pkg.SEARCH_STARTS_WITH, lambda r: r.startswith(needle)),
+                         (pkg.SEARCH_CONTAINS, lambda r: needle in r)):
+            want = np.array([fn(r) for r in padded], dtype=bool)
+            got_n = pkg.columnar_search_device(ctx, col.data_ptr(), 0, n, stride, needle, mode, bm.data_ptr())
+            bits = np.unpackbits(bm.cpu().numpy().view(np.uint8), bitorder="little")[:n].astype(bool)
+            assert got_n == int(want.sum()) and np.array_equal(bits, want), (stride, needle, mode, "fixed width")

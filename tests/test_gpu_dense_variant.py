@@ -37,7 +37,7 @@ def index_both(pkg, torch, dctx, ctx, host, *, base_off=0, in_quote_in=0, misali
     cap = (n + 1) if cap is None else cap
     out = []
     for c in (dctx, ctx):
-        c.hint_density(1, 2) if c is dctx else c.hint_density(0, 0)      # (a synchronous call re-learns the density: pin it)
+        c.hint_density(1, 2) if c is dctx else c.hint_density(1, 1000)      # (a synchronous call re-learns the density: pin it)
         dtape = torch.full((cap + 8,), -1, dtype=torch.int64, device="cuda:0")
         r = c.stage1_index_device(dbuf.data_ptr() + misalign, n, base_off, in_quote_in, dtape.data_ptr(), cap, allow_overflow=True)
         torch.cuda.synchronize()
@@ -141,7 +141,7 @@ def test_baseline_configurations_at_1_gib(pkg, dctx, ctx, oracle, name):
     cap = S + 16
     tapes = []
     for c in (dctx, ctx):
-        c.hint_density(1, 2) if c is dctx else c.hint_density(0, 0)
+        c.hint_density(1, 2) if c is dctx else c.hint_density(1, 1000)
         want_kernel = DENSE if c is dctx else DEFAULT
         assert c.kernel_name() == want_kernel
         t = torch.full((cap,), -1, dtype=torch.int64, device="cuda:0")
@@ -198,3 +198,121 @@ def test_config4_shard_cut_mid_row_with_guess_and_reemit_flow(pkg, dctx, oracle)
     assert rec.in_quote_in_used == (truth ^ 1) and rec.error == 0 and rec.count != count_true
     k = min(want2.size - 8, rec.count)
     assert np.array_equal(dtape[:k].cpu().numpy().view(np.uint64), want2[:k])
+
+
+# ---- round 5: the dense geometry wherever it applies (VERDICT r4 missing #4, #5) ------------------------------------------------
+DENSE_D1 = "void csvsimd_dense::stage1_kernel<true, 0, 1, false, true>(csvsimd_dense::KernelArgs)"
+
+
+def test_a_fresh_context_looks_at_the_data_before_its_first_synchronous_launch(pkg):
+    """No hint, no history: the first synchronous call on >= 8 MiB samples sixteen 64-KiB windows and chooses.  The
+    asynchronous entry point never does (it may not synchronise) and stays on the default geometry until told."""
+    import torch
+    for name, want in (("1024x4_dense", DENSE), ("64x31_noquote", DEFAULT), ("16x32_q10", DEFAULT)):
+        cols, width, seed, q = pkg.WORKLOADS[name]
+        n = pkg.workload_len(name, 64 << 20)
+        dbuf = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+        pkg.synth_fill_device(dbuf.data_ptr(), 0, n, cols, width, seed, q)
+        cap = n // (width + 1) + 64
+        t = torch.empty(int(cap * 1.3), dtype=torch.int64, device="cuda:0")
+        dres = torch.zeros(8, dtype=torch.int64, device="cuda:0")
+        c = pkg.Context(0)
+        try:
+            assert c.kernel_name() == DEFAULT
+            c.stage1_index_device_async(dbuf.data_ptr(), n, 0, 0, t.data_ptr(), t.numel(), dres.data_ptr(), 0)
+            torch.cuda.synchronize()
+            assert c.kernel_name() == DEFAULT                      # an asynchronous launch teaches the host nothing
+            r = c.stage1_index_device(dbuf.data_ptr(), n, 0, 0, t.data_ptr(), t.numel())
+            assert r.error == 0 and c.kernel_name() == want, name
+        finally:
+            c.close()
+
+
+@pytest.mark.parametrize("name", ["16x32_noquote", "16x32_q10", "1024x4_dense", "64x31_noquote", "64x31_q10"])
+def test_dense_batch_on_every_configuration(pkg, dctx, ctx, oracle, name):
+    """DENSE x BATCH: 24 slices (whole rows, 1 ... 9 MiB, every other one entered inside a string, odd base offsets) of
+    each BASELINE corpus in ONE batched launch of the dense geometry == each slice alone through the default
+    instantiation == the oracle (a 2-MiB head of every slice, the count of all of it)."""
+    import torch
+    cols, width, seed, q = pkg.WORKLOADS[name]
+    row = cols * (width + 1)
+    rng = np.random.default_rng(17)
+    n = pkg.workload_len(name, 160 << 20)
+    dbuf = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    pkg.synth_fill_device(dbuf.data_ptr(), 0, n, cols, width, seed, q)
+    items, singles, off = [], [], 0
+    for i in range(24):
+        ln = int(rng.integers(1 << 20, 9 << 20)) // row * row + (i % 3) * 7     # (not always whole rows: ragged ends too)
+        ln = min(ln, n - off)
+        cap = ln // (width + 1) * 2 + 64
+        tb = torch.full((cap + 8,), -1, dtype=torch.int64, device="cuda:0")
+        ts = torch.full((cap + 8,), -1, dtype=torch.int64, device="cuda:0")
+        items.append((dbuf.data_ptr() + off, ln, 1000 * i + 1, tb.data_ptr(), cap, i & 1))
+        singles.append((off, ln, 1000 * i + 1, ts, cap, i & 1, tb))
+        off += ln
+    dres = torch.zeros((24, 8), dtype=torch.int64, device="cuda:0")
+    dctx.hint_density(1, 2)
+    dctx.stage1_index_batch_device_async(items, dres.data_ptr())
+    torch.cuda.synchronize()
+    for i, (o, ln, base, ts, cap, st, tb) in enumerate(singles):
+        ctx.hint_density(1, 1000)
+        r0 = ctx.stage1_index_device(dbuf.data_ptr() + o, ln, base, st, ts.data_ptr(), cap)
+        assert r0.error == 0
+        r = pkg.ShardResult.from_buffer_copy(dres[i].cpu().numpy().tobytes())
+        assert same_record(r, r0) and r.error == 0, (name, i)
+        assert torch.equal(tb, ts), (name, i)
+        head = min(ln, 2 << 20)
+        want, _ = oracle.scalar_index(dbuf[o: o + head].cpu().numpy(), base_off=base, in_quote_in=st)
+        k = max(want.size - 4, 0)
+        assert np.array_equal(tb[:k].cpu().numpy().view(np.uint64), want[:k]), (name, i)
+
+
+@pytest.mark.parametrize("name", ["16x32_noquote", "16x32_q10", "1024x4_dense", "64x31_noquote", "64x31_q10"])
+def test_dense_geometry_with_another_delimiter_and_quote_byte(pkg, oracle, name):
+    """DENSE x dialect 1 (delimiter ';', quote "'"): 256 MiB of each BASELINE corpus with its ',' and '"' bytes replaced,
+    through the dense geometry == through the default geometry of the same dialect == the reference-dialect tape of the
+    untouched corpus (the replacement is a bijection on the special bytes) == the oracle's dialect index on a head."""
+    import torch
+    cols, width, seed, q = pkg.WORKLOADS[name]
+    n = pkg.workload_len(name, 256 << 20)
+    dbuf = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    pkg.synth_fill_device(dbuf.data_ptr(), 0, n, cols, width, seed, q)
+    cap = n // (width + 1) + 64
+    ref_tape = torch.full((cap,), -1, dtype=torch.int64, device="cuda:0")
+    c0 = pkg.Context(0)
+    r_ref = c0.stage1_index_device(dbuf.data_ptr(), n, 5, 0, ref_tape.data_ptr(), cap)
+    alt = dbuf.clone()
+    alt[dbuf == 0x2C] = ord(";")
+    alt[dbuf == 0x22] = ord("'")
+    dia = pkg.Dialect(";", "'")
+    from csv_simd_amd import sharded
+    tapes = []
+    try:
+        for dense in (True, False):
+            c0.hint_density(1, 2) if dense else c0.hint_density(1, 1000)
+            assert c0.kernel_name(dia) == (DENSE_D1 if dense else "void csvsimd::stage1_kernel<true, 0, 1, false, false>(csvsimd::KernelArgs)")
+            t = torch.full((cap,), -1, dtype=torch.int64, device="cuda:0")
+            dres = torch.zeros(8, dtype=torch.int64, device="cuda:0")
+            c0.stage1_index_device_dialect_async(dia, alt.data_ptr(), n, 5, 0, t.data_ptr(), cap, dres.data_ptr(), 0)
+            torch.cuda.synchronize()
+            r = sharded.result_from_words(dres.cpu().tolist())
+            assert (r.count, r.in_quote_out, r.error) == (r_ref.count, r_ref.in_quote_out, 0), (name, dense)
+            tapes.append(t)
+        assert torch.equal(tapes[0], tapes[1]) and torch.equal(tapes[0], ref_tape)
+        head = alt[: 4 << 20].cpu().numpy()
+        want, _, _ = oracle.dialect_index(head, ord(";"), ord("'"), 0, base_off=5)
+        assert np.array_equal(tapes[0][: want.size - 4].cpu().numpy().view(np.uint64), want[:-4])
+        # quoting switched off in the dialect (quote = 0): every delimiter, CR and LF counts, also in the dense geometry
+        nq = pkg.Dialect(";", None)
+        c0.hint_density(1, 2)
+        capq = int(cap * 1.4)
+        t = torch.full((capq,), -1, dtype=torch.int64, device="cuda:0")
+        dres = torch.zeros(8, dtype=torch.int64, device="cuda:0")
+        c0.stage1_index_device_dialect_async(nq, alt.data_ptr(), n, 0, 0, t.data_ptr(), capq, dres.data_ptr(), 0)
+        torch.cuda.synchronize()
+        r = sharded.result_from_words(dres.cpu().tolist())
+        want, _, _ = oracle.dialect_index(head, ord(";"), 0, 0)
+        assert r.error == 0 and np.array_equal(t[: want.size - 4].cpu().numpy().view(np.uint64), want[:-4])
+        assert r.count == int(((alt == ord(";")) | (alt == 0x0A) | (alt == 0x0D)).sum().item())
+    finally:
+        c0.close()

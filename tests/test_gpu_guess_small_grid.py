@@ -44,7 +44,7 @@ def run_guess(pkg, torch, c, shard, base_off, dense):
     n = shard.size
     dbuf = torch.from_numpy(shard).to("cuda:0")
     dtape = torch.full((n + 9,), -1, dtype=torch.int64, device="cuda:0")
-    c.hint_density(1, 2) if dense else c.hint_density(0, 0)
+    c.hint_density(1, 2) if dense else c.hint_density(1, 1000)
     r = c.stage1_index_device(dbuf.data_ptr(), n, base_off, pkg.ENTER_GUESS, dtape.data_ptr(), n + 1)
     torch.cuda.synchronize()
     return dtape[: r.count].cpu().numpy().view(np.uint64), r
@@ -135,7 +135,7 @@ def test_three_guess_launches_share_the_gpu(pkg, oracle, torch_cuda, dense):
         dres = [torch.zeros(8, dtype=torch.int64, device="cuda:0") for _ in cuts]
         for c in ctxs:
             c.reserve(n)
-            c.hint_density(1, 2) if dense else c.hint_density(0, 0)
+            c.hint_density(1, 2) if dense else c.hint_density(1, 1000)
         torch.cuda.synchronize()
         for rep in range(6):
             for c, s, db, dt, dr, cut in zip(ctxs, streams, dbufs, dtapes, dres, cuts):
