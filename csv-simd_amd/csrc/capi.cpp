@@ -885,14 +885,16 @@ static int stage1_index_host_impl(csvsimd_ctx* ctx, const csvsimd_dialect* diale
 // The chunk plan of the ingest pipeline: chunk i = [cuts[i], cuts[i + 1]).  The slots hold up to 32 MiB.  A call's wall time
 // is   staging of the FIRST chunk  +  the H2D copies of all chunks (the link: 53 GiB/s, ~8 us between copies)  +  kernel,
 // way back and expansion of the LAST chunk — so the plan starts small, doubles up to full slots, and halves down again at
-// the end:  len / 32 (256 KiB ... 4 MiB)  x2 x2 ...  32 MiB ... 32 MiB  ... x1/2 x1/2  len / 16 (512 KiB ... 8 MiB).
-// 2 GiB: 4, 8, 16, 32 x 62, 16, 8 MiB.  32 MiB: 1, 2, 4, 8, 7, 4, 4, 2.  4 MiB: 256, 512 KiB, 1 MiB, 768 KiB, 1 MiB, 512 KiB.
+// the end:  len / 32 (1 ... 4 MiB)  x2 x2 ...  32 MiB ... 32 MiB  ... x1/2 x1/2  len / 16 (1 ... 8 MiB).
+// 2 GiB: 4, 8, 16, 32 x 62, 16, 8 MiB.  32 MiB: 1, 2, 4, 8, 3, 8, 4, 2.  4 MiB: 1, 2, 1.  No chunk below 1 MiB: a copy has a
+// fixed cost of ~18 us that only another copy's transfer can hide (1 MiB crosses the link in 18 us), and ENQUEUEING a copy
+// below ~1 MiB blocks the caller (64 KiB: 44 us per call, 1 MiB: 1.4 us — profiles/r05_api_cost.txt).
 // Round 4 cut a file below 128 MiB into four equal chunks of >= 4 MiB (a 32-MiB file waited 120 us for the staging of its
 // first 8 MiB and 100 us for the way back of its last 8 MiB: 1.03 ms against 0.59 ms of link time) because a chunk cost the
 // submitter ~100 us then; with the record published by the packing kernel and polled it is ~20 us (five calls).
 // No stub: a remainder shorter than a quarter of the chunk before it is folded into that chunk.
 static std::vector<uint64_t> ingest_chunk_plan(uint64_t len, uint64_t uniform_override) {
-    constexpr uint64_t kKiB = 1ull << 10, kMiB = 1ull << 20, kMax = csvsimd_ctx::kChunk;
+    constexpr uint64_t kMiB = 1ull << 20, kMax = csvsimd_ctx::kChunk;
     std::vector<uint64_t> cuts;
     cuts.push_back(0);
     if (len == 0) return cuts;
@@ -913,8 +915,8 @@ static std::vector<uint64_t> ingest_chunk_plan(uint64_t len, uint64_t uniform_ov
         return (e && *e && atoll(e) > 0) ? (uint64_t)atoll(e) * 1024 : dflt;
     };
     auto round64k = [](uint64_t v) { return (v + 65535) & ~(uint64_t)65535; };
-    const uint64_t first = knob("CSVSIMD_INGEST_FIRST_KIB", std::min(4 * kMiB, std::max(256 * kKiB, round64k(len / 32))));
-    const uint64_t last = knob("CSVSIMD_INGEST_LAST_KIB", std::min(8 * kMiB, std::max(512 * kKiB, round64k(len / 16))));
+    const uint64_t first = knob("CSVSIMD_INGEST_FIRST_KIB", std::min(4 * kMiB, std::max(1 * kMiB, round64k(len / 32))));
+    const uint64_t last = knob("CSVSIMD_INGEST_LAST_KIB", std::min(8 * kMiB, std::max(1 * kMiB, round64k(len / 16))));
     std::vector<uint64_t> front, back;  // sizes from the file's start / from its end
     uint64_t rem = len, f = std::min(first, kMax), b = std::min(last, kMax);
     for (bool at_front = true; rem; at_front = !at_front) {
@@ -1052,20 +1054,11 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
     int rc = pipe_setup(ctx, (int)std::min<uint64_t>(std::max<uint64_t>(nchunks, 1), S), largest);
     if (rc != CSVSIMD_OK) return rc;
     hipStream_t st = ctx->pipe_stream;
-    // Up to kZeroCopyMax the stage-1 kernel reads the chunk straight from its pinned slot — no H2D copy, no event, no second
-    // stream: a chunk costs the submitter two kernel launches.  Measured (scripts/ubench/api_cost.cpp, profiles/r05_api_cost.txt):
-    // a kernel reads 4 MiB of pinned host memory in 81 us (enqueue to flag seen, 48 GiB/s; 8 MiB 154 us, 32 MiB 593 us =
-    // 52.7 GiB/s, the link's rate), a hipMemcpyAsync of 4 MiB followed by a kernel takes 98 us (8 MiB: 172): the copy
-    // engine's fixed ~17 us per copy is what a short file cannot hide.  A long file keeps the copies: its kernels then read
-    // HBM, not the link, and the link carries nothing twice.
-    uint64_t zero_copy_max = 48ull << 20;
-    if (const char* e = getenv("CSVSIMD_INGEST_ZEROCOPY_MIB")) zero_copy_max = (uint64_t)std::max(0, atoi(e)) << 20;  // TUNING
-    const bool zero_copy = len <= zero_copy_max;
-    void* in_dev[S] = {};  // where the kernels read slot k's chunk: the pinned slot itself, or its device copy
-    for (int k = 0; k < S; ++k) {
-        in_dev[k] = ctx->d_in[k];
-        if (zero_copy && ctx->pin_in[k]) HIP_TRY(hipHostGetDevicePointer(&in_dev[k], ctx->pin_in[k], 0));
-    }
+    // (Measured and rejected, round 5: letting the stage-1 kernel read a chunk straight from its pinned slot — no H2D copy, no
+    // event.  A plain streaming kernel reads pinned memory at the link's rate (4 MiB in 81 us against 98 us for copy +
+    // kernel: profiles/r05_api_cost.txt), but this kernel's loads are the transposing ones — a wave instruction takes 16 bytes
+    // from each of 64 different 64-byte segments — and host memory is not cached on the GPU side: every segment crosses the
+    // link four times.  32 MiB: 1 341 us against 947 us with the copies; 4 MiB: no difference: profiles/r05_midsize_zero_copy.txt.)
     // a file of a few MiB: the host-side copies ARE the critical path — slices of 128 KiB, workers polling for them
     const size_t min_slice = len <= (64ull << 20) ? (128u << 10) : CopyPool::kMinSlice;
     CopyPool::Busy busy(len <= (256ull << 20) ? ctx->copier.get() : nullptr);
@@ -1146,15 +1139,11 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
         const int k = (int)(j % S);
         {
             const double t0 = now();
-            // the slot's previous chunk (j - S) has been enqueued — zero copy: has been READ by its kernels (its record is in)
-            await([&] {
-                return sh.abort.load(std::memory_order_acquire) || j < (uint64_t)S ||
-                       (zero_copy ? sh.finished : sh.h2d).load(std::memory_order_acquire) + S > j;
-            });
+            await([&] { return sh.abort.load(std::memory_order_acquire) || j < (uint64_t)S || sh.h2d.load(std::memory_order_acquire) + S > j; });  // chunk j - S has been enqueued
             t_wait += now() - t0;
             if (sh.abort.load(std::memory_order_acquire)) return false;
         }
-        if (j >= (uint64_t)S && !zero_copy) {  // ... and has left the staging slot
+        if (j >= (uint64_t)S) {  // ... and has left the staging slot
             const double t0 = now();
             const hipError_t e = hipEventSynchronize(ctx->ev_in[k]);
             t_wait += now() - t0;
@@ -1181,7 +1170,7 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
         const uint64_t i = slot[k].chunk, off = cuts[i], clen = cuts[i + 1] - off;
         csvsimd_dialect dia;
         if (dialect) { dia = *dialect; dia.escape_in = (uint8_t)host_esc; }
-        int rc_ = stage1_async_impl(ctx, dialect ? &dia : nullptr, in_dev[k], clen, off, host_inq,
+        int rc_ = stage1_async_impl(ctx, dialect ? &dia : nullptr, ctx->d_in[k], clen, off, host_inq,
                                     tape ? ctx->d_tape[k] : nullptr, slot[k].cap, ctx->d_res[k], st, nullptr,
                                     chained ? ctx->d_res[(k + S - 1) % S] : nullptr);
         if (rc_ != CSVSIMD_OK) return rc_;
@@ -1275,13 +1264,11 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
         // Two copy streams take turns: a copy's set-up and completion signalling (~30 us, measured as the difference between
         // 68 chunked copies and one copy of the same 2 GiB) overlap the other stream's transfer instead of idling the link.
         // d_in[k] is free: the record of the slot's previous chunk (i - S) was read before this call (S > kLag).
-        if (!zero_copy) {
-            hipStream_t cs = (h2d_streams == 2 && (i & 1)) ? ctx->in_stream2 : ctx->in_stream;
-            HIP_TRY(hipMemcpyAsync(ctx->d_in[k], ctx->pin_in[k], clen, hipMemcpyHostToDevice, cs));
-            HIP_TRY(hipEventRecord(ctx->ev_in[k], cs));
-            bump(sh.h2d, i + 1);
-            HIP_TRY(hipStreamWaitEvent(st, ctx->ev_in[k], 0));
-        }
+        hipStream_t cs = (h2d_streams == 2 && (i & 1)) ? ctx->in_stream2 : ctx->in_stream;
+        HIP_TRY(hipMemcpyAsync(ctx->d_in[k], ctx->pin_in[k], clen, hipMemcpyHostToDevice, cs));
+        HIP_TRY(hipEventRecord(ctx->ev_in[k], cs));
+        bump(sh.h2d, i + 1);
+        HIP_TRY(hipStreamWaitEvent(st, ctx->ev_in[k], 0));
         t_submit += now() - t0;
         if (i >= (uint64_t)S) {  // the slot's previous chunk (i - S): its offsets must have left pin_out[k]
             const double t1 = now();
