@@ -2240,7 +2240,7 @@ int csvsimd_column_frequency_device(csvsimd_ctx* ctx, const void* dbytes, const 
         map[i] = RowMap{n, chunks[i].start / row_size - 1, chunks[i].start};  // seek_field numbering: the header row is not a record
         n += rows[i];
     }
-    if (n >= 0xffffffffull) return CSVSIMD_ERR_INVALID_ARG;  // record ids are 32-bit (Tape.record_cnt, src/tape.rs:76)
+    if (n > (1ull << 28)) return CSVSIMD_ERR_INVALID_ARG;  // (see csvsimd_columnar_frequency_device_async: at most 2^28 records per count)
     static_assert(sizeof(csvsimd_freq_status) == 32 && sizeof(csvsimd_freq_entry) == 32, "layouts shared with the kernels");
     *status = csvsimd_freq_status{n, 0, 0, 0};
     if (n == 0) return CSVSIMD_OK;
@@ -2251,7 +2251,9 @@ int csvsimd_column_frequency_device(csvsimd_ctx* ctx, const void* dbytes, const 
     // (rounds 1-3 and the first version of this path waited for the longest field before they gathered).
     const FreqLayout L0 = freq_layout(n, n_chunks, 0);
     if (scratch_bytes < L0.total + n * 16) return CSVSIMD_ERR_TAPE_CAPACITY;  // not even 16-byte rows (status->max_field_bytes stays 0)
-    const uint64_t stride = std::min<uint64_t>(((scratch_bytes - L0.total) / n) & ~(uint64_t)15, 0xfffffff0ull);
+    // ... but never wider than the documented 4 096 bytes: a caller that hands over one large arena for everything would
+    // otherwise have every record gathered and hashed as a row of KiB or MiB
+    const uint64_t stride = std::min<uint64_t>(((scratch_bytes - L0.total) / n) & ~(uint64_t)15, 4096);
     const FreqLayout L = freq_layout(n, n_chunks, stride);
     char* const base = (char*)d_scratch;
     HIP_TRY(hipMemsetAsync(base, 0, 64, s));
@@ -2370,8 +2372,12 @@ int csvsimd_columnar_frequency_device_async(csvsimd_ctx* ctx, const void* d_col,
     return csvsimd_guarded([&]() -> int {
     if (!ctx || !d_scratch || !d_status || (n_records && !d_col) || (entries_cap && !d_entries)) return CSVSIMD_ERR_INVALID_ARG;
     if (((uintptr_t)d_scratch & 15) || ((uintptr_t)d_entries & 7) || ((uintptr_t)d_status & 7)) return CSVSIMD_ERR_INVALID_ARG;
+    // n_records: one call counts up to 2^28 records (268 M).  The second pass cuts the hash space into at most 4 096
+    // partitions and a partition's tuples are merged 6 144 at a time, every round re-reading the partition's tuple run: all
+    // distinct, 2^28 records are 11 rounds per partition; towards the 2^32 the record ids allow the re-reads would grow
+    // quadratically.  Larger columns: count slices of <= 2^28 records and merge the entry lists.
     if (stride == 0 || (stride & 15u) || stride > 4096 || ((uintptr_t)d_col & 15) || ((uintptr_t)d_len & 3) ||
-        n_records >= 0xffffffffull)
+        n_records > (1ull << 28))
         return CSVSIMD_ERR_INVALID_ARG;
     if (scratch_bytes < csvsimd::colfreq_scratch_bytes(n_records)) return CSVSIMD_ERR_TAPE_CAPACITY;
     static_assert(sizeof(csvsimd_colfreq_status) == 32 && sizeof(csvsimd_colfreq_entry) == 16, "layouts shared with the kernels");

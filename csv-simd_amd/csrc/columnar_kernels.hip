@@ -251,10 +251,14 @@ struct ColView {
 // eight bytes, the scheme of wyhash's 32-bit variant): two words of state, the row xored in eight bytes at a time, each step
 // replacing the state by the two halves of (s0 ^ k0) * (s1 ^ k1).  The low bits of a product are poorly mixed, so the
 // result's halves are s0 ^ s1 after two and after three closing steps.
+// The old halves are folded back in (round 5): a bare product is absorbing — a row whose first dword made
+// s0 ^ 0x53c5ca59 zero zeroed the whole state, whatever its next four bytes held, so a crafted (or binary) column could put
+// more than a table's worth of DISTINCT values on one 64-bit hash and make the count fail with `overflow`, every time.
 __device__ __forceinline__ void cf_mix(u32& s0, u32& s1) {
     const u64 c = (u64)(s0 ^ 0x53c5ca59u) * (u64)(s1 ^ 0x74743c1bu);
-    s0 = (u32)c;
-    s1 = (u32)(c >> 32);
+    const u32 o0 = s0;
+    s0 = (u32)c + s1;
+    s1 = (u32)(c >> 32) ^ o0;
 }
 __device__ __forceinline__ void cf_absorb(u32& s0, u32& s1, const u32x4c v) {
     s0 ^= v.x;

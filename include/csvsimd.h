@@ -426,8 +426,10 @@ int csvsimd_gather_fields_device(const void* dbytes, uint64_t bytes_len, const v
  *                 aligned; n_records = the chunks' records together.  The column is gathered at the largest stride the
  *                 scratch holds — size it for the longest field you expect, not generously: a stride of 256 bytes for
  *                 8-byte values moves 32 x the bytes.  If some field is longer than that stride the call returns
- *                 CSVSIMD_ERR_TAPE_CAPACITY with status->max_field_bytes set (the longest field of the column, always
- *                 reported) — size the scratch from that and call again
+ *                 CSVSIMD_ERR_TAPE_CAPACITY with status->max_field_bytes set (the longest field of the column, reported
+ *                 by every call that got as far as gathering the column: a scratch too small even for 16-byte rows is
+ *                 refused before that, with max_field_bytes 0) — size the scratch from that and call again.  The stride
+ *                 is capped at 4 096 bytes however large the scratch is.  At most 2^28 records per call
  *   d_entries   : entries_cap csvsimd_freq_entry, unordered (sort by first_record for a deterministic order);
  *                 status->n_distinct of them are valid (CSVSIMD_ERR_TAPE_CAPACITY if more exist than fit)
  * Synchronous on hip_stream (one wait, at the end).  The slow path next to the columnar one: it touches one or two
@@ -502,7 +504,8 @@ int csvsimd_chunk_to_columns_device(csvsimd_ctx* ctx, const void* dbytes, uint64
  * csvsimd_columnar_frequency_device = the same + the status copied to the host + one synchronisation; it returns
  * CSVSIMD_ERR_TAPE_CAPACITY if status->n_distinct > entries_cap, if status->truncated records are longer than the stride
  * (their counts would merge values that differ past it: transpose with a larger stride), or if status->overflow (more
- * than 8 192 distinct values share 21 hash bits: not a property of real data). */
+ * than 8 192 distinct values share 21 hash bits: not a property of real data).  n_records <= 2^28 per call
+ * (CSVSIMD_ERR_INVALID_ARG above: count slices and merge the entry lists). */
 typedef struct csvsimd_colfreq_entry {
     uint64_t first_record, count;
 } csvsimd_colfreq_entry;
