@@ -163,8 +163,15 @@ public:
     // From here to the matching quiet(): idle workers poll for slices instead of sleeping on the condition variable — a
     // sleeping worker takes 20-60 us to start on a slice (futex wake + a core leaving its idle state), which is the whole
     // copy time of a few MiB.  Held for the duration of ONE ingest call (RAII: Busy); nests.
+    // After the call has ended the workers go on polling for kLingerSeconds: a caller that reads file after file finds them
+    // awake (a sleeping worker's first slice starts 20-60 us late — a quarter of a 4-MiB call).
     void busy() { spinners_.fetch_add(1, std::memory_order_acq_rel); cv_work_.notify_all(); }
-    void quiet() { spinners_.fetch_sub(1, std::memory_order_acq_rel); }
+    void quiet() {
+        linger_until_.store(steady_seconds() + kLingerSeconds, std::memory_order_release);
+        spinners_.fetch_sub(1, std::memory_order_acq_rel);
+    }
+    static constexpr double kLingerSeconds = 300e-6;
+    static double steady_seconds() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     struct Busy {
         CopyPool* p;
         explicit Busy(CopyPool* pool) : p(pool) { if (p) p->busy(); }
@@ -220,7 +227,7 @@ private:
             }
             pending_.store(jobs_.size(), std::memory_order_release);
         }
-        if (spinners_.load(std::memory_order_acquire) == 0) cv_work_.notify_all();  // (pollers see pending_)
+        cv_work_.notify_all();  // (pollers see pending_ first; a worker that has just gone to sleep needs the notification)
         Job first = whole;
         first.n = std::min(slice, whole.n);
         execute(first);  // the calling thread takes the first slice
@@ -273,12 +280,18 @@ private:
             {
                 std::unique_lock<std::mutex> g(m_);
                 while (!stop_ && jobs_.empty()) {
-                    if (spinners_.load(std::memory_order_acquire)) {
-                        // an ingest call is running: poll (without the lock) until a slice shows up or the call ends
+                    const bool hot = spinners_.load(std::memory_order_acquire) != 0 ||
+                                     steady_seconds() < linger_until_.load(std::memory_order_acquire);
+                    if (hot) {
+                        // an ingest call is running (or one has just ended): poll (without the lock) until a slice shows up,
+                        // the call ends and the linger runs out, or the pool is stopped
                         g.unlock();
-                        while (spinners_.load(std::memory_order_acquire) && pending_.load(std::memory_order_acquire) == 0 &&
-                               !stop_flag_.load(std::memory_order_acquire))
+                        for (int spins = 0; pending_.load(std::memory_order_acquire) == 0 && !stop_flag_.load(std::memory_order_acquire); ++spins) {
                             for (int i = 0; i < 32; ++i) _mm_pause();
+                            if ((spins & 15) == 15 && spinners_.load(std::memory_order_acquire) == 0 &&
+                                steady_seconds() >= linger_until_.load(std::memory_order_acquire))
+                                break;
+                        }
                         g.lock();
                     } else {
                         cv_work_.wait(g);
@@ -302,6 +315,7 @@ private:
     std::vector<Job> jobs_;
     std::atomic<size_t> pending_{0};     // jobs_.size(), readable without the lock (pollers)
     std::atomic<int> spinners_{0};       // ingest calls in progress: workers poll instead of sleeping
+    std::atomic<double> linger_until_{0.0};  // ... and until then after the last one ended
     std::atomic<bool> stop_flag_{false};
     bool stop_ = false;
 };
@@ -328,6 +342,7 @@ public:
             std::lock_guard<std::mutex> g(m_);
             task_ = std::move(f);
             busy_ = true;
+            posted_.store(true, std::memory_order_release);
         }
         cv_.notify_all();
     }
@@ -340,8 +355,19 @@ private:
     void run() {
         std::unique_lock<std::mutex> g(m_);
         for (;;) {
+            // a task has just ended: the next call's is probably microseconds away — poll for ~300 us before sleeping
+            if (!stop_ && !busy_) {
+                g.unlock();
+                const double until = CopyPool::steady_seconds() + CopyPool::kLingerSeconds;
+                for (int spins = 0; !posted_.load(std::memory_order_acquire); ++spins) {
+                    for (int i = 0; i < 32; ++i) _mm_pause();
+                    if ((spins & 15) == 15 && CopyPool::steady_seconds() >= until) break;
+                }
+                g.lock();
+            }
             cv_.wait(g, [this] { return stop_ || busy_; });
             if (!busy_) return;
+            posted_.store(false, std::memory_order_release);
             std::function<void()> f = std::move(task_);
             g.unlock();
             f();
@@ -354,6 +380,7 @@ private:
     std::mutex m_;
     std::condition_variable cv_;
     std::function<void()> task_;
+    std::atomic<bool> posted_{false};  // busy_ went up (readable without the lock: the lingering poll)
     bool busy_ = false, stop_ = false;
     std::thread th_;  // last: started when everything above exists
 };

@@ -977,20 +977,20 @@ __global__ __launch_bounds__(256) void colsearch_kernel(const ColView c, const u
 // The kernel above reads a row eight bytes at a time, three dword loads per step and lane: on a 1-GiB column it is bound by
 // the number of load instructions, not by HBM (profiles/r05_consumers_1GiB_before.json).  Here a lane fetches its whole row
 // with one or two 16-byte loads — the NEXT batch of rows is requested before this one is searched — and searches it in
-// registers: `contains` finds the start positions whose first two bytes are the needle's by an exact zero-byte test on
-// eight positions at a time (x ^ pattern has a zero byte <=> ((x & 0x7f..) + 0x7f..) | x has bit 7 clear there), and only
-// those — one position in 65 536 on random text — are compared in full, from the row's cache line.  Same results, bit for
+// registers: `contains` finds the start positions whose first three bytes are the needle's by an exact zero-byte test on
+// four positions at a time (x ^ pattern has a zero byte <=> ((x & 0x7f..) + 0x7f..) | x has bit 7 clear there), and only
+// those — one position in 17 576 on random lower-case text — are compared in full, from the row's cache line.  Same results, bit for
 // bit (tests/test_gpu_columnar.py runs both on every case).
-__device__ __forceinline__ u64 zero_bytes(u64 x) {  // bit 7 of every byte of x that is zero
-    const u64 k7 = 0x7f7f7f7f7f7f7f7full;
+__device__ __forceinline__ u32 zero_bytes32(u32 x) {  // bit 7 of every byte of x that is zero (exact: no borrow between bytes)
+    const u32 k7 = 0x7f7f7f7fu;
     return ~(((x & k7) + k7) | x | k7);
 }
 template <u32 STRIDE>
-__global__ __launch_bounds__(256) void colsearch_small_kernel(const ColView c, const uint8_t* __restrict__ needle, u32 m, int mode,
-                                                              u64* __restrict__ bitmap, u64* __restrict__ count,
-                                                              u64* __restrict__ truncated) {
+__global__ __launch_bounds__(256, 2) void colsearch_small_kernel(const ColView c, const uint8_t* __restrict__ needle, u32 m, int mode,
+                                                                 u64* __restrict__ bitmap, u64* __restrict__ count,
+                                                                 u64* __restrict__ truncated) {
     static_assert(STRIDE == 16 || STRIDE == 32, "rows that fit one or two 16-byte loads");
-    constexpr u32 W = STRIDE / 8;  // 64-bit words per row
+    constexpr u32 D = STRIDE / 4;  // dwords per row
     __shared__ u64 s_needle[kColMaxNeedle / 8 + 1];
     for (u32 k = threadIdx.x; k < kColMaxNeedle / 8 + 1; k += blockDim.x) {
         u64 w = 0;
@@ -1001,83 +1001,124 @@ __global__ __launch_bounds__(256) void colsearch_small_kernel(const ColView c, c
     __syncthreads();
     const u64 n_words = (c.n_rows + 63) / 64;
     const u32 lane = threadIdx.x & 63u;
-    u64 nd[W];  // the needle's first STRIDE bytes, masked to m
+    u32 nd[D], nmask[D];  // the needle's first STRIDE bytes and which of them exist
 #pragma unroll
-    for (u32 k = 0; k < W; ++k) nd[k] = s_needle[k];
-    u64 nmask[W];
-#pragma unroll
-    for (u32 k = 0; k < W; ++k) nmask[k] = m >= 8 * k + 8 ? ~0ull : (m > 8 * k ? (1ull << (8 * (m - 8 * k))) - 1ull : 0ull);
-    const u64 b0 = (nd[0] & 0xffull) * 0x0101010101010101ull, b1 = ((nd[0] >> 8) & 0xffull) * 0x0101010101010101ull;
+    for (u32 k = 0; k < D; ++k) {
+        nd[k] = (u32)(s_needle[k >> 1] >> (32 * (k & 1)));
+        nmask[k] = m >= 4 * k + 4 ? ~0u : (m > 4 * k ? (1u << (8 * (m - 4 * k))) - 1u : 0u);
+    }
+    // the needle's first three bytes, each broadcast to a dword: the filter of `contains`
+    const u32 b0 = (nd[0] & 0xffu) * 0x01010101u, b1 = ((nd[0] >> 8) & 0xffu) * 0x01010101u, b2 = ((nd[0] >> 16) & 0xffu) * 0x01010101u;
     u32 hits = 0, trunc = 0;
     const u64 step = ((u64)gridDim.x * blockDim.x) >> 6;
     u64 word = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    // the batch in flight: this lane's row and its length
+    // The batch in flight: 64 rows.  A wave's loads are 16 bytes per lane over CONTIGUOUS kibibytes (two instructions cover
+    // the 2 KiB of 64 32-byte rows): a lane that fetched its own row — two loads 32 bytes apart from its neighbour's —
+    // streamed at 4.9 TB/s, this layout at the rate of a plain copy.  With 32-byte rows a lane therefore holds two HALVES:
+    // piece `lane` of rows 0..31 (row lane / 2, half lane & 1) and piece `lane` of rows 32..63; neighbours swap one of them
+    // (DPP) and the even lanes end up with rows 0..31, the odd lanes with rows 32..63 — row_of_lane below.
     u32x4c va = {0, 0, 0, 0}, vb = {0, 0, 0, 0};
     u32 vlen = STRIDE;
+    const u32 row_of_lane = STRIDE == 32 ? (lane >> 1) + ((lane & 1u) << 5) : lane;
     auto fetch = [&](u64 wd) {
-        const u64 i = wd * 64 + lane;
-        if (wd < n_words && i < c.n_rows) {
-            const u32x4c* const p = reinterpret_cast<const u32x4c*>(c.col + i * STRIDE);
-            va = __builtin_nontemporal_load(p);
-            if (STRIDE == 32) vb = __builtin_nontemporal_load(p + 1);
-            vlen = c.len ? __builtin_nontemporal_load(c.len + i) : STRIDE;
-        }
+        if (wd >= n_words) return;
+        const u64 i0 = wd * 64;
+        const u64 pieces = c.n_rows * (STRIDE / 16);  // 16-byte pieces of the column
+        const u32x4c* const p = reinterpret_cast<const u32x4c*>(c.col + i0 * STRIDE);
+        const u64 q0 = i0 * (STRIDE / 16);
+        va = q0 + lane < pieces ? __builtin_nontemporal_load(p + lane) : u32x4c{0, 0, 0, 0};
+        if (STRIDE == 32) vb = q0 + 64 + lane < pieces ? __builtin_nontemporal_load(p + 64 + lane) : u32x4c{0, 0, 0, 0};
+        vlen = (c.len && i0 + row_of_lane < c.n_rows) ? __builtin_nontemporal_load(c.len + i0 + row_of_lane) : STRIDE;
     };
     fetch(word);
     for (; word < n_words; word += step) {
         const u32x4c ra = va, rb = vb;
         const u32 full = vlen;
         fetch(word + step);  // (the loads of the next batch are in flight while this one is searched)
-        const u64 i = word * 64 + lane;
+        const u64 i = word * 64 + row_of_lane;
+        u32 d[D + 1];
+        if (STRIDE == 32) {
+            // the half my neighbour needs: an even lane gives away its piece of rows 32..63, an odd lane its piece of rows 0..31
+            const bool odd = (lane & 1u) != 0;
+            const u32x4c give = odd ? ra : rb;
+            u32x4c got;
+            got.x = (u32)__builtin_amdgcn_mov_dpp((int)give.x, 0xb1, 0xf, 0xf, true);  // quad_perm [1, 0, 3, 2]
+            got.y = (u32)__builtin_amdgcn_mov_dpp((int)give.y, 0xb1, 0xf, 0xf, true);
+            got.z = (u32)__builtin_amdgcn_mov_dpp((int)give.z, 0xb1, 0xf, 0xf, true);
+            got.w = (u32)__builtin_amdgcn_mov_dpp((int)give.w, 0xb1, 0xf, 0xf, true);
+            const u32x4c lo = odd ? got : ra, hi = odd ? rb : got;
+            d[0] = lo.x; d[1] = lo.y; d[2] = lo.z; d[3] = lo.w;
+            d[4] = hi.x; d[5] = hi.y; d[6] = hi.z; d[7] = hi.w;
+        } else {
+            d[0] = ra.x; d[1] = ra.y; d[2] = ra.z; d[3] = ra.w;
+        }
+        d[D] = 0;
         bool match = false;
         if (i < c.n_rows) {
             if (full > STRIDE) ++trunc;
             const u32 n = full < STRIDE ? full : STRIDE;
-            u64 r[W + 1];
-            r[0] = ((u64)ra.y << 32) | ra.x;
-            r[1] = ((u64)ra.w << 32) | ra.z;
-            if (STRIDE == 32) {
-                r[2] = ((u64)rb.y << 32) | rb.x;
-                r[3] = ((u64)rb.w << 32) | rb.z;
-            }
-            r[W] = 0;
             if (mode != 2) {
                 match = m <= STRIDE && (mode == 0 ? n == m : n >= m);
+                u32 diff = 0;
 #pragma unroll
-                for (u32 k = 0; k < W; ++k) match = match && ((r[k] ^ nd[k]) & nmask[k]) == 0;
+                for (u32 k = 0; k < D; ++k) diff |= (d[k] ^ nd[k]) & nmask[k];
+                match = match && diff == 0;
             } else if (m == 0) {
                 match = true;
             } else if (n >= m) {
                 const u32 last = n - m;  // last start position
-                u64 found = 0;
+                // start positions whose first min(m, 3) bytes are the needle's: an exact zero-byte test per prefix byte on the
+                // row shifted by that byte's offset (v_alignbyte), four positions per dword
+                u32 any = 0, cand[D];
 #pragma unroll
-                for (u32 k = 0; k < W; ++k) {
-                    u64 cand = zero_bytes(r[k] ^ b0);
-                    if (m >= 2) cand &= zero_bytes(((r[k] >> 8) | (r[k + 1] << 56)) ^ b1);
-                    // positions 8k .. 8k + 7 that may start a match: <= last
-                    const u64 keep = last >= 8 * k + 7 ? ~0ull : (last >= 8 * k ? (1ull << (8 * (last - 8 * k + 1))) - 1ull : 0ull);
-                    cand &= keep;
-                    if (m <= 2) {
-                        found |= cand;
-                    } else {
-                        while (cand && !found) {  // rare: both leading bytes agree — the rest, from the row's cache line
-                            const u32 pos = 8 * k + ((u32)__builtin_ctzll(cand) >> 3);
-                            cand &= cand - 1;
-                            const uint8_t* const row = c.col + i * STRIDE;
+                for (u32 k = 0; k < D; ++k) {
+                    u32 z = zero_bytes32(d[k] ^ b0);
+                    if (m >= 2) z &= zero_bytes32(__builtin_amdgcn_alignbyte(d[k + 1], d[k], 1) ^ b1);
+                    if (m >= 3) z &= zero_bytes32(__builtin_amdgcn_alignbyte(d[k + 1], d[k], 2) ^ b2);
+                    // positions 4k .. 4k + 3 that may start a match: <= last
+                    const u32 cnt = last >= 4 * k + 3 ? 4u : (last >= 4 * k ? last - 4 * k + 1u : 0u);
+                    z &= cnt >= 4 ? ~0u : ((1u << (8 * cnt)) - 1u);
+                    cand[k] = z;
+                    any |= z;
+                }
+                if (m <= 3) {
+                    match = any != 0;
+                } else if (any) {
+                    // rare (one start position in 17 576 on random lower-case text): the rest of the needle, from the row's
+                    // cache line
+                    const uint8_t* const row = c.col + i * STRIDE;
+#pragma unroll
+                    for (u32 k = 0; k < D; ++k) {
+                        u32 z = cand[k];
+                        while (z && !match) {
+                            const u32 pos = 4 * k + ((u32)__builtin_ctz(z) >> 3);
+                            z &= z - 1;
                             bool ok = true;
                             for (u32 q = 0; 8 * q < m && ok; ++q) {
                                 const u32 left = m - 8 * q;
                                 const u64 mask = left >= 8 ? ~0ull : ((1ull << (8 * left)) - 1ull);
                                 ok = ((col_load8(row, pos + 8 * q, STRIDE) ^ s_needle[q]) & mask) == 0;
                             }
-                            if (ok) found = 1;
+                            match = ok;
                         }
                     }
                 }
-                match = found != 0;
             }
         }
-        const u64 bits = __ballot(match);
+        u64 bits = __ballot(match);
+        if (STRIDE == 32) {
+            // bit 2k = row k, bit 2k + 1 = row 32 + k: the even bits, packed, are the word's low half, the odd bits its high half
+            auto pack_even = [](u64 x) -> u64 {
+                x &= 0x5555555555555555ull;
+                x = (x | (x >> 1)) & 0x3333333333333333ull;
+                x = (x | (x >> 2)) & 0x0f0f0f0f0f0f0f0full;
+                x = (x | (x >> 4)) & 0x00ff00ff00ff00ffull;
+                x = (x | (x >> 8)) & 0x0000ffff0000ffffull;
+                x = (x | (x >> 16)) & 0x00000000ffffffffull;
+                return x;
+            };
+            bits = pack_even(bits) | (pack_even(bits >> 1) << 32);
+        }
         if (lane == 0) {
             bitmap[word] = bits;
             hits += (u32)__builtin_popcountll(bits);
