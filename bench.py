@@ -1359,6 +1359,7 @@ def main():
                     help="do the sharded step inside the C ABI (csvsimd_stage1_index_sharded: ncclAllGather "
                          "from C++) instead of torch.distributed.all_gather_into_tensor")
     ap.add_argument("--only-batch", action="store_true", help="development: run the `batch_many_files` leg alone")
+    ap.add_argument("--batch-k", type=int, default=0, help="with --only-batch: run this one batch size (8 or 64) alone")
     ap.add_argument("--only-latency", action="store_true", help="development: run the `latency` leg alone")
     ap.add_argument("--only-small-files", action="store_true", help="development: run the `small_files` leg alone")
     ap.add_argument("--only-consumers-large", action="store_true", help="development / profiling: run the `consumers_at_1GiB` leg alone")
@@ -1424,7 +1425,10 @@ def main():
         print(json.dumps({"consumers": consumers_leg(pkg, oracle or graft.load_oracle(), device)}))
         return
     if args.only_batch:
-        print(json.dumps({"batch_many_files": batch_leg(pkg, device), "at_8_GiB_per_batch": batch_leg(pkg, device, k=64)}))
+        if args.batch_k:     # profiling: ONE batch size per process, so that a kernel-stats row is one launch shape
+            print(json.dumps({f"batch_of_{args.batch_k}": batch_leg(pkg, device, k=args.batch_k)}))
+        else:
+            print(json.dumps({"batch_many_files": batch_leg(pkg, device), "at_8_GiB_per_batch": batch_leg(pkg, device, k=64)}))
         return
     if args.only_latency:
         print(json.dumps({"latency": latency_leg(pkg, oracle or graft.load_oracle(), device)}))

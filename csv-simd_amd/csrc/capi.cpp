@@ -1086,7 +1086,15 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
     // kernel: profiles/r05_api_cost.txt), but this kernel's loads are the transposing ones — a wave instruction takes 16 bytes
     // from each of 64 different 64-byte segments — and host memory is not cached on the GPU side: every segment crosses the
     // link four times.  32 MiB: 1 341 us against 947 us with the copies; 4 MiB: no difference: profiles/r05_midsize_zero_copy.txt.)
-    // a file of a few MiB: the host-side copies ARE the critical path — slices of 128 KiB, workers polling for them
+    // a file of a few MiB: the chunks go in by a kernel that reads the pinned slot, not by the copy engine (its ~18 us per copy
+    // are a fifth of such a call: text_kernels.hip, h2d_blit_kernel)
+    uint64_t blit_max = 64ull << 20;
+    if (const char* e = getenv("CSVSIMD_INGEST_BLIT_MIB")) blit_max = (uint64_t)std::max(0, atoi(e)) << 20;  // TUNING
+    const bool blit = len <= blit_max;
+    void* pin_dev[S] = {};
+    for (int k = 0; k < S && blit; ++k)
+        if (ctx->pin_in[k]) HIP_TRY(hipHostGetDevicePointer(&pin_dev[k], ctx->pin_in[k], 0));
+    // ... and the host-side copies ARE the critical path — slices of 128 KiB, workers polling for them
     const size_t min_slice = len <= (64ull << 20) ? (128u << 10) : CopyPool::kMinSlice;
     CopyPool::Busy busy(len <= (256ull << 20) ? ctx->copier.get() : nullptr);
 
@@ -1292,7 +1300,8 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
         // 68 chunked copies and one copy of the same 2 GiB) overlap the other stream's transfer instead of idling the link.
         // d_in[k] is free: the record of the slot's previous chunk (i - S) was read before this call (S > kLag).
         hipStream_t cs = (h2d_streams == 2 && (i & 1)) ? ctx->in_stream2 : ctx->in_stream;
-        HIP_TRY(hipMemcpyAsync(ctx->d_in[k], ctx->pin_in[k], clen, hipMemcpyHostToDevice, cs));
+        if (blit) HIP_TRY(csvsimd::launch_h2d_blit(ctx->d_in[k], pin_dev[k], clen, cs));  // (see text_kernels.hip: h2d_blit_kernel)
+        else HIP_TRY(hipMemcpyAsync(ctx->d_in[k], ctx->pin_in[k], clen, hipMemcpyHostToDevice, cs));
         HIP_TRY(hipEventRecord(ctx->ev_in[k], cs));
         bump(sh.h2d, i + 1);
         HIP_TRY(hipStreamWaitEvent(st, ctx->ev_in[k], 0));
@@ -1529,7 +1538,10 @@ static int stage1_index_batch_body(csvsimd_ctx* ctx, csvsimd_host_batch_item* it
             }
         hipStream_t st = ctx->pipe_stream;
         void* bout_dev[S] = {};
+        void* pin_dev[S] = {};
         void* rec_dev_base = nullptr;
+        if (!getenv("CSVSIMD_INGEST_BLIT_MIB") || atoi(getenv("CSVSIMD_INGEST_BLIT_MIB")) > 0)  // TUNING
+            for (int k = 0; k < (int)std::min<uint64_t>(ngroups, S); ++k) HIP_TRY(hipHostGetDevicePointer(&pin_dev[k], ctx->pin_in[k], 0));
         for (int k = 0; k < (int)std::min<uint64_t>(ngroups, S); ++k) HIP_TRY(hipHostGetDevicePointer(&bout_dev[k], ctx->pin_bout[k], 0));
         HIP_TRY(hipHostGetDevicePointer(&rec_dev_base, (void*)ctx->h_res, 0));
         CopyPool::Busy busy(ctx->copier.get());
@@ -1648,7 +1660,8 @@ static int stage1_index_batch_body(csvsimd_ctx* ctx, csvsimd_host_batch_item* it
             await([&] { return aborted() || sh.staged.load(std::memory_order_acquire) > j; });
             if (aborted()) return sh.err != CSVSIMD_OK ? sh.err : CSVSIMD_ERR_INTERNAL;
             hipStream_t cs = (j & 1) ? ctx->in_stream2 : ctx->in_stream;
-            HIP_TRY(hipMemcpyAsync(ctx->d_in[k], ctx->pin_in[k], g.in_bytes, hipMemcpyHostToDevice, cs));
+            if (pin_dev[k]) HIP_TRY(csvsimd::launch_h2d_blit(ctx->d_in[k], pin_dev[k], g.in_bytes, cs));  // (groups are <= 4 MiB: h2d_blit_kernel)
+            else HIP_TRY(hipMemcpyAsync(ctx->d_in[k], ctx->pin_in[k], g.in_bytes, hipMemcpyHostToDevice, cs));
             HIP_TRY(hipEventRecord(ctx->ev_in[k], cs));
             bump(sh.h2d, j + 1);
             HIP_TRY(hipStreamWaitEvent(st, ctx->ev_in[k], 0));

@@ -21,7 +21,7 @@ CMD="python3 $REPO/bench.py --only-consumers-large"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/cl_stats" -- $CMD > "$OUT/cl_stats.log" 2>&1
 find "$OUT/cl_stats" -name "*kernel_stats.csv" -exec cp {} "$OUT/r05_kernel_stats_consumers_1GiB.csv" \;
 i=0
-for grp in FETCH_SIZE WRITE_SIZE "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
+for grp in FETCH_SIZE WRITE_SIZE "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
     i=$((i + 1))
     rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmc$i" -- $CMD > "$OUT/pmc$i.log" 2>&1 || echo "pass $i ($grp) failed" >> "$OUT/pmc_failures.txt"
 done
@@ -37,11 +37,30 @@ for path in glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv")
                 continue
             acc[k.split("(")[0]][r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
 res = {}
+CASES = ("all_distinct", "100_values", "10000_values")   # bench.py consumers_large_leg runs them in this order, 16 calls each
 for k, c in sorted(acc.items()):
     e = {}
     for name, per in c.items():
-        vals = sorted(per.values())
-        e[name] = {"dispatches": len(vals), "median_per_dispatch": vals[len(vals) // 2], "max_per_dispatch": vals[-1]}
+        order = sorted(per, key=lambda d: int(d))
+        vals = [per[d] for d in order]
+        sv = sorted(vals)
+        e[name] = {"dispatches": len(vals), "median_per_dispatch": sv[len(sv) // 2], "max_per_dispatch": sv[-1]}
+        if "colfreq" in k and len(vals) % 3 == 0:
+            third = len(vals) // 3
+            for ci, case in enumerate(CASES):
+                part = sorted(vals[ci * third:(ci + 1) * third])
+                e[name][case] = part[len(part) // 2]
+    # bytes the L2 requested from the fabric, by request size (the 32 / 64 / 128-byte counters); FETCH_SIZE tallies every
+    # request at 64 bytes, which is why it reads half of a stream of 128-byte requests
+    def med(name, case=None):
+        v = e.get(name)
+        return None if v is None else (v[case] if case and case in v else v["median_per_dispatch"])
+    for case in ((None,) if "colfreq" not in k else (None,) + CASES):
+        a, b, c128, tot = med("TCC_EA0_RDREQ_32B_sum", case), med("TCC_EA0_RDREQ_64B_sum", case), med("TCC_EA0_RDREQ_128B_sum", case), med("TCC_EA0_RDREQ_sum", case)
+        if None not in (a, b, c128, tot):
+            e["read_bytes_by_request_size" + ("" if case is None else "_" + case)] = {
+                "32B": a, "64B": b, "128B": c128, "all_requests": tot, "bytes": 32 * a + 64 * b + 128 * c128,
+                "requests_not_in_a_size_counter": tot - a - b - c128}
     res[k] = e
 json.dump(res, open(os.path.join(out, "r05_pmc_consumers_1GiB.json"), "w"), indent=1)
 print(json.dumps(res, indent=1)[:6000])
