@@ -1086,15 +1086,11 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
     // kernel: profiles/r05_api_cost.txt), but this kernel's loads are the transposing ones — a wave instruction takes 16 bytes
     // from each of 64 different 64-byte segments — and host memory is not cached on the GPU side: every segment crosses the
     // link four times.  32 MiB: 1 341 us against 947 us with the copies; 4 MiB: no difference: profiles/r05_midsize_zero_copy.txt.)
-    // a file of a few MiB: the chunks go in by a kernel that reads the pinned slot, not by the copy engine (its ~18 us per copy
-    // are a fifth of such a call: text_kernels.hip, h2d_blit_kernel)
-    uint64_t blit_max = 64ull << 20;
-    if (const char* e = getenv("CSVSIMD_INGEST_BLIT_MIB")) blit_max = (uint64_t)std::max(0, atoi(e)) << 20;  // TUNING
-    const bool blit = len <= blit_max;
-    void* pin_dev[S] = {};
-    for (int k = 0; k < S && blit; ++k)
-        if (ctx->pin_in[k]) HIP_TRY(hipHostGetDevicePointer(&pin_dev[k], ctx->pin_in[k], 0));
-    // ... and the host-side copies ARE the critical path — slices of 128 KiB, workers polling for them
+    // (Measured and rejected as well: a chunk's way in as a KERNEL that reads the pinned slot with contiguous 16-byte wave loads
+    // instead of a hipMemcpyAsync with its ~18 us of fixed cost — alone such a kernel reads pinned memory at the link's rate,
+    // inside the pipeline, next to the staging copies and the stage-1 launches, it made 22 GiB/s: 4 MiB 262 us against 225,
+    // 32 MiB 1 429 against 956, the 10 000-file batch 1.92 ms against 1.36: profiles/r05_midsize_blit.txt.)
+    // a file of a few MiB: the host-side copies ARE the critical path — slices of 128 KiB, workers polling for them
     const size_t min_slice = len <= (64ull << 20) ? (128u << 10) : CopyPool::kMinSlice;
     CopyPool::Busy busy(len <= (256ull << 20) ? ctx->copier.get() : nullptr);
 
@@ -1300,8 +1296,7 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
         // 68 chunked copies and one copy of the same 2 GiB) overlap the other stream's transfer instead of idling the link.
         // d_in[k] is free: the record of the slot's previous chunk (i - S) was read before this call (S > kLag).
         hipStream_t cs = (h2d_streams == 2 && (i & 1)) ? ctx->in_stream2 : ctx->in_stream;
-        if (blit) HIP_TRY(csvsimd::launch_h2d_blit(ctx->d_in[k], pin_dev[k], clen, cs));  // (see text_kernels.hip: h2d_blit_kernel)
-        else HIP_TRY(hipMemcpyAsync(ctx->d_in[k], ctx->pin_in[k], clen, hipMemcpyHostToDevice, cs));
+        HIP_TRY(hipMemcpyAsync(ctx->d_in[k], ctx->pin_in[k], clen, hipMemcpyHostToDevice, cs));
         HIP_TRY(hipEventRecord(ctx->ev_in[k], cs));
         bump(sh.h2d, i + 1);
         HIP_TRY(hipStreamWaitEvent(st, ctx->ev_in[k], 0));
@@ -1538,10 +1533,7 @@ static int stage1_index_batch_body(csvsimd_ctx* ctx, csvsimd_host_batch_item* it
             }
         hipStream_t st = ctx->pipe_stream;
         void* bout_dev[S] = {};
-        void* pin_dev[S] = {};
         void* rec_dev_base = nullptr;
-        if (!getenv("CSVSIMD_INGEST_BLIT_MIB") || atoi(getenv("CSVSIMD_INGEST_BLIT_MIB")) > 0)  // TUNING
-            for (int k = 0; k < (int)std::min<uint64_t>(ngroups, S); ++k) HIP_TRY(hipHostGetDevicePointer(&pin_dev[k], ctx->pin_in[k], 0));
         for (int k = 0; k < (int)std::min<uint64_t>(ngroups, S); ++k) HIP_TRY(hipHostGetDevicePointer(&bout_dev[k], ctx->pin_bout[k], 0));
         HIP_TRY(hipHostGetDevicePointer(&rec_dev_base, (void*)ctx->h_res, 0));
         CopyPool::Busy busy(ctx->copier.get());
@@ -1660,8 +1652,7 @@ static int stage1_index_batch_body(csvsimd_ctx* ctx, csvsimd_host_batch_item* it
             await([&] { return aborted() || sh.staged.load(std::memory_order_acquire) > j; });
             if (aborted()) return sh.err != CSVSIMD_OK ? sh.err : CSVSIMD_ERR_INTERNAL;
             hipStream_t cs = (j & 1) ? ctx->in_stream2 : ctx->in_stream;
-            if (pin_dev[k]) HIP_TRY(csvsimd::launch_h2d_blit(ctx->d_in[k], pin_dev[k], g.in_bytes, cs));  // (groups are <= 4 MiB: h2d_blit_kernel)
-            else HIP_TRY(hipMemcpyAsync(ctx->d_in[k], ctx->pin_in[k], g.in_bytes, hipMemcpyHostToDevice, cs));
+            HIP_TRY(hipMemcpyAsync(ctx->d_in[k], ctx->pin_in[k], g.in_bytes, hipMemcpyHostToDevice, cs));
             HIP_TRY(hipEventRecord(ctx->ev_in[k], cs));
             bump(sh.h2d, j + 1);
             HIP_TRY(hipStreamWaitEvent(st, ctx->ev_in[k], 0));

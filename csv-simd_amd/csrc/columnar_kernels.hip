@@ -985,7 +985,7 @@ __device__ __forceinline__ u32 zero_bytes32(u32 x) {  // bit 7 of every byte of 
     const u32 k7 = 0x7f7f7f7fu;
     return ~(((x & k7) + k7) | x | k7);
 }
-template <u32 STRIDE>
+template <u32 STRIDE, bool COALESCED>
 __global__ __launch_bounds__(256, 2) void colsearch_small_kernel(const ColView c, const uint8_t* __restrict__ needle, u32 m, int mode,
                                                                  u64* __restrict__ bitmap, u64* __restrict__ count,
                                                                  u64* __restrict__ truncated) {
@@ -1012,22 +1012,33 @@ __global__ __launch_bounds__(256, 2) void colsearch_small_kernel(const ColView c
     u32 hits = 0, trunc = 0;
     const u64 step = ((u64)gridDim.x * blockDim.x) >> 6;
     u64 word = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    // The batch in flight: 64 rows.  A wave's loads are 16 bytes per lane over CONTIGUOUS kibibytes (two instructions cover
-    // the 2 KiB of 64 32-byte rows): a lane that fetched its own row — two loads 32 bytes apart from its neighbour's —
-    // streamed at 4.9 TB/s, this layout at the rate of a plain copy.  With 32-byte rows a lane therefore holds two HALVES:
-    // piece `lane` of rows 0..31 (row lane / 2, half lane & 1) and piece `lane` of rows 32..63; neighbours swap one of them
-    // (DPP) and the even lanes end up with rows 0..31, the odd lanes with rows 32..63 — row_of_lane below.
+    // The batch in flight: 64 rows.  Two ways to fetch 32-byte rows:
+    //   COALESCED  a wave's loads are 16 bytes per lane over CONTIGUOUS kibibytes (two instructions cover the 2 KiB of 64 rows).
+    //              A lane then holds two HALVES — piece `lane` of rows 0..31 (row lane / 2, half lane & 1) and piece `lane` of
+    //              rows 32..63 — neighbours swap one of them (DPP), the even lanes end up with rows 0..31, the odd lanes with
+    //              rows 32..63 (row_of_lane), and the ballot's bits are un-interleaved.  equals / starts-with, which are all
+    //              memory: 0.213 ms for 1 GiB = 63 % of 8 TB/s (a lane fetching its own row: 0.230 = 58 %).
+    //   otherwise  a lane fetches its own row (two loads 32 bytes apart from its neighbour's: 4.9 TB/s).  `contains`, which is
+    //              bound by its ~200 VALU instructions per row: the swap, the selects and the bit shuffle cost it more
+    //              (0.29 ms) than the better stream gives (0.265 ms without them) — profiles/r05_consumers_1GiB_*.json.
+    constexpr bool kSwap = COALESCED && STRIDE == 32;
     u32x4c va = {0, 0, 0, 0}, vb = {0, 0, 0, 0};
     u32 vlen = STRIDE;
-    const u32 row_of_lane = STRIDE == 32 ? (lane >> 1) + ((lane & 1u) << 5) : lane;
+    const u32 row_of_lane = kSwap ? (lane >> 1) + ((lane & 1u) << 5) : lane;
     auto fetch = [&](u64 wd) {
         if (wd >= n_words) return;
         const u64 i0 = wd * 64;
-        const u64 pieces = c.n_rows * (STRIDE / 16);  // 16-byte pieces of the column
-        const u32x4c* const p = reinterpret_cast<const u32x4c*>(c.col + i0 * STRIDE);
-        const u64 q0 = i0 * (STRIDE / 16);
-        va = q0 + lane < pieces ? __builtin_nontemporal_load(p + lane) : u32x4c{0, 0, 0, 0};
-        if (STRIDE == 32) vb = q0 + 64 + lane < pieces ? __builtin_nontemporal_load(p + 64 + lane) : u32x4c{0, 0, 0, 0};
+        if (kSwap) {
+            const u64 pieces = c.n_rows * 2;  // 16-byte pieces of the column
+            const u32x4c* const p = reinterpret_cast<const u32x4c*>(c.col + i0 * STRIDE);
+            const u64 q0 = i0 * 2;
+            va = q0 + lane < pieces ? __builtin_nontemporal_load(p + lane) : u32x4c{0, 0, 0, 0};
+            vb = q0 + 64 + lane < pieces ? __builtin_nontemporal_load(p + 64 + lane) : u32x4c{0, 0, 0, 0};
+        } else if (i0 + lane < c.n_rows) {
+            const u32x4c* const p = reinterpret_cast<const u32x4c*>(c.col + (i0 + lane) * STRIDE);
+            va = __builtin_nontemporal_load(p);
+            if (STRIDE == 32) vb = __builtin_nontemporal_load(p + 1);
+        }
         vlen = (c.len && i0 + row_of_lane < c.n_rows) ? __builtin_nontemporal_load(c.len + i0 + row_of_lane) : STRIDE;
     };
     fetch(word);
@@ -1037,7 +1048,7 @@ __global__ __launch_bounds__(256, 2) void colsearch_small_kernel(const ColView c
         fetch(word + step);  // (the loads of the next batch are in flight while this one is searched)
         const u64 i = word * 64 + row_of_lane;
         u32 d[D + 1];
-        if (STRIDE == 32) {
+        if (kSwap) {
             // the half my neighbour needs: an even lane gives away its piece of rows 32..63, an odd lane its piece of rows 0..31
             const bool odd = (lane & 1u) != 0;
             const u32x4c give = odd ? ra : rb;
@@ -1051,6 +1062,7 @@ __global__ __launch_bounds__(256, 2) void colsearch_small_kernel(const ColView c
             d[4] = hi.x; d[5] = hi.y; d[6] = hi.z; d[7] = hi.w;
         } else {
             d[0] = ra.x; d[1] = ra.y; d[2] = ra.z; d[3] = ra.w;
+            if (STRIDE == 32) { d[4] = rb.x; d[5] = rb.y; d[6] = rb.z; d[7] = rb.w; }
         }
         d[D] = 0;
         bool match = false;
@@ -1106,7 +1118,7 @@ __global__ __launch_bounds__(256, 2) void colsearch_small_kernel(const ColView c
             }
         }
         u64 bits = __ballot(match);
-        if (STRIDE == 32) {
+        if (kSwap) {
             // bit 2k = row k, bit 2k + 1 = row 32 + k: the even bits, packed, are the word's low half, the odd bits its high half
             auto pack_even = [](u64 x) -> u64 {
                 x &= 0x5555555555555555ull;
@@ -1135,11 +1147,14 @@ hipError_t launch_colsearch(const void* d_col, const void* d_len, u64 n_rows, u3
     // rows of 16 / 32 bytes and a needle that fits the row: the register-resident search.  A persistent-sized grid (8
     // workgroups per CU) whose waves walk the column with one batch of loads in flight each.
     const bool small = (stride == 16 || stride == 32) && needle_len <= stride;
-    if (small && stride == 32)
-        hipLaunchKernelGGL(colsearch_small_kernel<32>, dim3(cgrid_for(n_rows, 256, 2048)), dim3(256), 0, stream, c,
+    if (small && stride == 32 && mode != 2)
+        hipLaunchKernelGGL((colsearch_small_kernel<32, true>), dim3(cgrid_for(n_rows, 256, 2048)), dim3(256), 0, stream, c,
+                           (const uint8_t*)d_needle, needle_len, mode, (u64*)d_bitmap, (u64*)d_count, (u64*)d_truncated);
+    else if (small && stride == 32)
+        hipLaunchKernelGGL((colsearch_small_kernel<32, false>), dim3(cgrid_for(n_rows, 256, 2048)), dim3(256), 0, stream, c,
                            (const uint8_t*)d_needle, needle_len, mode, (u64*)d_bitmap, (u64*)d_count, (u64*)d_truncated);
     else if (small)
-        hipLaunchKernelGGL(colsearch_small_kernel<16>, dim3(cgrid_for(n_rows, 256, 2048)), dim3(256), 0, stream, c,
+        hipLaunchKernelGGL((colsearch_small_kernel<16, false>), dim3(cgrid_for(n_rows, 256, 2048)), dim3(256), 0, stream, c,
                            (const uint8_t*)d_needle, needle_len, mode, (u64*)d_bitmap, (u64*)d_count, (u64*)d_truncated);
     else
     hipLaunchKernelGGL(colsearch_kernel, dim3(cgrid_for(n_rows, 256, 8192)), dim3(256), 0, stream, c,

@@ -162,8 +162,6 @@ hipError_t launch_narrow_tape(const void* d_tape, const void* d_result, uint64_t
                               hipStream_t stream, void* h_rec_dev = nullptr, uint64_t seq = 0, void* d_arrivals = nullptr);
 // 16 x 64 KiB of the buffer: d_out2[0] += bytes equal to the delimiter, CR or LF, d_out2[1] += bytes looked at (both zeroed first)
 hipError_t launch_density_sample(const void* dbuf, uint64_t len, uint32_t delimiter, void* d_out2, hipStream_t stream);
-// a chunk's way in as a kernel: pinned host memory (through its device mapping) -> device memory, 64 KiB per workgroup
-hipError_t launch_h2d_blit(void* d_dst, const void* src_dev, uint64_t bytes, hipStream_t stream);
 int stage1_max_blocks_per_cu();
 
 }  // namespace csvsimd

@@ -358,41 +358,6 @@ __global__ __launch_bounds__(256) void narrow_tape_kernel(const u64* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
-// ingest of a file of a few MiB: the way IN of a chunk as a kernel.  A hipMemcpyAsync from pinned memory has a fixed cost of
-// ~18 us per copy that nothing hides in a call whose chunks cross the link in 18-150 us each (1 MiB + a flag kernel: 42 us
-// enqueue to seen; a kernel READING 1 MiB of pinned memory: the transfer + 6 us — profiles/r05_api_cost.txt), and alternating
-// copy streams do not overlap it (32 MiB in eight copies: 43 GiB/s on a 53 GiB/s link).  This kernel reads the pinned slot
-// through the GPU's mapping of it, 16 bytes per lane, contiguous per wave — the access shape that reaches the link's rate —
-// and writes HBM; 64 KiB per workgroup so that a 1-MiB chunk already has sixteen of them in flight.  Long files keep the
-// copy engine: it costs them 3 % and leaves every CU to the stage-1 kernel.
-// ---------------------------------------------------------------------------------------------
-typedef uint32_t u32x4b __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void h2d_blit_kernel(const u32x4b* __restrict__ src, u32x4b* __restrict__ dst, u64 n16) {
-    constexpr u32 kPer = (64u << 10) / 16;  // 16-byte pieces per workgroup
-    const u64 base = (u64)blockIdx.x * kPer;
-    u32x4b v[16];
-#pragma unroll
-    for (u32 j = 0; j < 16; ++j) {
-        const u64 i = base + (u64)j * 256 + threadIdx.x;
-        if (i < n16) v[j] = src[i];
-    }
-#pragma unroll
-    for (u32 j = 0; j < 16; ++j) {
-        const u64 i = base + (u64)j * 256 + threadIdx.x;
-        if (i < n16) __builtin_nontemporal_store(v[j], dst + i);
-    }
-}
-
-hipError_t launch_h2d_blit(void* d_dst, const void* src_dev, u64 bytes, hipStream_t stream) {
-    // both 16-byte aligned (hipMalloc / hipHostMalloc); a ragged tail is rounded up: the slots are padded
-    const u64 n16 = (bytes + 15) / 16;
-    if (n16 == 0) return hipSuccess;
-    const u64 wgs = (n16 + 4095) / 4096;
-    hipLaunchKernelGGL(h2d_blit_kernel, dim3((u32)wgs), dim3(256), 0, stream, (const u32x4b*)src_dev, (u32x4b*)d_dst, n16);
-    return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------------------
 // Which instantiation for data nobody has seen yet?  Sixteen 64-KiB windows spread over the buffer, one workgroup each:
 // bytes equal to the delimiter, CR or LF (quotes ignored: an upper bound of the entries, close enough to put the data on
 // one side of 0.125 entries per byte).  1 MiB read: a few microseconds, once per context (capi.cpp: the synchronous device
