@@ -985,6 +985,9 @@ __device__ __forceinline__ u32 zero_bytes32(u32 x) {  // bit 7 of every byte of 
     const u32 k7 = 0x7f7f7f7fu;
     return ~(((x & k7) + k7) | x | k7);
 }
+// ... and the cheaper test (one subtraction and one three-input bit operation): never misses a zero byte, but also flags a
+// byte that is 0x01 right above a zero byte (the borrow) — good enough for a FILTER whose survivors are compared in full
+__device__ __forceinline__ u32 zero_bytes32_filter(u32 x) { return (x - 0x01010101u) & ~x & 0x80808080u; }
 template <u32 STRIDE, bool COALESCED>
 __global__ __launch_bounds__(256, 2) void colsearch_small_kernel(const ColView c, const uint8_t* __restrict__ needle, u32 m, int mode,
                                                                  u64* __restrict__ bitmap, u64* __restrict__ count,
@@ -1081,12 +1084,21 @@ __global__ __launch_bounds__(256, 2) void colsearch_small_kernel(const ColView c
                 const u32 last = n - m;  // last start position
                 // start positions whose first min(m, 3) bytes are the needle's: an exact zero-byte test per prefix byte on the
                 // row shifted by that byte's offset (v_alignbyte), four positions per dword
+                // (needles of up to three bytes are decided by the filter alone: the exact test; longer ones are compared in full
+                // afterwards: the cheaper test)
                 u32 any = 0, cand[D];
+                const bool exact = m <= 3;  // (wave-uniform)
 #pragma unroll
                 for (u32 k = 0; k < D; ++k) {
-                    u32 z = zero_bytes32(d[k] ^ b0);
-                    if (m >= 2) z &= zero_bytes32(__builtin_amdgcn_alignbyte(d[k + 1], d[k], 1) ^ b1);
-                    if (m >= 3) z &= zero_bytes32(__builtin_amdgcn_alignbyte(d[k + 1], d[k], 2) ^ b2);
+                    u32 z;
+                    if (exact) {
+                        z = zero_bytes32(d[k] ^ b0);
+                        if (m >= 2) z &= zero_bytes32(__builtin_amdgcn_alignbyte(d[k + 1], d[k], 1) ^ b1);
+                        if (m >= 3) z &= zero_bytes32(__builtin_amdgcn_alignbyte(d[k + 1], d[k], 2) ^ b2);
+                    } else {
+                        z = zero_bytes32_filter(d[k] ^ b0) & zero_bytes32_filter(__builtin_amdgcn_alignbyte(d[k + 1], d[k], 1) ^ b1) &
+                            zero_bytes32_filter(__builtin_amdgcn_alignbyte(d[k + 1], d[k], 2) ^ b2);
+                    }
                     // positions 4k .. 4k + 3 that may start a match: <= last
                     const u32 cnt = last >= 4 * k + 3 ? 4u : (last >= 4 * k ? last - 4 * k + 1u : 0u);
                     z &= cnt >= 4 ? ~0u : ((1u << (8 * cnt)) - 1u);

@@ -79,10 +79,11 @@ bool dialect_hash(uint32_t delim, uint32_t quote, uint32_t esc, DialectHash& h);
 hipError_t launch_stage1(const Stage1Launch& L, hipStream_t stream);
 }  // namespace csvsimd
 namespace csvsimd_dense {
-hipError_t launch_stage1_dense(const csvsimd::Stage1Launch& L, hipStream_t stream);  // stage1_dense.hip
+hipError_t launch_stage1_dense(const csvsimd::Stage1Launch& L, hipStream_t stream);     // stage1_dense.hip
+hipError_t launch_stage1_dense_d1(const csvsimd::Stage1Launch& L, hipStream_t stream);  // stage1_dense_d1.hip (another delimiter / quote byte)
 hipError_t launch_stage1_batch_dense(void* d_items, void* d_first_tiles, void* d_tots, uint32_t n_items, uint32_t total_tiles,
                                      csvsimd_shard_result* d_results, void* scratch_base, uint64_t* scratch_desc,
-                                     uint32_t max_blocks, hipStream_t stream);
+                                     uint32_t max_blocks, hipStream_t stream);  // stage1_dense_batch.hip
 }
 namespace csvsimd {
 hipError_t launch_synth(void* dbuf, uint64_t file_off, uint64_t len, uint32_t cols, uint32_t width,

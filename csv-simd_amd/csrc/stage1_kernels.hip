@@ -1957,25 +1957,41 @@ static void fill_kernel_args(const Stage1Launch& L, KernelArgs& a) {
 }
 
 #ifdef CSVSIMD_DENSE_TU
-// the dense geometry's launchers: an emitting launch of the reference dialect or of another delimiter / quote byte (no
+// The dense geometry's launchers: an emitting launch of the reference dialect or of another delimiter / quote byte (no
 // escape byte), one buffer or — reference dialect — a batch (launch_stage1 / launch_stage1_batch of the other compilation
-// hand over)
+// hand over).  ONE instantiation per translation unit (CSVSIMD_DENSE_WHICH: stage1_dense.hip, stage1_dense_d1.hip,
+// stage1_dense_batch.hip): compiled next to its siblings the default dense kernel came out with other register allocation
+// (55 -> 91 SGPRs spilled to VGPR lanes), alone it is the kernel round 4 measured.
+#if CSVSIMD_DENSE_WHICH == 0
 hipError_t launch_stage1_dense(const Stage1Launch& L, hipStream_t stream) {
+    if (L.delimiter != ',' || L.quote != '"') return launch_stage1_dense_d1(L, stream);
     KernelArgs a;
     fill_kernel_args(L, a);
     const u32 want = a.num_tiles ? a.num_tiles : 1u;
     const u32 grid = want < L.max_blocks ? want : L.max_blocks;
     hipError_t e;
     if (L.ev_begin && (e = hipEventRecord(L.ev_begin, stream)) != hipSuccess) return e;
-    if (L.delimiter != ',' || L.quote != '"')
-        hipLaunchKernelGGL((stage1_kernel<true, 0, 1, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);
-    else
-        hipLaunchKernelGGL((stage1_kernel<true, 0, 0, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);
+    hipLaunchKernelGGL((stage1_kernel<true, 0, 0, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (L.ev_end && (e = hipEventRecord(L.ev_end, stream)) != hipSuccess) return e;
     return hipSuccess;
 }
+#elif CSVSIMD_DENSE_WHICH == 1
+hipError_t launch_stage1_dense_d1(const Stage1Launch& L, hipStream_t stream) {
+    KernelArgs a;
+    fill_kernel_args(L, a);
+    const u32 want = a.num_tiles ? a.num_tiles : 1u;
+    const u32 grid = want < L.max_blocks ? want : L.max_blocks;
+    hipError_t e;
+    if (L.ev_begin && (e = hipEventRecord(L.ev_begin, stream)) != hipSuccess) return e;
+    hipLaunchKernelGGL((stage1_kernel<true, 0, 1, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (L.ev_end && (e = hipEventRecord(L.ev_end, stream)) != hipSuccess) return e;
+    return hipSuccess;
+}
+#else
 // (first_tile of every buffer counts tiles of THIS geometry: CSVSIMD_MIN_TILE_BYTES)
 hipError_t launch_stage1_batch_dense(void* d_items, void* d_first_tiles, void* d_tots, u32 n_items, u32 total_tiles,
                                      csvsimd_shard_result* d_results, void* scratch_base, u64* scratch_desc, u32 max_blocks,
@@ -1998,6 +2014,7 @@ hipError_t launch_stage1_batch_dense(void* d_items, void* d_first_tiles, void* d
     hipLaunchKernelGGL((stage1_kernel<true, 0, 0, true, true>), dim3(grid), dim3(kThreads), 0, stream, a);
     return hipGetLastError();
 }
+#endif
 }  // namespace csvsimd_dense
 #else
 

@@ -184,15 +184,20 @@ int csvsimd_stage1_index_batch(csvsimd_ctx* ctx, csvsimd_host_batch_item* items,
 
 /* How csvsimd_stage1_index cuts a buffer of `len` bytes into the chunks it streams through the GPU (the host side owns
  * the chunking; reference: csv_simd::create maps the whole file and streaming is a TODO, src/lib.rs:61-74, README.md:23):
- * cuts[0] = 0 < cuts[1] < ... = len, chunk i = [cuts[i], cuts[i + 1]).  No chunk exceeds the 32-MiB slot, a large
- * file ramps up (4, 8, 16 MiB) and down, and no chunk of a multi-chunk plan is shorter than 4 MiB.  *n_cuts = entries
- * needed; CSVSIMD_ERR_TAPE_CAPACITY if cap is smaller (nothing is written). */
+ * cuts[0] = 0 < cuts[1] < ... = len, chunk i = [cuts[i], cuts[i + 1]).  No chunk exceeds the 32-MiB slot; the plan starts
+ * at len / 32 (1 ... 4 MiB), doubles up to full slots and halves down to len / 16 (1 ... 8 MiB) — a call waits for the
+ * staging of its first chunk and for the way back of its last one, everything between overlaps — and no chunk of a
+ * multi-chunk plan is shorter than 256 KiB (a stub is folded into its neighbour).  2 GiB: 4, 8, 16, 32 ... 32, 16, 8 MiB;
+ * 32 MiB: 1, 2, 4, 8, 3, 8, 4, 2; 4 MiB: 1, 2, 1.  *n_cuts = entries needed; CSVSIMD_ERR_TAPE_CAPACITY if cap is smaller
+ * (nothing is written). */
 int csvsimd_ingest_chunk_plan(uint64_t len, uint64_t* cuts, uint64_t cap, uint64_t* n_cuts);
 
 /* Where the wall time of the calling thread's most recent csvsimd_stage1_index[_dialect] call went, by thread of its
  * pipeline (seconds).  A file of three or more chunks runs on three host threads — stager (user buffer -> pinned
- * slots, ahead of the H2D copies), submitter (the caller: H2D copies, launches, records), expander (32-bit offsets in the
- * pinned slots -> the caller's tape); a shorter one runs the same steps in turn on the caller's thread. */
+ * slots, ahead of the H2D copies; the first chunk is staged by the caller), submitter (the caller: H2D copies, launches,
+ * polling the records the packing kernel publishes in pinned memory), expander (32-bit offsets in the pinned slots -> the
+ * caller's tape; the last chunk is expanded by the caller); a shorter one runs the same steps in turn on the caller's
+ * thread.  The two extra threads belong to the context and sleep between calls. */
 typedef struct csvsimd_ingest_phases {
     uint64_t bytes, chunks;
     uint32_t host_threads;       /* 3 or 1 */
