@@ -988,6 +988,31 @@ __device__ __forceinline__ u32 zero_bytes32(u32 x) {  // bit 7 of every byte of 
 // ... and the cheaper test (one subtraction and one three-input bit operation): never misses a zero byte, but also flags a
 // byte that is 0x01 right above a zero byte (the borrow) — good enough for a FILTER whose survivors are compared in full
 __device__ __forceinline__ u32 zero_bytes32_filter(u32 x) { return (x - 0x01010101u) & ~x & 0x80808080u; }
+// start positions of a row (D dwords + a zero dword) whose first PREFIX bytes are the needle's and that are <= last: one flag
+// (bit 7) per position in cand[]; returns their OR.  Straight-line code per (PREFIX, EXACT): with the prefix length tested
+// inside the unrolled loop a one-byte needle ran slower than a twelve-byte one.
+template <u32 D, u32 PREFIX, bool EXACT>
+__device__ __forceinline__ u32 prefix_candidates(const u32 (&d)[D + 1], u32 b0, u32 b1, u32 b2, u32 last, u32 (&cand)[D]) {
+    u32 any = 0;
+#pragma unroll
+    for (u32 k = 0; k < D; ++k) {
+        u32 z = EXACT ? zero_bytes32(d[k] ^ b0) : zero_bytes32_filter(d[k] ^ b0);
+        if (PREFIX >= 2) {
+            const u32 x1 = __builtin_amdgcn_alignbyte(d[k + 1], d[k], 1) ^ b1;
+            z &= EXACT ? zero_bytes32(x1) : zero_bytes32_filter(x1);
+        }
+        if (PREFIX >= 3) {
+            const u32 x2 = __builtin_amdgcn_alignbyte(d[k + 1], d[k], 2) ^ b2;
+            z &= EXACT ? zero_bytes32(x2) : zero_bytes32_filter(x2);
+        }
+        // positions 4k .. 4k + 3 that may start a match: <= last
+        const u32 cnt = last >= 4 * k + 3 ? 4u : (last >= 4 * k ? last - 4 * k + 1u : 0u);
+        z &= cnt >= 4 ? ~0u : ((1u << (8 * cnt)) - 1u);
+        cand[k] = z;
+        any |= z;
+    }
+    return any;
+}
 template <u32 STRIDE, bool COALESCED>
 __global__ __launch_bounds__(256, 2) void colsearch_small_kernel(const ColView c, const uint8_t* __restrict__ needle, u32 m, int mode,
                                                                  u64* __restrict__ bitmap, u64* __restrict__ count,
@@ -1086,25 +1111,11 @@ __global__ __launch_bounds__(256, 2) void colsearch_small_kernel(const ColView c
                 // row shifted by that byte's offset (v_alignbyte), four positions per dword
                 // (needles of up to three bytes are decided by the filter alone: the exact test; longer ones are compared in full
                 // afterwards: the cheaper test)
-                u32 any = 0, cand[D];
-                const bool exact = m <= 3;  // (wave-uniform)
-#pragma unroll
-                for (u32 k = 0; k < D; ++k) {
-                    u32 z;
-                    if (exact) {
-                        z = zero_bytes32(d[k] ^ b0);
-                        if (m >= 2) z &= zero_bytes32(__builtin_amdgcn_alignbyte(d[k + 1], d[k], 1) ^ b1);
-                        if (m >= 3) z &= zero_bytes32(__builtin_amdgcn_alignbyte(d[k + 1], d[k], 2) ^ b2);
-                    } else {
-                        z = zero_bytes32_filter(d[k] ^ b0) & zero_bytes32_filter(__builtin_amdgcn_alignbyte(d[k + 1], d[k], 1) ^ b1) &
-                            zero_bytes32_filter(__builtin_amdgcn_alignbyte(d[k + 1], d[k], 2) ^ b2);
-                    }
-                    // positions 4k .. 4k + 3 that may start a match: <= last
-                    const u32 cnt = last >= 4 * k + 3 ? 4u : (last >= 4 * k ? last - 4 * k + 1u : 0u);
-                    z &= cnt >= 4 ? ~0u : ((1u << (8 * cnt)) - 1u);
-                    cand[k] = z;
-                    any |= z;
-                }
+                u32 cand[D];
+                const u32 any = m == 1   ? prefix_candidates<D, 1, true>(d, b0, b1, b2, last, cand)
+                                : m == 2 ? prefix_candidates<D, 2, true>(d, b0, b1, b2, last, cand)
+                                : m == 3 ? prefix_candidates<D, 3, true>(d, b0, b1, b2, last, cand)
+                                         : prefix_candidates<D, 3, false>(d, b0, b1, b2, last, cand);
                 if (m <= 3) {
                     match = any != 0;
                 } else if (any) {
