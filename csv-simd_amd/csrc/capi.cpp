@@ -621,7 +621,7 @@ static int dialect_check(const csvsimd_dialect* d) {
 static int stage1_async_impl(csvsimd_ctx* ctx, const csvsimd_dialect* dialect, const void* dbuf, uint64_t len,
                              uint64_t base_off, uint32_t in_quote_in, void* dtape, uint64_t tape_cap, void* d_result,
                              void* hip_stream, const uint32_t* d_state = nullptr,
-                             const csvsimd_shard_result* d_chain = nullptr) {
+                             const csvsimd_shard_result* d_chain = nullptr, bool short_launch = false) {
     if (!ctx || !d_result || (len && !dbuf) || (!dtape && tape_cap)) return CSVSIMD_ERR_INVALID_ARG;
     // a shard's entry count must fit the 39-bit field of a look-back word (288 GB of HBM is 2^38.1 bytes)
     if (len >= (1ull << 39)) return CSVSIMD_ERR_INVALID_ARG;
@@ -647,6 +647,10 @@ static int stage1_async_impl(csvsimd_ctx* ctx, const csvsimd_dialect* dialect, c
     // (the dense instantiation exists for emitting launches without an escape byte: the reference dialect, another
     // delimiter / quote byte)
     L.dense = (!dialect || !dialect->escape) && dtape && ctx->density > csvsimd_ctx::kDenseThreshold;
+    // The host-buffer paths' launches over a few MiB (a small file, a chunk of a mid-size one) run the 64-KiB-tile geometry
+    // whatever the density: such a launch is all fill and drain (~21 us for 1 ... 8 MiB in the default geometry), and the
+    // shorter tiles shorten exactly that (a 4-MiB call: 178 -> 166 us, 2 MiB: 126 -> 115: profiles/r05_midsize_after.json).
+    if (short_launch && len <= (4ull << 20) && (!dialect || !dialect->escape) && dtape) L.dense = true;
     if (dialect) {
         L.delimiter = dialect->delimiter;
         L.quote = dialect->quote;
@@ -1013,7 +1017,8 @@ static int stage1_index_host_small(csvsimd_ctx* ctx, const csvsimd_dialect* dial
         HIP_TRY(hipHostGetDevicePointer(&d_in, ctx->pin_small_in, 0));
         HIP_TRY(hipHostGetDevicePointer(&d_out, ctx->pin_small_out, 0));
         const uint64_t cap = tape ? ctx->pin_small_out_entries : 0;
-        rc = stage1_async_impl(ctx, dialect, d_in, len, 0, 0, tape ? (char*)d_out + 64 : nullptr, cap, d_out, ctx->pipe_stream);
+        rc = stage1_async_impl(ctx, dialect, d_in, len, 0, 0, tape ? (char*)d_out + 64 : nullptr, cap, d_out, ctx->pipe_stream, nullptr,
+                               nullptr, /*short_launch=*/true);
         if (rc != CSVSIMD_OK) return rc;
         HIP_TRY(hipStreamSynchronize(ctx->pipe_stream));
         r = *reinterpret_cast<const csvsimd_shard_result*>(ctx->pin_small_out);
@@ -1203,14 +1208,20 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
         if (dialect) { dia = *dialect; dia.escape_in = (uint8_t)host_esc; }
         int rc_ = stage1_async_impl(ctx, dialect ? &dia : nullptr, ctx->d_in[k], clen, off, host_inq,
                                     tape ? ctx->d_tape[k] : nullptr, slot[k].cap, ctx->d_res[k], st, nullptr,
-                                    chained ? ctx->d_res[(k + S - 1) % S] : nullptr);
+                                    chained ? ctx->d_res[(k + S - 1) % S] : nullptr, /*short_launch=*/true);
         if (rc_ != CSVSIMD_OK) return rc_;
         void *out_dev = nullptr, *rec_dev = nullptr;
         if (tape) HIP_TRY(hipHostGetDevicePointer(&out_dev, ctx->pin_out[k], 0));
         HIP_TRY(hipHostGetDevicePointer(&rec_dev, (void*)ctx->h_res, 0));
         rec_dev = (char*)rec_dev + (size_t)k * sizeof(csvsimd_ctx::HostRecord);
         const double out_bytes = tape ? std::min<double>(entries_per_byte * (double)clen, (double)slot[k].cap) * 4.0 : 0.0;
-        const int wgs = (int)std::min<double>(std::max(1.0, std::ceil(out_bytes / (double)(2u << 20))), (double)ctx->n_cus);
+        // one workgroup per 2 MiB of offsets for a full-size chunk of a long file (a burst of writes stalls the copies behind it,
+        // above); the chunks of a file of a few MiB — and the ramp of a long one — have little behind them to protect, and a
+        // lone workgroup needs 20-150 us to push 128 KiB - 1 MiB over the link (the GPU-side timeline of a 4-MiB and a 32-MiB
+        // call, profiles/r05_midsize_timeline.txt: these kernels, one after the other on the stream, were the calls' critical
+        // path, not the copies: 597 of a 32-MiB call's 936 us): one workgroup per 16 KiB there
+        const double per_wg = clen <= (16ull << 20) ? (double)(16u << 10) : (double)(2u << 20);
+        const int wgs = (int)std::min<double>(std::max(1.0, std::ceil(out_bytes / per_wg)), (double)ctx->n_cus);
         slot[k].seq = ++ctx->pub_seq;
         HIP_TRY(csvsimd::launch_narrow_tape(ctx->d_tape[k], ctx->d_res[k], slot[k].cap, off, out_dev, wgs, st, rec_dev, slot[k].seq,
                                             (char*)ctx->d_pub + 64 * k));
