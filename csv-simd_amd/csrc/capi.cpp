@@ -1451,8 +1451,8 @@ int csvsimd_stage1_index_dialect(csvsimd_ctx* ctx, const csvsimd_dialect* dialec
  * than its share of the group's tape block (an entry per 4 bytes), goes through csvsimd_stage1_index's own path afterwards. */
 namespace {
 constexpr uint64_t kBatchItemMax = 1ull << 20;       // larger files are not worth packing: they fill a pipeline by themselves
-constexpr uint64_t kBatchGroupBytes = 4ull << 20;    // packed bytes per group (the 8-MiB slot class holds it with its table)
-constexpr uint32_t kBatchGroupItems = 2048;          // files per group (a file is at least one 256-KiB tile of ticket space)
+constexpr uint64_t kBatchGroupBytes = 4ull << 20;    // packed bytes per group (measured: 2 MiB 1.30-1.41 ms, 4 MiB 1.17-1.27, 7.5 MiB 1.50-1.55 for 10 000 files of 3.7 KiB)
+constexpr uint32_t kBatchGroupItems = 2048;          // files per group (a file is at least one tile of ticket space: the default scratch holds 16 384 64-KiB tiles)
 struct BatchGroup {
     uint32_t first = 0, count = 0;   // items [first, first + count) of the packed order
     uint64_t in_bytes = 0;           // packed input incl. table
@@ -1480,6 +1480,15 @@ static int stage1_index_batch_body(csvsimd_ctx* ctx, csvsimd_host_batch_item* it
         uint32_t out_cap;    // entries its share of the group's tape block holds
         uint64_t out_off;    // of its tape in the group's output block (bytes, 128-byte aligned)
     };
+    // Which geometry?  A file is at least one tile of the launch's ticket space, and a tile costs its workgroup a full count
+    // phase whatever it holds: 1 100 files of 3.7 KiB (a 4-MiB group) took the default geometry's 256-KiB tiles 90-100 us —
+    // as long as the group's copy (the call's GPU-side timeline, profiles/r05_small_files_timeline.txt) — so batches of
+    // small files run the 64-KiB-tile (dense) instantiation, which is the same tape for any density.
+    uint64_t packed_bytes = 0, packed_files = 0;
+    for (uint32_t i = 0; i < n_items; ++i)
+        if (items[i].len <= kBatchItemMax) { packed_bytes += items[i].len; ++packed_files; }
+    const bool small_tiles = packed_files && packed_bytes / packed_files <= (128u << 10);
+    const uint64_t tile_bytes = small_tiles ? CSVSIMD_MIN_TILE_BYTES : CSVSIMD_TILE_BYTES;
     std::vector<Placed> placed;
     std::vector<uint32_t> alone;  // items that take the single-file path
     std::vector<BatchGroup> groups;
@@ -1514,7 +1523,7 @@ static int stage1_index_batch_body(csvsimd_ctx* ctx, csvsimd_host_batch_item* it
             placed.push_back(Placed{i, (uint32_t)in_cur, (uint32_t)want_cap, out_cur});
             in_cur += in_need;
             out_cur += out_need;
-            g.tiles += it.len ? (uint32_t)((it.len + CSVSIMD_TILE_BYTES - 1) / CSVSIMD_TILE_BYTES) : 0u;
+            g.tiles += it.len ? (uint32_t)((it.len + tile_bytes - 1) / tile_bytes) : 0u;
             ++g.count;
         }
         close_group();
@@ -1531,7 +1540,7 @@ static int stage1_index_batch_body(csvsimd_ctx* ctx, csvsimd_host_batch_item* it
         }
         int rc = pipe_setup(ctx, (int)std::min<uint64_t>(ngroups, S), max_in);
         if (rc != CSVSIMD_OK) return rc;
-        rc = csvsimd_ctx_reserve(ctx, (uint64_t)max_tiles * CSVSIMD_TILE_BYTES);
+        rc = csvsimd_ctx_reserve(ctx, (uint64_t)max_tiles * tile_bytes);
         if (rc != CSVSIMD_OK) return rc;
         for (int k = 0; k < (int)std::min<uint64_t>(ngroups, S); ++k)
             if (ctx->pin_bout_bytes[k] < max_out) {
@@ -1605,7 +1614,7 @@ static int stage1_index_batch_body(csvsimd_ctx* ctx, csvsimd_host_batch_item* it
             for (uint32_t q = 0; q < g.count; ++q) {
                 firsts[q] = tiles;
                 const uint64_t len = items[placed[g.first + q].item].len;
-                tiles += len ? (uint32_t)((len + CSVSIMD_TILE_BYTES - 1) / CSVSIMD_TILE_BYTES) : 0u;
+                tiles += len ? (uint32_t)((len + tile_bytes - 1) / tile_bytes) : 0u;
             }
             const std::function<void(size_t, size_t)> pack = [&](size_t a, size_t b) {
                 for (size_t q = a; q < b; ++q) {
@@ -1676,8 +1685,9 @@ static int stage1_index_batch_body(csvsimd_ctx* ctx, csvsimd_host_batch_item* it
             ctx->last_stream = st;
             ctx->launched = true;
             char* const d_in = (char*)ctx->d_in[k];
-            HIP_TRY(csvsimd::launch_stage1_batch(d_in + g.off_table, d_in + g.off_first, d_in + g.off_tot, g.count, g.tiles,
-                                                 (csvsimd_shard_result*)bout_dev[k], ctx->scratch, L.scratch_desc, ctx->max_blocks, st));
+            HIP_TRY((small_tiles ? csvsimd_dense::launch_stage1_batch_dense : csvsimd::launch_stage1_batch)(
+                d_in + g.off_table, d_in + g.off_first, d_in + g.off_tot, g.count, g.tiles, (csvsimd_shard_result*)bout_dev[k],
+                ctx->scratch, L.scratch_desc, ctx->max_blocks, st));
             seqs[k] = ++ctx->pub_seq;
             // the publisher: (no tape to pack) copies record 0 next to the sequence word, which is what the host polls
             HIP_TRY(csvsimd::launch_narrow_tape(nullptr, bout_dev[k], 0, 0, nullptr, 1, st,
