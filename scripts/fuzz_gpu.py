@@ -94,7 +94,23 @@ def main():
         if time.time() > t_say:   # a line a minute: a silent GPU command is taken for hung after seven
             print(f"# {cases} cases", file=sys.stderr, flush=True)
             t_say = time.time() + 60
-        mode = int(rng.integers(0, 8)) if only_mode is None else only_mode
+        mode = int(rng.integers(0, 9)) if only_mode is None else only_mode
+        if mode == 8:
+            # MANY host files in one call (round 5: csvsimd_stage1_index_batch): every file's tape must be its own
+            k = int(rng.integers(1, 400))
+            files = []
+            for _ in range(k):
+                kind = rng.random()
+                size = int(rng.integers(0, 64)) if kind < 0.1 else int(rng.integers(0, 40 << 10)) if kind < 0.95 else int(rng.integers(0, 3 << 20))
+                files.append(make_case(rng)[:size].copy())
+            got = ctx.read_many(files)
+            for i, (f, g) in enumerate(zip(files, got)):
+                if not np.array_equal(g, oracle.scalar_read(f)):
+                    bad.append({"case": cases, "mode": "host batch", "item": i, "n": int(f.size)})
+                    break
+            cases += 1
+            bytes_total += sum(int(f.size) for f in files)
+            continue
         if mode == 0:
             # a BATCH of buffers in one launch: every record and every tape must be the buffer's own
             k = int(rng.integers(1, 12))
@@ -216,8 +232,11 @@ def main():
         dbuf[mis: mis + n] = torch.from_numpy(d)
         dtape = torch.full((cap + 8,), -1, dtype=torch.int64, device="cuda:0")
         # either instantiation (round 4: the dense one has another geometry and another emit path, the same results)
-        ctx.hint_density(1, 2) if rng.random() < 0.5 else ctx.hint_density(0, 0)
+        ctx.hint_density(1, 2) if rng.random() < 0.5 else ctx.hint_density(1, 1000)
+        # any grid (round 5: a launch, CSVSIMD_ENTER_GUESS included, needs no particular number of resident workgroups)
+        ctx.limit_workgroups(int(rng.choice([0, 0, 0, 1, 2, 3, 7, 33, 200])))
         r = ctx.stage1_index_device(dbuf.data_ptr() + mis, n, base, inq, dtape.data_ptr(), cap, allow_overflow=True)
+        ctx.limit_workgroups(0)
         torch.cuda.synchronize()
         k = min(r.count, cap)
         got = dtape[:k].cpu().numpy().view(np.uint64)

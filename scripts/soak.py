@@ -46,7 +46,9 @@ def main():
         for ci, (name, n, dbuf, dtape, cap, dialect, mis) in enumerate(cases):
             inq = launches % 3   # 0, 1, and 2 = CSVSIMD_ENTER_GUESS (the kernel's own choice must be the same every time too)
             # both instantiations in turn (round 4): the dense one must give the default one's record and checksum
-            ctx.hint_density(1, 2) if (launches // 3) % 2 else ctx.hint_density(0, 0)
+            ctx.hint_density(1, 2) if (launches // 3) % 2 else ctx.hint_density(1, 1000)
+            # ... on grids of every size (round 5: csvsimd_ctx_limit_workgroups; the signature must not depend on it)
+            ctx.limit_workgroups((0, 0, 1, 2, 5, 64)[(launches // 6) % 6])
             if dialect is None:
                 ctx.stage1_index_device_async(dbuf.data_ptr() + mis, n, 123, inq, dtape.data_ptr(), cap, dres.data_ptr())
             else:
