@@ -98,11 +98,14 @@ def main():
         if mode == 8:
             # MANY host files in one call (round 5: csvsimd_stage1_index_batch): every file's tape must be its own
             k = int(rng.integers(1, 400))
+            pool = np.concatenate([make_case(rng), make_case(rng)])       # the files are slices of two generated cases
             files = []
             for _ in range(k):
                 kind = rng.random()
                 size = int(rng.integers(0, 64)) if kind < 0.1 else int(rng.integers(0, 40 << 10)) if kind < 0.95 else int(rng.integers(0, 3 << 20))
-                files.append(make_case(rng)[:size].copy())
+                size = min(size, pool.size)
+                at = int(rng.integers(0, pool.size - size + 1))
+                files.append(pool[at: at + size].copy())
             got = ctx.read_many(files)
             for i, (f, g) in enumerate(zip(files, got)):
                 if not np.array_equal(g, oracle.scalar_read(f)):

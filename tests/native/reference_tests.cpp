@@ -204,6 +204,44 @@ void repeated_reads_one_context(csvsimd_ctx* ctx, const std::string& dir) {
     CHECK(best < 1000.0);
 }
 
+// A directory of small files in ONE call (round 5: csvsimd_stage1_index_batch): the reference reads file by file
+// (csv_simd::create, src/lib.rs:61-74); every item must come back exactly as csvsimd_stage1_index returns it alone —
+// here the crate's three fixtures, each three times, in one batch.
+void read_many_fixtures(csvsimd_ctx* ctx, const std::string& dir) {
+    const char* names[3] = {"/reader_test01.csv", "/sample.csv", "/sample_rx.csv"};
+    Mmap maps[3];
+    std::vector<std::uint64_t> alone[3];
+    for (int i = 0; i < 3; ++i) {
+        CHECK(maps[i].open(dir + names[i]));
+        CHECK(reader_read(ctx, maps[i], alone[i]));
+    }
+    std::vector<std::vector<std::uint64_t>> tapes(9);
+    std::vector<csvsimd_host_batch_item> items(9);
+    for (int k = 0; k < 9; ++k) {
+        const Mmap& m = maps[k % 3];
+        tapes[k].assign(m.len + 1, ~0ull);
+        items[k] = csvsimd_host_batch_item{m.ptr, m.len, tapes[k].data(), tapes[k].size(), 0, 0, 0};
+    }
+    const int rc = csvsimd_stage1_index_batch(ctx, items.data(), (std::uint32_t)items.size());
+    CHECK(rc == CSVSIMD_OK);
+    for (int k = 0; k < 9; ++k) {
+        CHECK(items[k].status == CSVSIMD_OK && items[k].tape_len == alone[k % 3].size());
+        tapes[k].resize(items[k].tape_len);
+        CHECK(tapes[k] == alone[k % 3]);
+    }
+    CHECK(tapes[0][1] == 4 && tapes[0].back() == 95);  // reader::tests::mk_index's two values, through the batch
+    // csvsimd_create (csv_simd::create in one call of the library) agrees with the C++ re-assembly above
+    csvsimd_tape* t = nullptr;
+    CHECK(csvsimd_create(ctx, (dir + "/sample.csv").c_str(), &t) == CSVSIMD_OK && t != nullptr);
+    if (t) {
+        std::uint64_t n = 0;
+        const std::uint64_t* idx = csvsimd_tape_index(t, &n);
+        CHECK(n == alone[1].size() && std::equal(idx, idx + n, alone[1].begin()));
+        CHECK(csvsimd_tape_field_cnt(t) == 3 && csvsimd_tape_record_cnt(t) == 15);
+        csvsimd_tape_destroy(t);
+    }
+}
+
 }  // namespace
 
 // in-process entry (tests/test_native_cpp.py loads libreference_tests.so with ctypes for the GPU part:
@@ -232,6 +270,8 @@ extern "C" int run_reference_tests(int gpu, const char* golden_dir) {
         create_sample_rx(ctx, dir);
         std::printf("test repeated reads, one context\n");
         repeated_reads_one_context(ctx, dir);
+        std::printf("test read_many(fixtures) + csvsimd_create\n");
+        read_many_fixtures(ctx, dir);
         csvsimd_ctx_destroy(ctx);
     } else {
         // no GPU: the library must refuse loudly, never fall back
