@@ -941,13 +941,9 @@ static std::vector<uint64_t> ingest_chunk_plan(uint64_t len, uint64_t uniform_ov
         }
         return cuts;
     }
-    auto knob = [](const char* name, uint64_t dflt) -> uint64_t {  // tuning knobs of scripts/probe_midsize.py; KiB
-        const char* e = getenv(name);
-        return (e && *e && atoll(e) > 0) ? (uint64_t)atoll(e) * 1024 : dflt;
-    };
     auto round64k = [](uint64_t v) { return (v + 65535) & ~(uint64_t)65535; };
-    const uint64_t first = knob("CSVSIMD_INGEST_FIRST_KIB", std::min(4 * kMiB, std::max(1 * kMiB, round64k(len / 32))));
-    const uint64_t last = knob("CSVSIMD_INGEST_LAST_KIB", std::min(8 * kMiB, std::max(1 * kMiB, round64k(len / 16))));
+    const uint64_t first = std::min(4 * kMiB, std::max(1 * kMiB, round64k(len / 32)));
+    const uint64_t last = std::min(8 * kMiB, std::max(1 * kMiB, round64k(len / 16)));
     std::vector<uint64_t> front, back;  // sizes from the file's start / from its end
     uint64_t rem = len, f = std::min(first, kMax), b = std::min(last, kMax);
     for (bool at_front = true; rem; at_front = !at_front) {

@@ -977,41 +977,32 @@ __global__ __launch_bounds__(256) void colsearch_kernel(const ColView c, const u
 // The kernel above reads a row eight bytes at a time, three dword loads per step and lane: on a 1-GiB column it is bound by
 // the number of load instructions, not by HBM (profiles/r05_consumers_1GiB_before.json).  Here a lane fetches its whole row
 // with one or two 16-byte loads — the NEXT batch of rows is requested before this one is searched — and searches it in
-// registers: `contains` finds the start positions whose first three bytes are the needle's by an exact zero-byte test on
-// four positions at a time (x ^ pattern has a zero byte <=> ((x & 0x7f..) + 0x7f..) | x has bit 7 clear there), and only
-// those — one position in 17 576 on random lower-case text — are compared in full, from the row's cache line.  Same results, bit for
-// bit (tests/test_gpu_columnar.py runs both on every case).
-__device__ __forceinline__ u32 zero_bytes32(u32 x) {  // bit 7 of every byte of x that is zero (exact: no borrow between bytes)
-    const u32 k7 = 0x7f7f7f7fu;
-    return ~(((x & k7) + k7) | x | k7);
-}
-// ... and the cheaper test (one subtraction and one three-input bit operation): never misses a zero byte, but also flags a
-// byte that is 0x01 right above a zero byte (the borrow) — good enough for a FILTER whose survivors are compared in full
-__device__ __forceinline__ u32 zero_bytes32_filter(u32 x) { return (x - 0x01010101u) & ~x & 0x80808080u; }
-// start positions of a row (D dwords + a zero dword) whose first PREFIX bytes are the needle's and that are <= last: one flag
-// (bit 7) per position in cand[]; returns their OR.  Straight-line code per (PREFIX, EXACT): with the prefix length tested
-// inside the unrolled loop a one-byte needle ran slower than a twelve-byte one.
-template <u32 D, u32 PREFIX, bool EXACT>
-__device__ __forceinline__ u32 prefix_candidates(const u32 (&d)[D + 1], u32 b0, u32 b1, u32 b2, u32 last, u32 (&cand)[D]) {
-    u32 any = 0;
+// registers: `contains` finds the start positions whose first three bytes are the needle's, four positions per dword and a
+// handful of instructions (prefix_candidates), and only those — one position in 17 576 on random lower-case text — are
+// compared in full, from the row's cache line.  Same results, bit for bit (tests/test_gpu_columnar.py: every mode, needle
+// length and alignment against Python's ==, startswith, in).
+// Start positions of a row (D dwords + a zero dword) whose first PREFIX bytes are the needle's: bit p of the result = position
+// p.  Per dword and prefix byte: one xor with the broadcast byte and one v_lerp_u8 — lerp(y, 0xff, 0) = (y + 255) >> 1 per byte
+// has bit 7 set exactly where y != 0 (the classification's trick, stage1_kernels.hip: no carry crosses a byte) — the shifted
+// views of the row by v_alignbyte; the three "differs" words are or-ed and inverted in one three-input bit operation, and the
+// four flags of a dword are gathered into the position mask by ONE v_dot4 (flags of 0x80 times weights 1, 2, 4, 8 — the odd
+// dwords use 16 ... 128 — summed into an accumulator per pair of dwords).  11 VALU per dword for a three-byte prefix; the
+// first version of this kernel spent 24 (64-bit SWAR zero-byte tests, a position limit per dword).
+template <u32 D, u32 PREFIX>
+__device__ __forceinline__ u32 prefix_candidates(const u32 (&d)[D + 1], u32 b0, u32 b1, u32 b2) {
+    u32 acc[D / 2];
 #pragma unroll
     for (u32 k = 0; k < D; ++k) {
-        u32 z = EXACT ? zero_bytes32(d[k] ^ b0) : zero_bytes32_filter(d[k] ^ b0);
-        if (PREFIX >= 2) {
-            const u32 x1 = __builtin_amdgcn_alignbyte(d[k + 1], d[k], 1) ^ b1;
-            z &= EXACT ? zero_bytes32(x1) : zero_bytes32_filter(x1);
-        }
-        if (PREFIX >= 3) {
-            const u32 x2 = __builtin_amdgcn_alignbyte(d[k + 1], d[k], 2) ^ b2;
-            z &= EXACT ? zero_bytes32(x2) : zero_bytes32_filter(x2);
-        }
-        // positions 4k .. 4k + 3 that may start a match: <= last
-        const u32 cnt = last >= 4 * k + 3 ? 4u : (last >= 4 * k ? last - 4 * k + 1u : 0u);
-        z &= cnt >= 4 ? ~0u : ((1u << (8 * cnt)) - 1u);
-        cand[k] = z;
-        any |= z;
+        u32 nz = __builtin_amdgcn_lerp(d[k] ^ b0, 0xffffffffu, 0u);
+        if (PREFIX >= 2) nz |= __builtin_amdgcn_lerp(__builtin_amdgcn_alignbyte(d[k + 1], d[k], 1) ^ b1, 0xffffffffu, 0u);
+        if (PREFIX >= 3) nz |= __builtin_amdgcn_lerp(__builtin_amdgcn_alignbyte(d[k + 1], d[k], 2) ^ b2, 0xffffffffu, 0u);
+        const u32 z = ~nz & 0x80808080u;  // bit 7 of every position whose prefix bytes all agree
+        acc[k >> 1] = __builtin_amdgcn_udot4(z, (k & 1u) ? 0x80402010u : 0x08040201u, (k & 1u) ? acc[k >> 1] : 0u, false);
     }
-    return any;
+    u32 c = 0;
+#pragma unroll
+    for (u32 j = 0; j < D / 2; ++j) c |= (acc[j] >> 7) << (8 * j);  // (sum of 0x80 * weight = the pair's eight flags << 7)
+    return c;
 }
 template <u32 STRIDE, bool COALESCED>
 __global__ __launch_bounds__(256, 2) void colsearch_small_kernel(const ColView c, const uint8_t* __restrict__ needle, u32 m, int mode,
@@ -1107,35 +1098,29 @@ __global__ __launch_bounds__(256, 2) void colsearch_small_kernel(const ColView c
                 match = true;
             } else if (n >= m) {
                 const u32 last = n - m;  // last start position
-                // start positions whose first min(m, 3) bytes are the needle's: an exact zero-byte test per prefix byte on the
-                // row shifted by that byte's offset (v_alignbyte), four positions per dword
-                // (needles of up to three bytes are decided by the filter alone: the exact test; longer ones are compared in full
-                // afterwards: the cheaper test)
-                u32 cand[D];
-                const u32 any = m == 1   ? prefix_candidates<D, 1, true>(d, b0, b1, b2, last, cand)
-                                : m == 2 ? prefix_candidates<D, 2, true>(d, b0, b1, b2, last, cand)
-                                : m == 3 ? prefix_candidates<D, 3, true>(d, b0, b1, b2, last, cand)
-                                         : prefix_candidates<D, 3, false>(d, b0, b1, b2, last, cand);
+                // start positions whose first min(m, 3) bytes are the needle's (prefix_candidates: exact), limited to the positions
+                // a match may start at: 0 .. last.  Needles of up to three bytes are decided by that alone.
+                const u32 cand = (m == 1   ? prefix_candidates<D, 1>(d, b0, b1, b2)
+                                  : m == 2 ? prefix_candidates<D, 2>(d, b0, b1, b2)
+                                           : prefix_candidates<D, 3>(d, b0, b1, b2)) &
+                                 (last >= 31u ? ~0u : ((2u << last) - 1u));
                 if (m <= 3) {
-                    match = any != 0;
-                } else if (any) {
+                    match = cand != 0;
+                } else if (cand) {
                     // rare (one start position in 17 576 on random lower-case text): the rest of the needle, from the row's
                     // cache line
                     const uint8_t* const row = c.col + i * STRIDE;
-#pragma unroll
-                    for (u32 k = 0; k < D; ++k) {
-                        u32 z = cand[k];
-                        while (z && !match) {
-                            const u32 pos = 4 * k + ((u32)__builtin_ctz(z) >> 3);
-                            z &= z - 1;
-                            bool ok = true;
-                            for (u32 q = 0; 8 * q < m && ok; ++q) {
-                                const u32 left = m - 8 * q;
-                                const u64 mask = left >= 8 ? ~0ull : ((1ull << (8 * left)) - 1ull);
-                                ok = ((col_load8(row, pos + 8 * q, STRIDE) ^ s_needle[q]) & mask) == 0;
-                            }
-                            match = ok;
+                    u32 z = cand;
+                    while (z && !match) {
+                        const u32 pos = (u32)__builtin_ctz(z);
+                        z &= z - 1;
+                        bool ok = true;
+                        for (u32 q = 0; 8 * q < m && ok; ++q) {
+                            const u32 left = m - 8 * q;
+                            const u64 mask = left >= 8 ? ~0ull : ((1ull << (8 * left)) - 1ull);
+                            ok = ((col_load8(row, pos + 8 * q, STRIDE) ^ s_needle[q]) & mask) == 0;
                         }
+                        match = ok;
                     }
                 }
             }
