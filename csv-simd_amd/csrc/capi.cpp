@@ -950,7 +950,9 @@ static std::vector<uint64_t> ingest_chunk_plan(uint64_t len, uint64_t uniform_ov
         uint64_t& next = at_front ? f : b;
         std::vector<uint64_t>& side = at_front ? front : back;
         uint64_t sz = std::min(next, rem);
-        if (rem - sz < sz / 4) sz = rem <= kMax ? rem : round64k(rem / 2);  // no stub: fold it, or cut what is left in two
+        // no stub (a remainder below a quarter of this chunk, or below 512 KiB: enqueueing a short copy blocks the caller): fold
+        // it, or cut what is left in two
+        if (rem - sz < std::max<uint64_t>(sz / 4, 512u << 10)) sz = rem <= kMax ? rem : round64k(rem / 2);
         side.push_back(sz);
         rem -= sz;
         next = std::min(next * 2, kMax);
@@ -1126,7 +1128,12 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
     struct Shared {
         std::mutex m;
         std::condition_variable cv;
-        std::atomic<uint64_t> staged{0};    // chunks whose bytes are in their pinned slot
+        std::atomic<uint64_t> staged{0};    // chunks whose bytes are in their pinned slot: all below this number are — counted by
+                                            // whoever stages chunks 1 .. (the stager thread, or the caller when it does everything)
+        std::atomic<bool> staged0{false};   // ... and chunk 0, which the CALLER stages while the stager thread is on chunk 1
+                                            // already: the two finish in either order (a hot stager with a short chunk 1 was
+                                            // first, its count was overwritten with 1, and the call waited for ever: found by
+                                            // scripts/fuzz_gpu.py's host-batch mode, round 5)
         std::atomic<uint64_t> h2d{0};       // chunks whose H2D copy has been enqueued (ev_in recorded)
         std::atomic<uint64_t> finished{0};  // chunks whose record has been read (slot[].at / ncopy / base valid)
         std::atomic<uint64_t> expanded{0};  // chunks whose entries have left their pinned slot
@@ -1182,7 +1189,15 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
             if (e != hipSuccess) { fail(CSVSIMD_ERR_HIP, std::string("hipEventSynchronize(ev_in): ") + hipGetErrorString(e)); return false; }
         }
         CSVSIMD_TIMED(t_copy, ctx->copier->copy(ctx->pin_in[k], buf + cuts[j], cuts[j + 1] - cuts[j], min_slice));
-        bump(sh.staged, j + 1);
+        if (j == 0) {
+            {
+                std::lock_guard<std::mutex> g(sh.m);
+                sh.staged0.store(true, std::memory_order_release);
+            }
+            sh.cv.notify_all();
+        } else {
+            bump(sh.staged, j + 1);
+        }
         return true;
     };
     // ---- expander: chunk j's 32-bit offsets -> the caller's tape ------------------------------------------------------------
@@ -1294,7 +1309,10 @@ static int stage1_index_host_body(csvsimd_ctx* ctx, const csvsimd_dialect* diale
         const uint64_t clen = cuts[i + 1] - cuts[i];
         {
             const double t0 = now();
-            await([&] { return sh.abort.load(std::memory_order_acquire) || sh.staged.load(std::memory_order_acquire) > i; });
+            await([&] {
+                return sh.abort.load(std::memory_order_acquire) ||
+                       (i == 0 ? sh.staged0.load(std::memory_order_acquire) : sh.staged.load(std::memory_order_acquire) > i);
+            });
             t_wait_staged += now() - t0;
             if (sh.abort.load(std::memory_order_acquire)) return sh.err != CSVSIMD_OK ? sh.err : CSVSIMD_ERR_INTERNAL;
         }
@@ -1558,6 +1576,7 @@ static int stage1_index_batch_body(csvsimd_ctx* ctx, csvsimd_host_batch_item* it
             std::mutex m;
             std::condition_variable cv;
             std::atomic<uint64_t> staged{0}, h2d{0}, finished{0}, expanded{0};
+            std::atomic<bool> staged0{false};  // (group 0 is the caller's, groups 1 .. the stager's: see stage1_index_host_body)
             std::atomic<bool> abort{false};
             int err = CSVSIMD_OK;
             std::string msg;
@@ -1630,7 +1649,15 @@ static int stage1_index_batch_body(csvsimd_ctx* ctx, csvsimd_host_batch_item* it
                 }
             };
             ctx->copier->parallel_for(g.count, 64, pack);
-            bump(sh.staged, j + 1);
+            if (j == 0) {
+                {
+                    std::lock_guard<std::mutex> g_(sh.m);
+                    sh.staged0.store(true, std::memory_order_release);
+                }
+                sh.cv.notify_all();
+            } else {
+                bump(sh.staged, j + 1);
+            }
             return true;
         };
         // ---- expander: every file of group j gets its tape and its outputs ---------------------------------------------------
@@ -1665,7 +1692,7 @@ static int stage1_index_batch_body(csvsimd_ctx* ctx, csvsimd_host_batch_item* it
         auto submit = [&](uint64_t j) -> int {
             const int k = (int)(j % S);
             const BatchGroup& g = groups[j];
-            await([&] { return aborted() || sh.staged.load(std::memory_order_acquire) > j; });
+            await([&] { return aborted() || (j == 0 ? sh.staged0.load(std::memory_order_acquire) : sh.staged.load(std::memory_order_acquire) > j); });
             if (aborted()) return sh.err != CSVSIMD_OK ? sh.err : CSVSIMD_ERR_INTERNAL;
             hipStream_t cs = (j & 1) ? ctx->in_stream2 : ctx->in_stream;
             HIP_TRY(hipMemcpyAsync(ctx->d_in[k], ctx->pin_in[k], g.in_bytes, hipMemcpyHostToDevice, cs));

@@ -187,7 +187,7 @@ int csvsimd_stage1_index_batch(csvsimd_ctx* ctx, csvsimd_host_batch_item* items,
  * cuts[0] = 0 < cuts[1] < ... = len, chunk i = [cuts[i], cuts[i + 1]).  No chunk exceeds the 32-MiB slot; the plan starts
  * at len / 32 (1 ... 4 MiB), doubles up to full slots and halves down to len / 16 (1 ... 8 MiB) — a call waits for the
  * staging of its first chunk and for the way back of its last one, everything between overlaps — and no chunk of a
- * multi-chunk plan is shorter than 256 KiB (a stub is folded into its neighbour).  2 GiB: 4, 8, 16, 32 ... 32, 16, 8 MiB;
+ * multi-chunk plan is shorter than 512 KiB (a stub is folded into its neighbour).  2 GiB: 4, 8, 16, 32 ... 32, 16, 8 MiB;
  * 32 MiB: 1, 2, 4, 8, 3, 8, 4, 2; 4 MiB: 1, 2, 1.  *n_cuts = entries needed; CSVSIMD_ERR_TAPE_CAPACITY if cap is smaller
  * (nothing is written). */
 int csvsimd_ingest_chunk_plan(uint64_t len, uint64_t* cuts, uint64_t cap, uint64_t* n_cuts);

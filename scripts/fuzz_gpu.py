@@ -95,6 +95,11 @@ def main():
             print(f"# {cases} cases", file=sys.stderr, flush=True)
             t_say = time.time() + 60
         mode = int(rng.integers(0, 9)) if only_mode is None else only_mode
+        if os.environ.get("FUZZ_TRACE"):   # which case is running (a hang is then the last line), and a watchdog per case
+            import faulthandler
+            faulthandler.cancel_dump_traceback_later()
+            faulthandler.dump_traceback_later(int(os.environ["FUZZ_TRACE"]), exit=True)
+            print(f"case {cases} mode {mode}", file=sys.stderr, flush=True)
         if mode == 8:
             # MANY host files in one call (round 5: csvsimd_stage1_index_batch): every file's tape must be its own
             k = int(rng.integers(1, 400))

@@ -119,3 +119,36 @@ def test_ten_thousand_4k_files_of_the_quoted_corpus(pkg, ctx, oracle):
     assert ctx.read_many([]) == []
     one = ctx.read_many([files[7]])
     assert np.array_equal(one[0], got[7])
+
+
+@pytest.mark.timeout(300)
+def test_hot_pipeline_threads_finish_in_any_order(pkg, oracle):
+    """Round 5's pipelines keep their stager / expander threads hot between calls, and the CALLER stages chunk (group) 0 while
+    the stager is on chunk 1 already: the two finish in either order.  The first version counted both in one word (the
+    stager's "2 staged" was overwritten by the caller's "1") and a call whose second chunk was short waited for ever — found
+    by scripts/fuzz_gpu.py, pinned here: thousands of back-to-back calls whose second chunk / group is a fraction of the
+    first, single files and batches alternating on one context."""
+    rng = np.random.default_rng(2)
+    c = pkg.Context(0)
+    try:
+        MiB = 1 << 20
+        sizes = [2 * MiB + 570_000, 2 * MiB + 600_001, 3 * MiB + 64, 2 * MiB + 524_289]     # plans [1 MiB, a short chunk, 1 MiB]
+        datas = [random_csvish(rng, n, 0.01) for n in sizes]
+        wants = [oracle.scalar_read(d) for d in datas]
+        for d in datas:
+            sz = [b - a for a, b in zip(pkg.ingest_chunk_plan(d.size), pkg.ingest_chunk_plan(d.size)[1:])]
+            assert len(sz) >= 3 and min(sz[1:-1] or sz) <= sz[0]
+        tapes = [np.empty(w.size + 8, dtype=np.uint64) for w in wants]
+        small = [random_csvish(rng, int(rng.integers(100, 9000)), 0.02) for _ in range(300)]
+        small_want = [oracle.scalar_read(f) for f in small]
+        for rep in range(1500):
+            i = rep % len(datas)
+            rc, tl, _ = c.read_into(datas[i], tapes[i])
+            assert rc == 0 and tl == wants[i].size
+            if rep % 100 == 0:
+                assert np.array_equal(tapes[i][:tl], wants[i])
+            if rep % 25 == 0:
+                got = c.read_many(small)
+                assert all(np.array_equal(g, w) for g, w in zip(got, small_want))
+    finally:
+        c.close()

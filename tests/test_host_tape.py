@@ -120,9 +120,9 @@ def test_ingest_chunk_plan_has_no_degenerate_chunk(pkg):
         sizes = [b - a for a, b in zip(cuts, cuts[1:])]
         assert all(s > 0 for s in sizes) and all(s <= 32 * MiB for s in sizes), (n, sizes)
         if len(sizes) > 1:
-            assert min(sizes) >= 256 * KiB, (n, sizes)
-            assert sizes[0] <= max(MiB, n // 32 + 64 * KiB) and sizes[0] <= 4 * MiB, (n, sizes)   # a short fill ...
-            assert sizes[-1] <= max(MiB, n // 16 + 64 * KiB) * 1.25 and sizes[-1] <= 10 * MiB, (n, sizes)   # ... and a short drain
+            assert min(sizes) >= 512 * KiB, (n, sizes)
+            assert sizes[0] <= max(MiB, n // 32 + 64 * KiB) + 512 * KiB and sizes[0] <= 4 * MiB + 512 * KiB, (n, sizes)   # a short fill ...
+            assert sizes[-1] <= max(MiB, n // 16 + 64 * KiB) * 1.25 + 512 * KiB and sizes[-1] <= 10 * MiB, (n, sizes)   # ... and a short drain
         # about log2 chunks on the way up and down, full slots between them
         assert len(sizes) <= 16 + n // (32 * MiB), (n, len(sizes))
     # a large file ramps up and down around full slots
