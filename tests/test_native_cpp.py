@@ -41,3 +41,15 @@ def test_reference_tests_gpu_part(exe, capfd):
     out = capfd.readouterr().out
     assert rc == 0, out
     assert "reader::tests::mk_index" in out and "create(sample_rx.csv)" in out and "ok: all checks passed" in out
+
+
+def test_ingest_pool_under_thread_sanitizer():
+    """csv-simd_amd/host/ingest_pool.hpp (CopyPool, TaskThread: what the ingest pipelines run their host side on) built with
+    -fsanitize=thread and driven like a pipeline drives it — a stager and an expander thread and the caller slicing work over
+    one pool, hot and cold starts, chunk 0 by the caller while the stager is on chunk 1: every byte in place, no data race
+    reported.  No GPU involved (GPU sanitizers are not available on this pool; the host side is where the threads are)."""
+    subprocess.run(["make", "-C", NATIVE, "-s", "pool_stress"], check=True)
+    p = subprocess.run([os.path.join(NATIVE, "pool_stress")], capture_output=True, text=True, timeout=600)
+    out = p.stdout + p.stderr
+    assert p.returncode == 0 and "pool_stress ok" in out, out[-3000:]
+    assert "ThreadSanitizer" not in out, out[-3000:]
