@@ -132,7 +132,7 @@ def test_hot_pipeline_threads_finish_in_any_order(pkg, oracle):
     c = pkg.Context(0)
     try:
         MiB = 1 << 20
-        sizes = [2 * MiB + 570_000, 2 * MiB + 600_001, 3 * MiB + 64, 2 * MiB + 524_289]     # plans [1 MiB, a short chunk, 1 MiB]
+        sizes = [2 * MiB + 570_000, 2 * MiB + 600_001, 2 * MiB + 800_064, 2 * MiB + 524_289]     # plans [1 MiB, a short chunk, 1 MiB]
         datas = [random_csvish(rng, n, 0.01) for n in sizes]
         wants = [oracle.scalar_read(d) for d in datas]
         for d in datas:
