@@ -827,7 +827,7 @@ def consumers_leg(pkg, oracle, device):
     col_ptr, len_ptr = ccols[field].data_ptr(), clens[field].data_ptr()
 
     def device_time(fn, reps=10):
-        """the call is asynchronous (two launches): events on the launch stream around `reps` back-to-back calls"""
+        """the call is asynchronous (two or three launches): events on the launch stream around `reps` back-to-back calls"""
         t_ = None
         for _ in range(3):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -788,7 +788,7 @@ def columnar_frequency_device(ctx: "Context", d_col: int, d_len: int, n_records:
 def columnar_frequency_device_async(ctx: "Context", d_col: int, d_len: int, n_records: int, stride: int, first_record: int,
                                     d_scratch: int, scratch_bytes: int, d_entries: int, entries_cap: int, d_status: int,
                                     stream: int = 0) -> None:
-    """The same as two launches on `stream` and nothing else: the 32-byte status record (n_records, n_distinct, truncated,
+    """The same as two launches on `stream` (three from 4 Mi records on) and nothing else: the 32-byte status record (n_records, n_distinct, truncated,
     overflow as 4 x uint64) is written to DEVICE memory at d_status; capturable into a graph."""
     _check(lib().csvsimd_columnar_frequency_device_async(ctx._h, d_col or None, d_len or None, n_records, stride,
                                                          first_record, d_scratch, scratch_bytes, d_entries or None,

@@ -319,7 +319,9 @@ __device__ __forceinline__ bool rows_equal(const ColView& c, u64 i, u64 j, u32 l
 //       (first record, count) straight to the output, reserving its range with ONE atomic per workgroup.
 //
 // Nothing is cleared per call (the status words are written, not accumulated, or zeroed by pass 1), nothing is scanned
-// that was not written, and the call is two launches on the caller's stream: asynchronous and capturable.
+// that was not written, and the call is two launches on the caller's stream: asynchronous and capturable.  (Round 5: from
+// 4 Mi records on a third launch goes first — colfreq_stream_kernel below, which counts long columns of few values in one
+// streaming pass per CU and hands the shares it cannot count to pass 1.)
 // Algorithmic bytes: the column and its lengths read once, 16 bytes per distinct value written; the tuples add 12 bytes
 // written + read per value that survives pass 1's aggregation.
 // ---------------------------------------------------------------------------------------------
@@ -357,16 +359,22 @@ static constexpr u32 kCfRound2 = 6144;       // tuples a pass-2 round may be ask
 #define CSVSIMD_CF_THREADS2 1024
 #endif
 static constexpr u32 kCfThreads2 = CSVSIMD_CF_THREADS2;
+#ifndef CSVSIMD_CF_BATCH2
+#define CSVSIMD_CF_BATCH2 1
+#endif
+static constexpr u32 kCfBatch2 = CSVSIMD_CF_BATCH2;  // tuples a pass-2 thread has in flight (tuning builds: see the loop)
 static constexpr u32 kCfTupleWords = 3;      // {first record, count, low 32 hash bits}
 static constexpr u32 kCfTickets = 16;        // pass 2's ticket counters, a 128-byte line each
 static constexpr u32 kCfTicketBytes = kCfTickets * 128;
+static constexpr u32 kCfMaxShares = 1024;    // colfreq_stream_kernel's workgroups (one per CU)
+static constexpr u32 kCfShareFlagBytes = kCfMaxShares * 4;
 
 struct ColFreqGeom {
     u32 slabs;       // W: pass-1 workgroups = tuple blocks
     u32 parts;       // P: partitions (a power of two)
     u64 offs_bytes;  // u16 offs[P + 2][W]: row p = where partition p starts in every block, row P = the block's tuple
                      // count, row P + 1 = records of the slab longer than the stride
-    u64 bytes;       // the whole scratch: [offs | tuples: W blocks of kCfSlab x 12 bytes | pass 2's tickets]
+    u64 bytes;       // the whole scratch: [offs | tuples: W blocks of kCfSlab x 12 bytes | pass 2's tickets | the shares' flags]
 };
 static ColFreqGeom colfreq_geom(u64 n_rows) {
     ColFreqGeom g;
@@ -377,7 +385,7 @@ static ColFreqGeom colfreq_geom(u64 n_rows) {
     while (p < want && p < kCfMaxParts) p <<= 1;
     g.parts = p;
     g.offs_bytes = (((u64)(g.parts + 2) * g.slabs * 2) + 255) & ~255ull;
-    g.bytes = g.offs_bytes + (u64)g.slabs * kCfSlab * kCfTupleWords * 4 + kCfTicketBytes;
+    g.bytes = g.offs_bytes + (u64)g.slabs * kCfSlab * kCfTupleWords * 4 + kCfTicketBytes + kCfShareFlagBytes;
     return g;
 }
 u64 colfreq_scratch_bytes(u64 n_rows) { return colfreq_geom(n_rows).bytes; }
@@ -419,7 +427,8 @@ __device__ u64 g_cf_trace[2][4096][8];
 template <bool ROWS_IN_LDS>
 __global__ __launch_bounds__(kCfThreads1, 4) void colfreq_partition_kernel(const ColView c, unsigned short* __restrict__ offs,
                                                                        u32* __restrict__ tuples, u32 parts, u32 slabs,
-                                                                       ColFreqStatus* __restrict__ status, u32* __restrict__ ticket) {
+                                                                       ColFreqStatus* __restrict__ status, u32* __restrict__ ticket,
+                                                                       const u32* __restrict__ share_done, u32 per_share) {
     __shared__ u64 s_key[kCfLds];    // hash bits 32..63 << 32 | (record - r0) + 1; 0 = empty
     __shared__ u32 s_count[kCfLds];
     __shared__ u32 s_first[kCfLds];  // smallest (record - r0) holding the slot's value
@@ -431,7 +440,12 @@ __global__ __launch_bounds__(kCfThreads1, 4) void colfreq_partition_kernel(const
     // phase A: the representatives' rows (kCfLds x 32 bytes); phase B: this block's tuples, sorted, before they leave
     __shared__ __attribute__((aligned(16))) u32 s_buf[kCfSlab * kCfTupleWords];
     static_assert(kCfSlab * kCfTupleWords * 4 >= kCfLds * 32, "the tuple staging doubles as the row cache");
-    const u32 t = threadIdx.x, w = blockIdx.x;
+    const u32 t = threadIdx.x;
+    // one slab per workgroup — or, behind colfreq_stream_kernel (long columns), one workgroup per CU that walks the slabs and
+    // skips those whose share the streaming kernel has counted already (4 096 workgroups of 140 KiB that only look at a flag
+    // took 8.5 us to pass through the CUs)
+    for (u32 w = blockIdx.x; w < slabs; w += gridDim.x) {
+    if (share_done && share_done[w / per_share]) continue;
     CF_STAMP(0, w, 0)
     for (u32 k = t; k < kCfLds; k += kCfThreads1) {
         s_key[k] = 0;
@@ -443,7 +457,7 @@ __global__ __launch_bounds__(kCfThreads1, 4) void colfreq_partition_kernel(const
     if (t == 0) {
         s_fill = 0;
         s_trunc = 0;
-        if (w == 0) {  // pass 2 (the next launch on this stream) adds to the one and may set the other
+        if (w == 0 && !share_done) {  // pass 2 (the next launch on this stream) adds to the one and may set the other
             status->n_distinct = 0;
             status->overflow = 0;
             for (u32 k = 0; k < kCfTickets; ++k) ticket[k * 32] = 0;
@@ -629,6 +643,248 @@ __global__ __launch_bounds__(kCfThreads1, 4) void colfreq_partition_kernel(const
         }
     }
     CF_STAMP(0, w, 5)
+    __syncthreads();  // (the next slab clears the tables)
+    }
+}
+
+// ---- long columns of few values (round 5) ---------------------------------------------------------------------------------
+// At 32 Mi records the kernel above runs sixteen times per CU, each time a chain of phases behind barriers (load, probe, sort,
+// write: 25 us per slab, the memory pipe idle in most of them) and leaves the same hundred tuples per slab for pass 2.  This
+// kernel is what a categorical column needs instead: ONE workgroup per CU walks a SHARE of `per_share` consecutive slabs with
+// one table that it keeps (2 048 slots, the representatives' rows beside them), the next batch of four rows per thread in
+// flight while this one is hashed and looked up, and no barrier until the share ends; the table then leaves as the share's
+// tuples, in the block of the share's first slab and in the same sorted form (the other slabs' runs are empty), so pass 2
+// does not know the difference.  A value that finds no slot ends the attempt: the workgroup marks its share "not done" and
+// colfreq_partition_kernel — launched behind this kernel, its workgroups return at once for finished shares — counts those
+// slabs the general way.  A column of distinct values costs every workgroup one batch before it gives up.
+static constexpr u32 kCfStreamSlots = 2048;
+static constexpr u32 kCfStreamThreads = 1024;
+#ifndef CSVSIMD_CF_STREAM_BATCH
+#define CSVSIMD_CF_STREAM_BATCH 2
+#endif
+static constexpr u32 kCfStreamBatch = CSVSIMD_CF_STREAM_BATCH;  // rows per thread and batch
+static constexpr u32 kCfStreamStep = kCfStreamThreads * kCfStreamBatch;  // records per workgroup and step
+template <u32 STRIDE>
+__global__ __launch_bounds__(kCfStreamThreads) void colfreq_stream_kernel(const ColView c, unsigned short* __restrict__ offs,
+                                                                        u32* __restrict__ tuples, u32 parts, u32 slabs, u32 per_share,
+                                                                        ColFreqStatus* __restrict__ status, u32* __restrict__ ticket,
+                                                                        u32* __restrict__ share_done) {
+    __shared__ u64 s_key[kCfStreamSlots];    // hash bits 32..63 << 32 | (record - r0) + 1; 0 = empty
+    __shared__ u32 s_count[kCfStreamSlots];
+    __shared__ u32 s_first[kCfStreamSlots];  // smallest (record - r0) holding the slot's value
+    __shared__ u32 s_hlo[kCfStreamSlots];    // hash bits 0..31
+    __shared__ u32 s_rlen[kCfStreamSlots];   // the representative's length; bit 31 = its row is in s_rows (set last)
+    __shared__ u32 s_hist[kCfMaxParts];
+    __shared__ u32 s_scan[kCfStreamThreads / 64];
+    __shared__ u32 s_fill, s_trunc, s_fail;
+    // the representatives' rows (bytes 0..15 of slot s in s_rows[s], 16..31 in s_rows[slots + s]); at the end: the tuples
+    __shared__ __attribute__((aligned(16))) u32x4c s_rows[2 * kCfStreamSlots];
+    static_assert(sizeof(u32x4c) * 2 * kCfStreamSlots >= kCfStreamSlots * kCfTupleWords * 4, "the row cache doubles as the tuple staging");
+    const u32 t = threadIdx.x, w = blockIdx.x;
+    for (u32 k = t; k < kCfStreamSlots; k += kCfStreamThreads) {
+        s_key[k] = 0;
+        s_count[k] = 0;
+        s_first[k] = 0xffffffffu;
+        s_rlen[k] = 0;
+    }
+    for (u32 k = t; k < parts; k += kCfStreamThreads) s_hist[k] = 0;
+    if (t == 0) {
+        s_fill = 0;
+        s_trunc = 0;
+        s_fail = 0;
+        if (w == 0) {  // pass 2 adds to the one and may set the other
+            status->n_distinct = 0;
+            status->overflow = 0;
+            for (u32 k = 0; k < kCfTickets; ++k) ticket[k * 32] = 0;
+        }
+    }
+    __syncthreads();
+    const u32 w0 = w * per_share;  // the share's first slab
+    const u64 r0 = (u64)w0 * kCfSlab;
+    const u64 share_records = (u64)per_share * kCfSlab;
+    const u32 nrec = (u32)(c.n_rows - r0 < share_records ? c.n_rows - r0 : share_records);
+    const u32* const lens = c.len ? c.len : reinterpret_cast<const u32*>(c.col);  // (no lengths: read anything, use the stride)
+    // (loads without branches around them — a record past the share's end is fetched from its last record's address and not
+    // looked at — so that the compiler can wait for the older batch alone while the younger one stays in flight)
+    struct Rows {
+        u32x4c a[kCfStreamBatch], b[kCfStreamBatch];
+        u32 len[kCfStreamBatch];
+    };
+    auto request = [&](Rows& n, u32 base) {
+        base = base < nrec ? base : 0u;
+#pragma unroll
+        for (u32 jj = 0; jj < kCfStreamBatch; ++jj) {
+            u32 li = base + jj * kCfStreamThreads + t;
+            li = li < nrec ? li : nrec - 1u;
+            const u64 i = r0 + li;
+            const u32x4c* const p0 = reinterpret_cast<const u32x4c*>(c.col + i * STRIDE);
+            n.a[jj] = __builtin_nontemporal_load(p0);
+            n.b[jj] = STRIDE > 16 ? __builtin_nontemporal_load(p0 + 1) : u32x4c{0, 0, 0, 0};
+            const u32 l = __builtin_nontemporal_load(lens + i);
+            n.len[jj] = c.len ? l : STRIDE;
+        }
+    };
+    u32 trunc = 0;
+    auto count = [&](const Rows& r, const u32 base) {
+        const u32x4c* const ra = r.a;
+        const u32x4c* const rb = r.b;
+        const u32* const rl_ = r.len;
+#pragma unroll
+        for (u32 jj = 0; jj < kCfStreamBatch; ++jj) {
+            const u32 li = base + jj * kCfStreamThreads + t;
+            if (li >= nrec) continue;
+            const u32 len = rl_[jj];
+            if (len > STRIDE) ++trunc;
+            const u64 h = hash_regs(STRIDE, len, ra[jj], rb[jj]);
+            const u32 tag = (u32)(h >> 32);
+            const u32 home = (u32)h & (kCfStreamSlots - 1);
+            // The common case by far, as one straight line: the value sits in its home slot with its row beside it.  Key, flag
+            // and row are requested together (the row is read BEHIND the flag and a wave's LDS operations execute in order: a
+            // flag that is up means the row read after it is complete); a record can only lower the slot's first record if it
+            // lies before the one that claimed the slot, whose number the key holds.
+            const u64 old0 = s_key[home];
+            const u32 rl0 = __hip_atomic_load(&s_rlen[home], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("" ::: "memory");
+            const u32x4c b0 = s_rows[home], b1 = STRIDE > 16 ? s_rows[kCfStreamSlots + home] : u32x4c{0, 0, 0, 0};
+            u32 diff = ((u32)(old0 >> 32) ^ tag) | (rl0 ^ (len | 0x80000000u)) | (ra[jj].x ^ b0.x) | (ra[jj].y ^ b0.y) |
+                       (ra[jj].z ^ b0.z) | (ra[jj].w ^ b0.w);
+            if (STRIDE > 16) diff |= (rb[jj].x ^ b1.x) | (rb[jj].y ^ b1.y) | (rb[jj].z ^ b1.z) | (rb[jj].w ^ b1.w);
+            if (diff == 0) {
+                atomicAdd(&s_count[home], 1u);
+                if (li + 1u < (u32)old0) atomicMin(&s_first[home], li);
+                continue;
+            }
+            // anything else: the slot is empty, another value's, or its row is still on the way
+            const u64 mine = ((u64)tag << 32) | (u64)(li + 1u);
+            bool done = false;
+            const int max_probes = __hip_atomic_load(&s_fill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < kCfStreamSlots * 3 / 4 ? 8 : 1;
+            u32 s = home;
+            for (int p = 0; p < max_probes && !done; ++p, s = (s + 1) & (kCfStreamSlots - 1)) {
+                u64 old = s_key[s];
+                const u32 rl = __hip_atomic_load(&s_rlen[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (old == 0) old = atomicCAS((unsigned long long*)&s_key[s], 0ull, (unsigned long long)mine);
+                if (old == 0) {
+                    s_hlo[s] = (u32)h;
+                    atomicAdd(&s_fill, 1u);
+                    atomicAdd(&s_count[s], 1u);
+                    atomicMin(&s_first[s], li);
+                    s_rows[s] = ra[jj];
+                    if (STRIDE > 16) s_rows[kCfStreamSlots + s] = rb[jj];
+                    __hip_atomic_store(&s_rlen[s], len | 0x80000000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    done = true;
+                } else if ((u32)(old >> 32) == tag) {
+                    bool eq;
+                    if (rl >> 31) {
+                        asm volatile("" ::: "memory");
+                        const u32x4c a0 = ra[jj], a1 = rb[jj];
+                        const u32x4c c0 = s_rows[s], c1 = STRIDE > 16 ? s_rows[kCfStreamSlots + s] : u32x4c{0, 0, 0, 0};
+                        eq = (rl & 0x7fffffffu) == len && a0.x == c0.x && a0.y == c0.y && a0.z == c0.z && a0.w == c0.w &&
+                             (STRIDE <= 16 || (a1.x == c1.x && a1.y == c1.y && a1.z == c1.z && a1.w == c1.w));
+                    } else {
+                        eq = rows_equal(c, r0 + li, r0 + ((u32)old - 1u), len);  // (the slot's copy is not there yet)
+                    }
+                    if (eq) {
+                        atomicAdd(&s_count[s], 1u);
+                        if (li + 1u < (u32)old) atomicMin(&s_first[s], li);
+                        done = true;
+                    }
+                }
+            }
+            if (!done) __hip_atomic_store(&s_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    // TWO batches are in flight while a third is counted: with one, a wave asked for its next rows only after it had counted
+    // the previous ones, and the memory pipe saw a gap per wave and batch (0.262 ms for 1 GiB; the bare stream 0.225)
+    Rows n0, n1;
+    request(n0, 0);
+    request(n1, kCfStreamStep);
+    for (u32 base = 0; base < nrec; base += 2 * kCfStreamStep) {
+        if (__hip_atomic_load(&s_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+        {
+            const Rows r = n0;
+            request(n0, base + 2 * kCfStreamStep);
+            count(r, base);
+        }
+        if (base + kCfStreamStep < nrec) {
+            const Rows r = n1;
+            request(n1, base + 3 * kCfStreamStep);
+            count(r, base + kCfStreamStep);
+        }
+    }
+    if (trunc) atomicAdd(&s_trunc, trunc);
+    __syncthreads();
+    if (s_fail) {
+        if (t == 0) share_done[w] = 0;
+        return;
+    }
+    // ---- the table leaves as the share's tuples, sorted by partition (the counting sort of colfreq_partition_kernel) ----------
+    constexpr u32 kOwn = kCfStreamSlots / kCfStreamThreads;
+    u32 rank[kOwn], part[kOwn];
+#pragma unroll
+    for (u32 j = 0; j < kOwn; ++j) {
+        const u32 slot = j * kCfStreamThreads + t;
+        part[j] = rank[j] = 0xffffffffu;
+        if (s_key[slot] != 0) {
+            part[j] = cf_part(s_key[slot], parts);  // (the key's upper half = hash bits 32..63)
+            rank[j] = atomicAdd(&s_hist[part[j]], 1u);
+        }
+    }
+    __syncthreads();
+    const u32 per = (parts + kCfStreamThreads - 1) / kCfStreamThreads;  // <= 4
+    u32 local = 0;
+    for (u32 k = 0; k < per; ++k) {
+        const u32 bin = t * per + k;
+        if (bin < parts) local += s_hist[bin];
+    }
+    const u32 incl = wave_incl_scan_u32(local);
+    if ((t & 63u) == 63u) s_scan[t >> 6] = incl;
+    __syncthreads();
+    u32 run = incl - local;
+    for (u32 k = 0; k < (t >> 6); ++k) run += s_scan[k];
+    u32 total = 0;
+    for (u32 k = 0; k < kCfStreamThreads / 64; ++k) total += s_scan[k];
+    const u32 share_slabs = slabs - w0 < per_share ? slabs - w0 : per_share;
+    for (u32 k = 0; k < per; ++k) {
+        const u32 bin = t * per + k;
+        if (bin < parts) {
+            const u32 cnt = s_hist[bin];
+            s_hist[bin] = run;  // the bin's start within the block
+            unsigned short* const o = offs + (u64)bin * slabs + w0;
+            o[0] = (unsigned short)run;
+            for (u32 q = 1; q < share_slabs; ++q) o[q] = 0;  // the share's other slabs: empty runs
+            run += cnt;
+        }
+    }
+    // rows `parts` (tuples in the block) and `parts + 1` (records longer than the stride: at most a slab's worth per entry)
+    for (u32 q = t; q < share_slabs; q += kCfStreamThreads) {
+        offs[(u64)parts * slabs + w0 + q] = (unsigned short)(q == 0 ? total : 0u);
+        const u32 before = q * kCfSlab;
+        const u32 left = s_trunc > before ? s_trunc - before : 0u;
+        offs[(u64)(parts + 1) * slabs + w0 + q] = (unsigned short)(left < kCfSlab ? left : kCfSlab);
+    }
+    __syncthreads();  // (the rows in s_rows are no longer read; every thread has its slots' partition starts)
+    u32* const s_buf = reinterpret_cast<u32*>(s_rows);
+#pragma unroll
+    for (u32 j = 0; j < kOwn; ++j) {
+        if (part[j] != 0xffffffffu) {
+            const u32 slot = j * kCfStreamThreads + t;
+            u32* const q = s_buf + (s_hist[part[j]] + rank[j]) * kCfTupleWords;
+            q[0] = (u32)r0 + s_first[slot];
+            q[1] = s_count[slot];
+            q[2] = s_hlo[slot];
+        }
+    }
+    __syncthreads();
+    u32* const block = tuples + (u64)w0 * kCfSlab * kCfTupleWords;
+    const u32 words = total * kCfTupleWords;
+    for (u32 k = 4 * t; k < words; k += 4 * kCfStreamThreads) {
+        if (k + 4 <= words) {
+            *reinterpret_cast<u32x4c*>(block + k) = *reinterpret_cast<const u32x4c*>(s_buf + k);
+        } else {
+            for (u32 q = k; q < words; ++q) block[q] = s_buf[q];
+        }
+    }
+    if (t == 0) share_done[w] = 1;
 }
 
 static constexpr u32 kCfGroup = 2 * kCfThreads2;  // blocks whose runs a pass-2 workgroup lines up at a time (two per thread)
@@ -755,30 +1011,45 @@ __global__ __launch_bounds__(kCfThreads2) void colfreq_reduce_kernel(const ColVi
                 const u32 g = slabs - w0 < kCfGroup ? slabs - w0 : kCfGroup;
                 const u32 tg = one_group ? total : line_up(w0, g);
                 if (p == blockIdx.x && w0 == 0 && r == 0) { CF_STAMP(1, p, 2) }
-                for (u32 k = t; k < tg; k += kCfThreads2) {
-                    u32 lo = 0, hi = g;  // the block whose run holds tuple k: the last one with s_pre <= k
-                    while (hi - lo > 1) {
-                        const u32 mid = (lo + hi) >> 1;
-                        if (s_pre[mid] <= k) lo = mid; else hi = mid;
-                    }
-                    const u32* const q = tuples + ((u64)(w0 + lo) * kCfSlab + s_beg[lo] + (k - s_pre[lo])) * kCfTupleWords;
-                    const u32 rec = q[0], cnt = q[1], h32 = q[2];
-                    if (rounds > 1 && ((h32 >> 13) % rounds) != r) continue;
-                    const u64 key = ((u64)h32 << 32) | ((u64)rec + 1);
-                    u32 s = h32 & (cap - 1);
-                    bool done = false;
-                    for (u32 probes = 0; probes < cap && !done; ++probes, s = (s + 1) & (cap - 1)) {
-                        u64 old = s_key[s];
-                        if (old == 0) old = atomicCAS((unsigned long long*)&s_key[s], 0ull, (unsigned long long)key);
-                        // (lengths and rows are read only when hash bits meet: a partition's records lie all over the
-                        // column, and a 4-byte read per tuple from a random place was a sector of traffic per distinct value)
-                        if (old == 0 || ((old >> 32) == h32 && rows_equal_eager(c, rec, (u32)old - 1u))) {
-                            atomicAdd(&s_count[s], cnt);
-                            atomicMin(&s_first[s], rec);
-                            done = true;
+                // (kCfBatch2 tuples per thread can be looked up and requested before the first one is merged.  Measured at 32 Mi
+                // distinct records, where a partition's 8 192 tuples take 62 us: 4 or 8 in flight 1.52-1.56 ms against 1.44 with
+                // one — the dependent trips of ONE tuple are not what a partition waits for; the product keeps one)
+                for (u32 k0 = t; k0 < tg; k0 += kCfBatch2 * kCfThreads2) {
+                    u32 rec[kCfBatch2], cnt[kCfBatch2], h32[kCfBatch2];
+#pragma unroll
+                    for (u32 j = 0; j < kCfBatch2; ++j) {
+                        const u32 k = k0 + j * kCfThreads2;
+                        rec[j] = cnt[j] = h32[j] = 0;  // (cnt == 0: no tuple)
+                        if (k < tg) {
+                            u32 lo = 0, hi = g;  // the block whose run holds tuple k: the last one with s_pre <= k
+                            while (hi - lo > 1) {
+                                const u32 mid = (lo + hi) >> 1;
+                                if (s_pre[mid] <= k) lo = mid; else hi = mid;
+                            }
+                            const u32* const q = tuples + ((u64)(w0 + lo) * kCfSlab + s_beg[lo] + (k - s_pre[lo])) * kCfTupleWords;
+                            rec[j] = q[0], cnt[j] = q[1], h32[j] = q[2];
                         }
                     }
-                    if (!done) s_overflow = 1;  // more distinct values with these hash bits than a table holds
+#pragma unroll
+                    for (u32 j = 0; j < kCfBatch2; ++j) {
+                        if (cnt[j] == 0) continue;
+                        if (rounds > 1 && ((h32[j] >> 13) % rounds) != r) continue;
+                        const u64 key = ((u64)h32[j] << 32) | ((u64)rec[j] + 1);
+                        u32 s = h32[j] & (cap - 1);
+                        bool done = false;
+                        for (u32 probes = 0; probes < cap && !done; ++probes, s = (s + 1) & (cap - 1)) {
+                            u64 old = s_key[s];
+                            if (old == 0) old = atomicCAS((unsigned long long*)&s_key[s], 0ull, (unsigned long long)key);
+                            // (lengths and rows are read only when hash bits meet: a partition's records lie all over the
+                            // column, and a 4-byte read per tuple from a random place was a sector of traffic per distinct value)
+                            if (old == 0 || ((old >> 32) == h32[j] && rows_equal_eager(c, rec[j], (u32)old - 1u))) {
+                                atomicAdd(&s_count[s], cnt[j]);
+                                atomicMin(&s_first[s], rec[j]);
+                                done = true;
+                            }
+                        }
+                        if (!done) s_overflow = 1;  // more distinct values with these hash bits than a table holds
+                    }
                 }
                 __syncthreads();
                 if (p == blockIdx.x && w0 == 0 && r == 0) { CF_STAMP(1, p, 3) }
@@ -866,13 +1137,39 @@ hipError_t launch_colfreq(const void* d_col, const void* d_len, u64 n_rows, u32 
     const ColView c = {(const uint8_t*)d_col, (const u32*)d_len, n_rows, stride};
     unsigned short* const offs = (unsigned short*)d_scratch;
     u32* const tuples = (u32*)((char*)d_scratch + g.offs_bytes);
-    u32* const ticket = (u32*)((char*)d_scratch + g.bytes - kCfTicketBytes);
+    u32* const ticket = (u32*)((char*)d_scratch + g.bytes - kCfTicketBytes - kCfShareFlagBytes);
+    u32* const share_flags = (u32*)((char*)d_scratch + g.bytes - kCfShareFlagBytes);
+    const u32 cus = (u32)(n_cus > 0 ? n_cus : 256);
+    // two rounds of slabs per CU and more (4 Mi records): first the streaming attempt, one workgroup per CU over a share of slabs
+#ifdef CSVSIMD_CF_NO_STREAM  // (tuning builds)
+    const bool stream_first = false;
+#else
+    const bool stream_first = (stride == 16 || stride == 32) && g.slabs >= 2 * cus && cus <= kCfMaxShares;
+#endif
+    const u32 per_share = stream_first ? (g.slabs + cus - 1) / cus : 1u;
+    if (stream_first) {
+        const u32 shares = (g.slabs + per_share - 1) / per_share;
+        if (stride == 32)
+            hipLaunchKernelGGL(colfreq_stream_kernel<32>, dim3(shares), dim3(kCfStreamThreads), 0, stream, c, offs, tuples, g.parts,
+                               g.slabs, per_share, status, ticket, share_flags);
+        else
+            hipLaunchKernelGGL(colfreq_stream_kernel<16>, dim3(shares), dim3(kCfStreamThreads), 0, stream, c, offs, tuples, g.parts,
+                               g.slabs, per_share, status, ticket, share_flags);
+        hipError_t e0 = hipGetLastError();
+        if (e0 != hipSuccess) return e0;
+    }
+    const u32* const done = stream_first ? share_flags : nullptr;
+#ifdef CSVSIMD_CF_GRID1_SLABS  // (tuning builds)
+    const u32 grid1 = g.slabs;
+#else
+    const u32 grid1 = stream_first ? cus : g.slabs;
+#endif
     if (stride <= 32)
-        hipLaunchKernelGGL(colfreq_partition_kernel<true>, dim3(g.slabs), dim3(kCfThreads1), 0, stream, c, offs, tuples, g.parts,
-                           g.slabs, status, ticket);
+        hipLaunchKernelGGL(colfreq_partition_kernel<true>, dim3(grid1), dim3(kCfThreads1), 0, stream, c, offs, tuples, g.parts,
+                           g.slabs, status, ticket, done, per_share);
     else
-        hipLaunchKernelGGL(colfreq_partition_kernel<false>, dim3(g.slabs), dim3(kCfThreads1), 0, stream, c, offs, tuples, g.parts,
-                           g.slabs, status, ticket);
+        hipLaunchKernelGGL(colfreq_partition_kernel<false>, dim3(grid1), dim3(kCfThreads1), 0, stream, c, offs, tuples, g.parts,
+                           g.slabs, status, ticket, done, per_share);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const u32 cap = (u32)(n_cus > 0 ? n_cus : 256);  // one 140-KiB workgroup per CU
@@ -1041,30 +1338,36 @@ __global__ __launch_bounds__(256, 2) void colsearch_small_kernel(const ColView c
     //              bound by its ~200 VALU instructions per row: the swap, the selects and the bit shuffle cost it more
     //              (0.29 ms) than the better stream gives (0.265 ms without them) — profiles/r05_consumers_1GiB_*.json.
     constexpr bool kSwap = COALESCED && STRIDE == 32;
-    u32x4c va = {0, 0, 0, 0}, vb = {0, 0, 0, 0};
-    u32 vlen = STRIDE;
     const u32 row_of_lane = kSwap ? (lane >> 1) + ((lane & 1u) << 5) : lane;
-    auto fetch = [&](u64 wd) {
+    // (no branch around a load: rows past the end are fetched from the last row's address and never looked at, a missing lengths
+    // array reads the column instead and the value is replaced — with loads under conditions the compiler can only wait for
+    // ALL outstanding loads, `s_waitcnt vmcnt(0)`, and the second batch in flight would be waited for with the first)
+    const u64 last_row = c.n_rows - 1;
+    const u32* const lens = c.len ? c.len : reinterpret_cast<const u32*>(c.col);
+    auto fetch = [&](u64 wd, u32x4c& va, u32x4c& vb, u32& vlen) {
+#ifdef CSVSIMD_CS_BRANCHY
         if (wd >= n_words) return;
+#else
+        if (wd >= n_words) wd = n_words - 1;
+#endif
         const u64 i0 = wd * 64;
         if (kSwap) {
-            const u64 pieces = c.n_rows * 2;  // 16-byte pieces of the column
-            const u32x4c* const p = reinterpret_cast<const u32x4c*>(c.col + i0 * STRIDE);
-            const u64 q0 = i0 * 2;
-            va = q0 + lane < pieces ? __builtin_nontemporal_load(p + lane) : u32x4c{0, 0, 0, 0};
-            vb = q0 + 64 + lane < pieces ? __builtin_nontemporal_load(p + 64 + lane) : u32x4c{0, 0, 0, 0};
-        } else if (i0 + lane < c.n_rows) {
-            const u32x4c* const p = reinterpret_cast<const u32x4c*>(c.col + (i0 + lane) * STRIDE);
+            const u64 last_piece = c.n_rows * 2 - 1;  // 16-byte pieces of the column
+            const u32x4c* const p = reinterpret_cast<const u32x4c*>(c.col);
+            const u64 q0 = i0 * 2 + lane, q1 = q0 + 64;
+            va = __builtin_nontemporal_load(p + (q0 < last_piece ? q0 : last_piece));
+            vb = __builtin_nontemporal_load(p + (q1 < last_piece ? q1 : last_piece));
+        } else {
+            const u64 r = i0 + lane < last_row ? i0 + lane : last_row;
+            const u32x4c* const p = reinterpret_cast<const u32x4c*>(c.col + r * STRIDE);
             va = __builtin_nontemporal_load(p);
             if (STRIDE == 32) vb = __builtin_nontemporal_load(p + 1);
         }
-        vlen = (c.len && i0 + row_of_lane < c.n_rows) ? __builtin_nontemporal_load(c.len + i0 + row_of_lane) : STRIDE;
+        const u64 rl = i0 + row_of_lane < last_row ? i0 + row_of_lane : last_row;
+        const u32 l = __builtin_nontemporal_load(lens + rl);
+        vlen = c.len ? l : STRIDE;
     };
-    fetch(word);
-    for (; word < n_words; word += step) {
-        const u32x4c ra = va, rb = vb;
-        const u32 full = vlen;
-        fetch(word + step);  // (the loads of the next batch are in flight while this one is searched)
+    auto search = [&](const u64 word, const u32x4c ra, const u32x4c rb, const u32 full) {
         const u64 i = word * 64 + row_of_lane;
         u32 d[D + 1];
         if (kSwap) {
@@ -1098,30 +1401,42 @@ __global__ __launch_bounds__(256, 2) void colsearch_small_kernel(const ColView c
                 match = true;
             } else if (n >= m) {
                 const u32 last = n - m;  // last start position
-                // start positions whose first min(m, 3) bytes are the needle's (prefix_candidates: exact), limited to the positions
-                // a match may start at: 0 .. last.  Needles of up to three bytes are decided by that alone.
+                if (m >= 4) {
+                    // Needles of four bytes and more: is there a start position whose first FOUR bytes are the needle's?  One
+                    // v_alignbyte (the row seen from that position) and one compare per position, the compare's lane mask or-ed
+                    // into a scalar pair: ~2 VALU per position instead of the prefix filter's 11 per dword.  The answer is per
+                    // row, not per position: the rare row that has one (one position in 456 976 on random lower-case text; a hit
+                    // in the zero padding only costs the look) is searched position by position from its cache line.
+                    u64 rows = 0;
+#pragma unroll
+                    for (u32 k = 0; k < D; ++k) {
+                        rows |= __ballot(d[k] == nd[0]);
+                        if (k + 1 < D) {
+                            rows |= __ballot(__builtin_amdgcn_alignbyte(d[k + 1], d[k], 1) == nd[0]);
+                            rows |= __ballot(__builtin_amdgcn_alignbyte(d[k + 1], d[k], 2) == nd[0]);
+                            rows |= __ballot(__builtin_amdgcn_alignbyte(d[k + 1], d[k], 3) == nd[0]);
+                        }
+                    }
+                    if ((rows >> lane) & 1ull) {
+                        const uint8_t* const row = c.col + i * STRIDE;
+                        for (u32 pos = 0; pos <= last && !match; ++pos) {
+                            bool ok = true;
+                            for (u32 q = 0; 8 * q < m && ok; ++q) {
+                                const u32 left = m - 8 * q;
+                                const u64 mask = left >= 8 ? ~0ull : ((1ull << (8 * left)) - 1ull);
+                                ok = ((col_load8(row, pos + 8 * q, STRIDE) ^ s_needle[q]) & mask) == 0;
+                            }
+                            match = ok;
+                        }
+                    }
+                } else {
+                // start positions whose first m (<= 3) bytes are the needle's (prefix_candidates: exact), limited to the positions
+                // a match may start at: 0 .. last: needles of up to three bytes are decided by that alone.
                 const u32 cand = (m == 1   ? prefix_candidates<D, 1>(d, b0, b1, b2)
                                   : m == 2 ? prefix_candidates<D, 2>(d, b0, b1, b2)
                                            : prefix_candidates<D, 3>(d, b0, b1, b2)) &
                                  (last >= 31u ? ~0u : ((2u << last) - 1u));
-                if (m <= 3) {
-                    match = cand != 0;
-                } else if (cand) {
-                    // rare (one start position in 17 576 on random lower-case text): the rest of the needle, from the row's
-                    // cache line
-                    const uint8_t* const row = c.col + i * STRIDE;
-                    u32 z = cand;
-                    while (z && !match) {
-                        const u32 pos = (u32)__builtin_ctz(z);
-                        z &= z - 1;
-                        bool ok = true;
-                        for (u32 q = 0; 8 * q < m && ok; ++q) {
-                            const u32 left = m - 8 * q;
-                            const u64 mask = left >= 8 ? ~0ull : ((1ull << (8 * left)) - 1ull);
-                            ok = ((col_load8(row, pos + 8 * q, STRIDE) ^ s_needle[q]) & mask) == 0;
-                        }
-                        match = ok;
-                    }
+                match = cand != 0;
                 }
             }
         }
@@ -1143,6 +1458,31 @@ __global__ __launch_bounds__(256, 2) void colsearch_small_kernel(const ColView c
             bitmap[word] = bits;
             hits += (u32)__builtin_popcountll(bits);
         }
+    };
+    // TWO batches of rows are in flight per wave while a third is searched: with one, a wave's 2 KiB were requested a
+    // search ahead of their use and the column streamed at the rate of (resident waves x 2 KiB) per memory latency.
+#ifndef CSVSIMD_CS_DEPTH
+#define CSVSIMD_CS_DEPTH 2
+#endif
+    constexpr u32 kDepth = CSVSIMD_CS_DEPTH;
+    u32x4c va[kDepth], vb[kDepth];
+    u32 vlen[kDepth];
+#pragma unroll
+    for (u32 j = 0; j < kDepth; ++j) {
+        va[j] = vb[j] = u32x4c{0, 0, 0, 0};
+        vlen[j] = STRIDE;
+        fetch(word + j * step, va[j], vb[j], vlen[j]);
+    }
+    for (; word < n_words; word += kDepth * step) {
+#pragma unroll
+        for (u32 j = 0; j < kDepth; ++j) {
+            if (word + j * step < n_words) {
+                const u32x4c ra = va[j], rb = vb[j];
+                const u32 full = vlen[j];
+                fetch(word + (kDepth + j) * step, va[j], vb[j], vlen[j]);
+                search(word + j * step, ra, rb, full);
+            }
+        }
     }
     if (lane == 0 && hits) atomicAdd((unsigned long long*)count, (unsigned long long)hits);
     if (trunc) atomicAdd((unsigned long long*)truncated, (unsigned long long)trunc);
@@ -1152,17 +1492,25 @@ hipError_t launch_colsearch(const void* d_col, const void* d_len, u64 n_rows, u3
                             u32 needle_len, int mode, void* d_bitmap, void* d_count, void* d_truncated, hipStream_t stream) {
     if (n_rows == 0) return hipSuccess;
     const ColView c = {(const uint8_t*)d_col, (const u32*)d_len, n_rows, stride};
-    // rows of 16 / 32 bytes and a needle that fits the row: the register-resident search.  A persistent-sized grid (8
-    // workgroups per CU) whose waves walk the column with one batch of loads in flight each.
+    // rows of 16 / 32 bytes and a needle that fits the row: the register-resident search.  A persistent-sized grid (4
+    // workgroups per CU) whose waves walk the column with two batches of loads in flight each.
     const bool small = (stride == 16 || stride == 32) && needle_len <= stride;
+#ifndef CSVSIMD_CS_GRID
+#define CSVSIMD_CS_GRID 4
+#endif
+    // workgroups per CU x 256 CUs.  Measured on one box, 1 GiB of 32-byte rows, equals / contains in ms, (batches in flight,
+    // workgroups per CU): (1, 8) 0.236 / 0.297, (1, 6) 0.222 / 0.283, (2, 8) 0.233 / 0.294, (2, 6) 0.224 / 0.285, (2, 4) 0.215 / 0.286,
+    // (2, 3) 0.230 / 0.340, (2, 2) 0.276 / 0.380, (3, 4) 0.229 / 0.309, (4, 4) 0.220 / 0.295 — fewer, longer streams until the
+    // arithmetic of `contains` runs out of waves (profiles/r05_colsearch_variants.txt)
+    constexpr u32 kSmallGrid = 256 * CSVSIMD_CS_GRID;
     if (small && stride == 32 && mode != 2)
-        hipLaunchKernelGGL((colsearch_small_kernel<32, true>), dim3(cgrid_for(n_rows, 256, 2048)), dim3(256), 0, stream, c,
+        hipLaunchKernelGGL((colsearch_small_kernel<32, true>), dim3(cgrid_for(n_rows, 256, kSmallGrid)), dim3(256), 0, stream, c,
                            (const uint8_t*)d_needle, needle_len, mode, (u64*)d_bitmap, (u64*)d_count, (u64*)d_truncated);
     else if (small && stride == 32)
-        hipLaunchKernelGGL((colsearch_small_kernel<32, false>), dim3(cgrid_for(n_rows, 256, 2048)), dim3(256), 0, stream, c,
+        hipLaunchKernelGGL((colsearch_small_kernel<32, false>), dim3(cgrid_for(n_rows, 256, kSmallGrid)), dim3(256), 0, stream, c,
                            (const uint8_t*)d_needle, needle_len, mode, (u64*)d_bitmap, (u64*)d_count, (u64*)d_truncated);
     else if (small)
-        hipLaunchKernelGGL((colsearch_small_kernel<16, false>), dim3(cgrid_for(n_rows, 256, 2048)), dim3(256), 0, stream, c,
+        hipLaunchKernelGGL((colsearch_small_kernel<16, false>), dim3(cgrid_for(n_rows, 256, kSmallGrid)), dim3(256), 0, stream, c,
                            (const uint8_t*)d_needle, needle_len, mode, (u64*)d_bitmap, (u64*)d_count, (u64*)d_truncated);
     else
     hipLaunchKernelGGL(colsearch_kernel, dim3(cgrid_for(n_rows, 256, 8192)), dim3(256), 0, stream, c,

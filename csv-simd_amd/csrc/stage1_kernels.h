@@ -133,7 +133,7 @@ hipError_t launch_to_columns(const void* dbytes, uint64_t bytes_len, const void*
                              uint64_t n_rows, const void* d_fields, uint32_t n_fields, void* d_cols, uint32_t stride,
                              void* d_lens, uint32_t rows_per_block, int n_cus, hipStream_t stream);
 uint32_t to_columns_window_bytes();
-// exact frequency count on a column: two launches, no device-memory table (columnar_kernels.hip)
+// exact frequency count on a column: two launches (three on long columns), no device-memory table (columnar_kernels.hip)
 uint64_t colfreq_scratch_bytes(uint64_t n_rows);
 // csvsimd_column_frequency_device: the column was gathered from chunks of the row-major file; the entries then leave as
 // csvsimd_freq_entry {record id, text span, count} — row -> record through the chunk map, span from the tape itself

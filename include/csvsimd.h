@@ -504,8 +504,10 @@ int csvsimd_chunk_to_columns_device(csvsimd_ctx* ctx, const void* dbytes, uint64
  *   d_entries : entries_cap csvsimd_colfreq_entry, unordered; n_distinct of the status are valid (the first entries_cap
  *               are written if there are more)
  *   d_status  : (_async) one csvsimd_colfreq_status in DEVICE memory, 8-byte aligned, written by the launches
- * csvsimd_columnar_frequency_device_async enqueues the two launches on hip_stream and returns: nothing is waited for,
- * allocated or copied — capturable into a hipGraph; the caller reads d_status when it needs it.
+ * csvsimd_columnar_frequency_device_async enqueues the launches on hip_stream (two; three from 4 Mi records on, where a
+ * streaming kernel — one workgroup per CU, one table kept over its whole share of the column — counts columns of few values
+ * first and leaves the rest to pass 1) and returns: nothing is waited for, allocated or copied — capturable into a hipGraph;
+ * the caller reads d_status when it needs it.
  * csvsimd_columnar_frequency_device = the same + the status copied to the host + one synchronisation; it returns
  * CSVSIMD_ERR_TAPE_CAPACITY if status->n_distinct > entries_cap, if status->truncated records are longer than the stride
  * (their counts would merge values that differ past it: transpose with a larger stride), or if status->overflow (more

@@ -34,7 +34,8 @@ scratch = torch.empty(need, dtype=torch.uint8, device=dev)
 ent = torch.empty((nrec + 8, 2), dtype=torch.int64, device=dev)
 d_status = torch.zeros(4, dtype=torch.int64, device=dev)
 alg = nrec * stride
-for label, k in (("all_distinct", 0), ("100", 100), ("10000", 10000)):
+kinds = [x for x in os.environ.get("PROBE_KINDS", "all_distinct,100,10000").split(",") if x]
+for label, k in (() if os.environ.get("PROBE_ONLY") == "search" else [(x, 0 if x == "all_distinct" else int(x)) for x in kinds]):
     if k:
         pick = torch.randint(0, k, (nrec,), device=dev, generator=g)
         c = col[:k][pick].contiguous()
@@ -51,6 +52,8 @@ for label, k in (("all_distinct", 0), ("100", 100), ("10000", 10000)):
                                "frac_of_8TBps": round(a / t / 8e12, 3)}
     if k:
         del c, pick
+if os.environ.get("PROBE_ONLY") == "freq":
+    print(json.dumps(out)); sys.exit(0)
 bm = torch.zeros((nrec + 63) // 64 + 1, dtype=torch.int64, device=dev)
 row = bytes(col[1000].cpu().numpy())
 for label, needle, mode in (("contains_6", row[4:10], pkg.SEARCH_CONTAINS), ("contains_1", row[4:5], pkg.SEARCH_CONTAINS),
@@ -58,7 +61,7 @@ for label, needle, mode in (("contains_6", row[4:10], pkg.SEARCH_CONTAINS), ("co
                             ("starts_with_5", row[:5], pkg.SEARCH_STARTS_WITH)):
     hits = pkg.columnar_search_device(ctx, col.data_ptr(), 0, nrec, stride, needle, mode, bm.data_ptr())
     ts = []
-    for _ in range(5):
+    for _ in range(int(os.environ.get("PROBE_REPS", "5"))):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         pkg.columnar_search_device(ctx, col.data_ptr(), 0, nrec, stride, needle, mode, bm.data_ptr())
         ts.append(time.perf_counter() - t0)
@@ -73,4 +76,7 @@ for s in range(stride - 6 + 1):
     m |= (sl[:, s: s + 6] == needle).all(dim=1)
 hits = pkg.columnar_search_device(ctx, col.data_ptr(), 0, 1 << 20, stride, row[4:10], pkg.SEARCH_CONTAINS, bm.data_ptr())
 out["contains_check"] = bool(int(m.sum()) == hits)
-print(json.dumps(out, indent=1))
+if os.environ.get("PROBE_ONLY") == "search":
+    print(os.environ.get("CSVSIMD_LIB", "product"), {k[10:]: v["ms_wall"] for k, v in out.items() if k.startswith("colsearch_")}, out["contains_check"])
+else:
+    print(json.dumps(out, indent=1))

@@ -141,7 +141,7 @@ def test_columnar_frequency_is_counter(ctx, pkg, oracle, torch_cuda):
     assert st.truncated == int((slens[0] > 16).sum())  and st.truncated > 0
 
 
-def test_columnar_frequency_async_is_two_launches_and_graph_capturable(ctx, pkg, torch_cuda):
+def test_columnar_frequency_async_is_launches_only_and_graph_capturable(ctx, pkg, torch_cuda):
     """The asynchronous form: nothing waited for, allocated or copied — so it can be captured and replayed on new data; the
     status record is read from device memory by the caller.  Sizes around the slab (8 192 records) and partition geometry
     (above 1 Mi records there are more partitions than workgroups: later partitions are drawn from tickets, and neighbouring
@@ -196,6 +196,57 @@ def test_columnar_frequency_async_is_two_launches_and_graph_capturable(ctx, pkg,
     pkg.columnar_frequency_device_async(ctx, 0, 0, 0, stride, 0, scratch.data_ptr(), need, 0, 0, d_status.data_ptr())
     torch.cuda.synchronize()
     assert d_status.cpu().tolist() == [0, 0, 0, 0]
+
+
+@pytest.mark.parametrize("stride", [16, 32])
+def test_columnar_frequency_long_columns_of_few_values(ctx, pkg, torch_cuda, stride):
+    """From 4 Mi records on (two slabs per CU and more) a streaming kernel counts first — one workgroup per CU keeps one table
+    over its whole share of slabs — and the general kernel only counts the shares it gave up on (round 5).  Columns that take
+    each way and BOTH in one call: few values everywhere; few values in the first 60 % and distinct ones after (shares of
+    either kind and one that changes its mind half way); as many values as a table just holds; with a lengths array, values
+    that differ only in their length, and more over-long records in one share than a slab's counter holds."""
+    torch = torch_cuda
+    rng = np.random.default_rng(4100 + stride)
+    n = 4_200_000 + 4321
+    need = pkg.columnar_frequency_scratch_bytes(n)
+    scratch = torch.full((need,), 0x5A, dtype=torch.uint8, device="cuda:0")
+    col = torch.zeros((n, stride), dtype=torch.uint8, device="cuda:0")
+    ent = torch.zeros((n + 4, 2), dtype=torch.int64, device="cuda:0")
+    split = int(n * 0.6)
+    for kind in ("few", "half", "edge", "lengths"):
+        lens = None
+        if kind == "few":
+            keys = rng.integers(0, 100, size=n).astype(np.uint64) * np.uint64(0x2545F4914F6CDD1D)
+        elif kind == "half":
+            keys = rng.integers(0, 50, size=n).astype(np.uint64)
+            keys[split:] = (np.arange(n - split, dtype=np.uint64) + np.uint64(1000)) * np.uint64(0x9E3779B97F4A7C15)
+        elif kind == "edge":
+            keys = rng.integers(0, 1500, size=n).astype(np.uint64) * np.uint64(0xD6E8FEB86659FD93)
+        else:
+            keys = rng.integers(0, 20, size=n).astype(np.uint64)
+            lens = rng.integers(8, stride + 1, size=n).astype(np.int32)
+            lens[100_000:130_000] = stride + 5          # 30 000 over-long records in ONE share (a slab's counter holds 8 192)
+            lens[n - 3] = stride + 1
+        host = np.zeros((n, stride), dtype=np.uint8)
+        host[:, :8] = keys.view(np.uint8).reshape(n, 8)
+        host[:, stride - 1] = 9
+        if lens is not None:
+            host[lens < stride, stride - 1] = 0      # (a column is zero padded past a value's length)
+        col.copy_(torch.from_numpy(host))
+        dl = torch.from_numpy(lens).to("cuda:0") if lens is not None else None
+        ent.fill_(-1)
+        st = pkg.columnar_frequency_device(ctx, col.data_ptr(), dl.data_ptr() if dl is not None else 0, n, stride, 11,
+                                           scratch.data_ptr(), need, ent.data_ptr(), ent.shape[0],
+                                           allow_capacity=lens is not None)   # (over-long records: counted, and reported by the code)
+        ident = keys if lens is None else keys * np.uint64(64) + lens.astype(np.uint64)   # (value, length): the identity of a record
+        uniq, first, counts = np.unique(ident, return_index=True, return_counts=True)
+        trunc = 0 if lens is None else int((lens > stride).sum())
+        assert (st.n_records, st.n_distinct, st.truncated, st.overflow) == (n, uniq.size, trunc, 0), (kind, stride)
+        got = ent[: uniq.size].cpu().numpy()
+        order = np.argsort(got[:, 0])
+        want_order = np.argsort(first)
+        assert np.array_equal(got[order, 0] - 11, first[want_order]) and np.array_equal(got[order, 1], counts[want_order]), (kind, stride)
+        assert bool((ent[uniq.size:] == -1).all())
 
 
 def test_columnar_frequency_same_hash_tag_never_merges(ctx, pkg, torch_cuda):
@@ -314,7 +365,8 @@ def test_columnar_search_on_16_and_32_byte_rows(ctx, pkg, torch_cuda, stride):
             assert got_n == int(want.sum()) and np.array_equal(bits, want), (stride, needle, mode)
     # no lengths array: every row is its whole zero-padded stride (fixed-width keys)
     padded = [host[i].tobytes() for i in range(n)]
-    for needle in (b"abc", padded[5][:7], padded[9], padded[3][stride - 3:], b"\0", b"c\0"):
+    for needle in (b"abc", padded[5][:7], padded[9], padded[3][stride - 3:], b"\0", b"c\0", b"\0\0\0\0", b"a\0\0\0\0",
+                   padded[7][stride - 6:], padded[11][stride - 4:], padded[13][2:stride]):
         for mode, fn in ((pkg.SEARCH_EQUALS, lambda r: r == needle), (pkg.SEARCH_STARTS_WITH, lambda r: r.startswith(needle)),
                          (pkg.SEARCH_CONTAINS, lambda r: needle in r)):
             want = np.array([fn(r) for r in padded], dtype=bool)
