@@ -204,7 +204,8 @@ def test_columnar_frequency_long_columns_of_few_values(ctx, pkg, torch_cuda, str
     over its whole share of slabs — and the general kernel only counts the shares it gave up on (round 5).  Columns that take
     each way and BOTH in one call: few values everywhere; few values in the first 60 % and distinct ones after (shares of
     either kind and one that changes its mind half way); as many values as a table just holds; with a lengths array, values
-    that differ only in their length, and more over-long records in one share than a slab's counter holds."""
+    that differ only in their length, and more over-long records in one share than a slab's counter holds; some thousand
+    values (the second streaming kernel: a larger table of keys, rows compared in the column), with and without lengths."""
     torch = torch_cuda
     rng = np.random.default_rng(4100 + stride)
     n = 4_200_000 + 4321
@@ -213,9 +214,16 @@ def test_columnar_frequency_long_columns_of_few_values(ctx, pkg, torch_cuda, str
     col = torch.zeros((n, stride), dtype=torch.uint8, device="cuda:0")
     ent = torch.zeros((n + 4, 2), dtype=torch.int64, device="cuda:0")
     split = int(n * 0.6)
-    for kind in ("few", "half", "edge", "lengths"):
+    for kind in ("few", "half", "edge", "lengths", "mid", "tenk", "near", "mid_lengths"):
         lens = None
-        if kind == "few":
+        if kind in ("mid", "tenk", "near"):
+            # some thousand values: the second streaming kernel's table of keys (12 288 values per share at most: "near" has
+            # shares on either side of that)
+            keys = rng.integers(0, {"mid": 5000, "tenk": 10_000, "near": 12_200}[kind], size=n).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        elif kind == "mid_lengths":
+            keys = rng.integers(0, 300, size=n).astype(np.uint64) * np.uint64(0xD6E8FEB86659FD93)
+            lens = rng.integers(8, stride + 1, size=n).astype(np.int32)      # x up to 25 lengths each: ~7 000 (value, length) pairs
+        elif kind == "few":
             keys = rng.integers(0, 100, size=n).astype(np.uint64) * np.uint64(0x2545F4914F6CDD1D)
         elif kind == "half":
             keys = rng.integers(0, 50, size=n).astype(np.uint64)
@@ -238,7 +246,11 @@ def test_columnar_frequency_long_columns_of_few_values(ctx, pkg, torch_cuda, str
         st = pkg.columnar_frequency_device(ctx, col.data_ptr(), dl.data_ptr() if dl is not None else 0, n, stride, 11,
                                            scratch.data_ptr(), need, ent.data_ptr(), ent.shape[0],
                                            allow_capacity=lens is not None)   # (over-long records: counted, and reported by the code)
-        ident = keys if lens is None else keys * np.uint64(64) + lens.astype(np.uint64)   # (value, length): the identity of a record
+        if lens is None:
+            ident = keys
+        else:                                         # (value, length): the identity of a record
+            _, kid = np.unique(keys, return_inverse=True)
+            ident = kid.astype(np.uint64) * np.uint64(64) + lens.astype(np.uint64)
         uniq, first, counts = np.unique(ident, return_index=True, return_counts=True)
         trunc = 0 if lens is None else int((lens > stride).sum())
         assert (st.n_records, st.n_distinct, st.truncated, st.overflow) == (n, uniq.size, trunc, 0), (kind, stride)
