@@ -651,29 +651,41 @@ __global__ __launch_bounds__(kCfThreads1, 4) void colfreq_partition_kernel(const
 // At 32 Mi records the kernel above runs sixteen times per CU, each time a chain of phases behind barriers (load, probe, sort,
 // write: 25 us per slab, the memory pipe idle in most of them) and leaves the same hundred tuples per slab for pass 2.  This
 // kernel is what a categorical column needs instead: ONE workgroup per CU walks a SHARE of `per_share` consecutive slabs with
-// one table that it keeps (2 048 slots, the representatives' rows beside them), the next batch of four rows per thread in
-// flight while this one is hashed and looked up, and no barrier until the share ends; the table then leaves as the share's
-// tuples, in the block of the share's first slab and in the same sorted form (the other slabs' runs are empty), so pass 2
-// does not know the difference.  A value that finds no slot ends the attempt: the workgroup marks its share "not done" and
-// colfreq_partition_kernel — launched behind this kernel, its workgroups return at once for finished shares — counts those
-// slabs the general way.  A column of distinct values costs every workgroup one batch before it gives up.
-static constexpr u32 kCfStreamSlots = 2048;
+// one table that it keeps, two batches of rows per thread in flight while a third is counted, and no barrier until the share
+// ends; the table then leaves as the share's tuples, in the block of the share's first slab and in the same sorted form (the
+// other slabs' runs are empty), so pass 2 does not know the difference.  A value that finds no slot ends the attempt: the
+// workgroup leaves its share "not done" and colfreq_partition_kernel — launched behind this kernel, its workgroups skip
+// finished shares — counts those slabs the general way.  A column of distinct values costs every workgroup one batch before
+// it gives up.
+// The table: 3 072 slots in groups of four.  A slot is a 32-bit key (12 hash bits | the number of a representative record
+// within the share, 20 bits; all ones = empty), a count, the representative's length (bit 31: its row has arrived) and a copy
+// of its row.  A value's probe sequence starts at its group: ONE 16-byte LDS read fetches the group's keys, the first with
+// the record's tag names the slot, row and length are compared from LDS.  Anything else — a new value, one that sits past
+// its group (2 % of the values when the table holds 1 000), a second key with the same tag, a row still on its way — goes
+// slot by slot from the group's start; the table takes 1 536 values (half its slots).  The smallest record of a value ends up as its representative (a 32-bit minimum on
+// the key: same tag, smaller record), the tuple's hash bits are recomputed from the row copy when the table leaves.
+// Measured at 32 Mi records x 32 bytes: 100 values 0.50 -> 0.28 ms (the bare stream of this kernel: 0.225; a version that
+// compared against the representative's row in the COLUMN instead of LDS, with 16 384 slots: 2 000 values 0.65 ms, 5 000
+// 1.0, 10 000 2.7 — a gather per record from the L2, whose working set is a share's representatives x 32 CUs).
+static constexpr u32 kCfStreamGroups = 768;
+static constexpr u32 kCfStreamSlots = kCfStreamGroups * 4;
 static constexpr u32 kCfStreamThreads = 1024;
 #ifndef CSVSIMD_CF_STREAM_BATCH
 #define CSVSIMD_CF_STREAM_BATCH 2
 #endif
 static constexpr u32 kCfStreamBatch = CSVSIMD_CF_STREAM_BATCH;  // rows per thread and batch
 static constexpr u32 kCfStreamStep = kCfStreamThreads * kCfStreamBatch;  // records per workgroup and step
+static constexpr u32 kCfStreamEmpty = 0xffffffffu;
+static constexpr u32 kCfStreamRecBits = 20;
+static constexpr u32 kCfStreamMaxShare = (1u << kCfStreamRecBits) - 1u;  // records per share (the empty key is tag and record all ones)
 template <u32 STRIDE>
 __global__ __launch_bounds__(kCfStreamThreads) void colfreq_stream_kernel(const ColView c, unsigned short* __restrict__ offs,
                                                                         u32* __restrict__ tuples, u32 parts, u32 slabs, u32 per_share,
                                                                         ColFreqStatus* __restrict__ status, u32* __restrict__ ticket,
                                                                         u32* __restrict__ share_done) {
-    __shared__ u64 s_key[kCfStreamSlots];    // hash bits 32..63 << 32 | (record - r0) + 1; 0 = empty
+    __shared__ __attribute__((aligned(16))) u32 s_key[kCfStreamSlots];
     __shared__ u32 s_count[kCfStreamSlots];
-    __shared__ u32 s_first[kCfStreamSlots];  // smallest (record - r0) holding the slot's value
-    __shared__ u32 s_hlo[kCfStreamSlots];    // hash bits 0..31
-    __shared__ u32 s_rlen[kCfStreamSlots];   // the representative's length; bit 31 = its row is in s_rows (set last)
+    __shared__ u32 s_rlen[kCfStreamSlots];
     __shared__ u32 s_hist[kCfMaxParts];
     __shared__ u32 s_scan[kCfStreamThreads / 64];
     __shared__ u32 s_fill, s_trunc, s_fail;
@@ -682,9 +694,8 @@ __global__ __launch_bounds__(kCfStreamThreads) void colfreq_stream_kernel(const 
     static_assert(sizeof(u32x4c) * 2 * kCfStreamSlots >= kCfStreamSlots * kCfTupleWords * 4, "the row cache doubles as the tuple staging");
     const u32 t = threadIdx.x, w = blockIdx.x;
     for (u32 k = t; k < kCfStreamSlots; k += kCfStreamThreads) {
-        s_key[k] = 0;
+        s_key[k] = kCfStreamEmpty;
         s_count[k] = 0;
-        s_first[k] = 0xffffffffu;
         s_rlen[k] = 0;
     }
     for (u32 k = t; k < parts; k += kCfStreamThreads) s_hist[k] = 0;
@@ -705,7 +716,7 @@ __global__ __launch_bounds__(kCfStreamThreads) void colfreq_stream_kernel(const 
     const u32 nrec = (u32)(c.n_rows - r0 < share_records ? c.n_rows - r0 : share_records);
     const u32* const lens = c.len ? c.len : reinterpret_cast<const u32*>(c.col);  // (no lengths: read anything, use the stride)
     // (loads without branches around them — a record past the share's end is fetched from its last record's address and not
-    // looked at — so that the compiler can wait for the older batch alone while the younger one stays in flight)
+    // looked at — so that the compiler can wait for the oldest batch alone while the younger ones stay in flight)
     struct Rows {
         u32x4c a[kCfStreamBatch], b[kCfStreamBatch];
         u32 len[kCfStreamBatch];
@@ -726,66 +737,77 @@ __global__ __launch_bounds__(kCfStreamThreads) void colfreq_stream_kernel(const 
     };
     u32 trunc = 0;
     auto count = [&](const Rows& r, const u32 base) {
-        const u32x4c* const ra = r.a;
-        const u32x4c* const rb = r.b;
-        const u32* const rl_ = r.len;
+        u32 home[kCfStreamBatch], mine[kCfStreamBatch];
+        u32x4c kq[kCfStreamBatch];
+#pragma unroll
+        for (u32 jj = 0; jj < kCfStreamBatch; ++jj) {  // the batch's groups of keys are requested together
+            const u32 li = base + jj * kCfStreamThreads + t;
+            const u64 h = hash_regs(STRIDE, r.len[jj], r.a[jj], r.b[jj]);
+            home[jj] = (u32)(((u64)(u32)h * kCfStreamGroups) >> 32) * 4;
+            mine[jj] = ((u32)(h >> 52) << kCfStreamRecBits) | li;
+            kq[jj] = *reinterpret_cast<const u32x4c*>(&s_key[home[jj]]);
+        }
 #pragma unroll
         for (u32 jj = 0; jj < kCfStreamBatch; ++jj) {
             const u32 li = base + jj * kCfStreamThreads + t;
             if (li >= nrec) continue;
-            const u32 len = rl_[jj];
+            const u32 len = r.len[jj];
             if (len > STRIDE) ++trunc;
-            const u64 h = hash_regs(STRIDE, len, ra[jj], rb[jj]);
-            const u32 tag = (u32)(h >> 32);
-            const u32 home = (u32)h & (kCfStreamSlots - 1);
-            // The common case by far, as one straight line: the value sits in its home slot with its row beside it.  Key, flag
-            // and row are requested together (the row is read BEHIND the flag and a wave's LDS operations execute in order: a
-            // flag that is up means the row read after it is complete); a record can only lower the slot's first record if it
-            // lies before the one that claimed the slot, whose number the key holds.
-            const u64 old0 = s_key[home];
-            const u32 rl0 = __hip_atomic_load(&s_rlen[home], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            asm volatile("" ::: "memory");
-            const u32x4c b0 = s_rows[home], b1 = STRIDE > 16 ? s_rows[kCfStreamSlots + home] : u32x4c{0, 0, 0, 0};
-            u32 diff = ((u32)(old0 >> 32) ^ tag) | (rl0 ^ (len | 0x80000000u)) | (ra[jj].x ^ b0.x) | (ra[jj].y ^ b0.y) |
-                       (ra[jj].z ^ b0.z) | (ra[jj].w ^ b0.w);
-            if (STRIDE > 16) diff |= (rb[jj].x ^ b1.x) | (rb[jj].y ^ b1.y) | (rb[jj].z ^ b1.z) | (rb[jj].w ^ b1.w);
-            if (diff == 0) {
-                atomicAdd(&s_count[home], 1u);
-                if (li + 1u < (u32)old0) atomicMin(&s_first[home], li);
-                continue;
+            // the first of the group's keys with this record's tag (an empty key's tag bits are all ones, and so may a record's
+            // be: the empty key itself is excluded)
+            const u32 tag = mine[jj] >> kCfStreamRecBits;
+            const bool m0 = (kq[jj].x >> kCfStreamRecBits) == tag && kq[jj].x != kCfStreamEmpty;
+            const bool m1 = (kq[jj].y >> kCfStreamRecBits) == tag && kq[jj].y != kCfStreamEmpty;
+            const bool m2 = (kq[jj].z >> kCfStreamRecBits) == tag && kq[jj].z != kCfStreamEmpty;
+            const bool m3 = (kq[jj].w >> kCfStreamRecBits) == tag && kq[jj].w != kCfStreamEmpty;
+            if (m0 || m1 || m2 || m3) {
+                const u32 at = home[jj] + (m0 ? 0u : m1 ? 1u : m2 ? 2u : 3u);
+                const u32 k0 = m0 ? kq[jj].x : m1 ? kq[jj].y : m2 ? kq[jj].z : kq[jj].w;
+                // (the row is read BEHIND the flag and a wave's LDS operations execute in order: a flag that is up means the row
+                // read after it is complete)
+                const u32 rl0 = __hip_atomic_load(&s_rlen[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                asm volatile("" ::: "memory");
+                const u32x4c b0 = s_rows[at], b1 = STRIDE > 16 ? s_rows[kCfStreamSlots + at] : u32x4c{0, 0, 0, 0};
+                u32 diff = (rl0 ^ (len | 0x80000000u)) | (r.a[jj].x ^ b0.x) | (r.a[jj].y ^ b0.y) | (r.a[jj].z ^ b0.z) | (r.a[jj].w ^ b0.w);
+                if (STRIDE > 16) diff |= (r.b[jj].x ^ b1.x) | (r.b[jj].y ^ b1.y) | (r.b[jj].z ^ b1.z) | (r.b[jj].w ^ b1.w);
+                if (diff == 0) {
+                    atomicAdd(&s_count[at], 1u);
+                    if (mine[jj] < k0) atomicMin(&s_key[at], mine[jj]);  // (same tag: the smaller record becomes the representative)
+                    continue;
+                }
             }
-            // anything else: the slot is empty, another value's, or its row is still on the way
-            const u64 mine = ((u64)tag << 32) | (u64)(li + 1u);
+            // slot by slot from the group's start
+            // (an empty slot ends the search: the value is new.  New values are taken while the table is less than half full —
+            // probe sequences stay short, and a column of many values gives up within its first few thousand records instead
+            // of at the end of the share, with the whole pass wasted)
             bool done = false;
-            const int max_probes = __hip_atomic_load(&s_fill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < kCfStreamSlots * 3 / 4 ? 8 : 1;
-            u32 s = home;
-            for (int p = 0; p < max_probes && !done; ++p, s = (s + 1) & (kCfStreamSlots - 1)) {
-                u64 old = s_key[s];
+            const bool room = __hip_atomic_load(&s_fill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < kCfStreamSlots / 2;
+            u32 s = home[jj];
+            for (u32 p = 0; p < kCfStreamSlots && !done; ++p, s = s + 1 < kCfStreamSlots ? s + 1 : 0) {
+                u32 old = s_key[s];
                 const u32 rl = __hip_atomic_load(&s_rlen[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (old == 0) old = atomicCAS((unsigned long long*)&s_key[s], 0ull, (unsigned long long)mine);
-                if (old == 0) {
-                    s_hlo[s] = (u32)h;
+                if (old == kCfStreamEmpty && !room) break;
+                if (old == kCfStreamEmpty) old = atomicCAS(&s_key[s], kCfStreamEmpty, mine[jj]);
+                if (old == kCfStreamEmpty) {
                     atomicAdd(&s_fill, 1u);
                     atomicAdd(&s_count[s], 1u);
-                    atomicMin(&s_first[s], li);
-                    s_rows[s] = ra[jj];
-                    if (STRIDE > 16) s_rows[kCfStreamSlots + s] = rb[jj];
+                    s_rows[s] = r.a[jj];
+                    if (STRIDE > 16) s_rows[kCfStreamSlots + s] = r.b[jj];
                     __hip_atomic_store(&s_rlen[s], len | 0x80000000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     done = true;
-                } else if ((u32)(old >> 32) == tag) {
+                } else if ((old >> kCfStreamRecBits) == tag) {
                     bool eq;
                     if (rl >> 31) {
                         asm volatile("" ::: "memory");
-                        const u32x4c a0 = ra[jj], a1 = rb[jj];
                         const u32x4c c0 = s_rows[s], c1 = STRIDE > 16 ? s_rows[kCfStreamSlots + s] : u32x4c{0, 0, 0, 0};
-                        eq = (rl & 0x7fffffffu) == len && a0.x == c0.x && a0.y == c0.y && a0.z == c0.z && a0.w == c0.w &&
-                             (STRIDE <= 16 || (a1.x == c1.x && a1.y == c1.y && a1.z == c1.z && a1.w == c1.w));
+                        eq = (rl & 0x7fffffffu) == len && r.a[jj].x == c0.x && r.a[jj].y == c0.y && r.a[jj].z == c0.z && r.a[jj].w == c0.w &&
+                             (STRIDE <= 16 || (r.b[jj].x == c1.x && r.b[jj].y == c1.y && r.b[jj].z == c1.z && r.b[jj].w == c1.w));
                     } else {
-                        eq = rows_equal(c, r0 + li, r0 + ((u32)old - 1u), len);  // (the slot's copy is not there yet)
+                        eq = rows_equal(c, r0 + li, r0 + (old & kCfStreamMaxShare), len);  // (the slot's copy is not there yet)
                     }
                     if (eq) {
                         atomicAdd(&s_count[s], 1u);
-                        if (li + 1u < (u32)old) atomicMin(&s_first[s], li);
+                        if (mine[jj] < old) atomicMin(&s_key[s], mine[jj]);
                         done = true;
                     }
                 }
@@ -793,8 +815,7 @@ __global__ __launch_bounds__(kCfStreamThreads) void colfreq_stream_kernel(const 
             if (!done) __hip_atomic_store(&s_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     };
-    // TWO batches are in flight while a third is counted: with one, a wave asked for its next rows only after it had counted
-    // the previous ones, and the memory pipe saw a gap per wave and batch (0.262 ms for 1 GiB; the bare stream 0.225)
+    // TWO batches are in flight while a third is counted
     Rows n0, n1;
     request(n0, 0);
     request(n1, kCfStreamStep);
@@ -817,16 +838,20 @@ __global__ __launch_bounds__(kCfStreamThreads) void colfreq_stream_kernel(const 
         if (t == 0) share_done[w] = 0;
         return;
     }
-    // ---- the table leaves as the share's tuples, sorted by partition (the counting sort of colfreq_partition_kernel) ----------
+    // ---- the table leaves as the share's tuples, sorted by partition (the counting sort of colfreq_partition_kernel); a slot's
+    // hash is that of its row copy -------------------------------------------------------------------------------------------
     constexpr u32 kOwn = kCfStreamSlots / kCfStreamThreads;
-    u32 rank[kOwn], part[kOwn];
+    u32 hlo[kOwn], place[kOwn];  // place: partition << 16 | rank within it; all ones = no tuple
 #pragma unroll
     for (u32 j = 0; j < kOwn; ++j) {
         const u32 slot = j * kCfStreamThreads + t;
-        part[j] = rank[j] = 0xffffffffu;
-        if (s_key[slot] != 0) {
-            part[j] = cf_part(s_key[slot], parts);  // (the key's upper half = hash bits 32..63)
-            rank[j] = atomicAdd(&s_hist[part[j]], 1u);
+        place[j] = 0xffffffffu;
+        hlo[j] = 0;
+        if (s_key[slot] != kCfStreamEmpty) {
+            const u64 h = hash_regs(STRIDE, s_rlen[slot] & 0x7fffffffu, s_rows[slot], STRIDE > 16 ? s_rows[kCfStreamSlots + slot] : u32x4c{0, 0, 0, 0});
+            const u32 part = cf_part(h, parts);
+            hlo[j] = (u32)h;
+            place[j] = (part << 16) | atomicAdd(&s_hist[part], 1u);
         }
     }
     __syncthreads();
@@ -866,12 +891,12 @@ __global__ __launch_bounds__(kCfStreamThreads) void colfreq_stream_kernel(const 
     u32* const s_buf = reinterpret_cast<u32*>(s_rows);
 #pragma unroll
     for (u32 j = 0; j < kOwn; ++j) {
-        if (part[j] != 0xffffffffu) {
+        if (place[j] != 0xffffffffu) {
             const u32 slot = j * kCfStreamThreads + t;
-            u32* const q = s_buf + (s_hist[part[j]] + rank[j]) * kCfTupleWords;
-            q[0] = (u32)r0 + s_first[slot];
+            u32* const q = s_buf + (s_hist[place[j] >> 16] + (place[j] & 0xffffu)) * kCfTupleWords;
+            q[0] = (u32)r0 + (s_key[slot] & kCfStreamMaxShare);
             q[1] = s_count[slot];
-            q[2] = s_hlo[slot];
+            q[2] = hlo[j];
         }
     }
     __syncthreads();
@@ -882,242 +907,6 @@ __global__ __launch_bounds__(kCfStreamThreads) void colfreq_stream_kernel(const 
             *reinterpret_cast<u32x4c*>(block + k) = *reinterpret_cast<const u32x4c*>(s_buf + k);
         } else {
             for (u32 q = k; q < words; ++q) block[q] = s_buf[q];
-        }
-    }
-    if (t == 0) share_done[w] = 1;
-}
-
-// ---- ... and of some thousand values ------------------------------------------------------------------------------------
-// A share whose values do not fit the 2 048 slots above (a column of 10 000 values: every slab of 8 192 records leaves ~5 500
-// tuples, pass 2 merges 22 M of them and compares a row from a random place of the column for each: 1.9 ms at 32 Mi records)
-// gets a second streaming attempt with a table of 16 384 slots of EIGHT bytes — a key of 12 hash bits and the number of a
-// representative record within the share (20 bits), and the count; linear probing that starts at a group of four slots, whose
-// keys one 16-byte LDS read fetches together (a value that sits further along takes the slot-by-slot path: 4 % of the values
-// when the table holds 10 000); no rows in LDS: a record whose tag meets the slot's
-// compares itself with the representative's row in the column, which a share's few thousand representatives keep in the L2.
-// The smallest record of a value becomes its representative (a 32-bit minimum on the key), the tuple's hash bits are
-// recomputed from the representative when the table leaves.  Shares the first kernel counted are skipped; what this one
-// gives up on as well (more than 12 288 values in a share) is pass 1's.
-static constexpr u32 kCfKeysSlots = 16384;
-static constexpr u32 kCfKeysEmpty = 0xffffffffu;
-static constexpr u32 kCfKeysRecBits = 20;
-static constexpr u32 kCfKeysMaxShare = (1u << kCfKeysRecBits) - 1u;  // records per share (the empty key is tag and record all ones)
-template <u32 STRIDE>
-__global__ __launch_bounds__(kCfStreamThreads) void colfreq_stream_keys_kernel(const ColView c, unsigned short* __restrict__ offs,
-                                                                             u32* __restrict__ tuples, u32 parts, u32 slabs,
-                                                                             u32 per_share, u32* __restrict__ share_done) {
-    __shared__ u32 s_key[kCfKeysSlots];    // hash bits 52..63 << 20 | (representative - r0); all ones = empty
-    __shared__ u32 s_count[kCfKeysSlots];
-    __shared__ u32 s_hist[kCfMaxParts];
-    __shared__ u32 s_scan[kCfStreamThreads / 64];
-    __shared__ u32 s_fill, s_trunc, s_fail;
-    const u32 t = threadIdx.x, w = blockIdx.x;
-    if (share_done[w]) return;  // (counted by colfreq_stream_kernel)
-    for (u32 k = t; k < kCfKeysSlots; k += kCfStreamThreads) {
-        s_key[k] = kCfKeysEmpty;
-        s_count[k] = 0;
-    }
-    for (u32 k = t; k < parts; k += kCfStreamThreads) s_hist[k] = 0;
-    if (t == 0) {
-        s_fill = 0;
-        s_trunc = 0;
-        s_fail = 0;
-    }
-    __syncthreads();
-    const u32 w0 = w * per_share;
-    const u64 r0 = (u64)w0 * kCfSlab;
-    const u64 share_records = (u64)per_share * kCfSlab;
-    const u32 nrec = (u32)(c.n_rows - r0 < share_records ? c.n_rows - r0 : share_records);
-    const u32* const lens = c.len ? c.len : reinterpret_cast<const u32*>(c.col);
-    struct Rows {
-        u32x4c a[kCfStreamBatch], b[kCfStreamBatch];
-        u32 len[kCfStreamBatch];
-    };
-    auto request = [&](Rows& n, u32 base) {
-        base = base < nrec ? base : 0u;
-#pragma unroll
-        for (u32 jj = 0; jj < kCfStreamBatch; ++jj) {
-            u32 li = base + jj * kCfStreamThreads + t;
-            li = li < nrec ? li : nrec - 1u;
-            const u64 i = r0 + li;
-            const u32x4c* const p0 = reinterpret_cast<const u32x4c*>(c.col + i * STRIDE);
-            n.a[jj] = __builtin_nontemporal_load(p0);
-            n.b[jj] = STRIDE > 16 ? __builtin_nontemporal_load(p0 + 1) : u32x4c{0, 0, 0, 0};
-            const u32 l = __builtin_nontemporal_load(lens + i);
-            n.len[jj] = c.len ? l : STRIDE;
-        }
-    };
-    // record (a, b, len) == record `rep` of the share?  (the representative's row from the column: the L2's by now)
-    auto same_as = [&](const u32x4c a, const u32x4c b, const u32 len, const u32 rep) -> bool {
-        const u64 j = r0 + rep;
-        const u32x4c* const q = reinterpret_cast<const u32x4c*>(c.col + j * STRIDE);
-        const u32x4c y0 = q[0], y1 = STRIDE > 16 ? q[1] : u32x4c{0, 0, 0, 0};
-        const u32 lj = c.len ? c.len[j] : STRIDE;
-        u32 diff = (len ^ lj) | (a.x ^ y0.x) | (a.y ^ y0.y) | (a.z ^ y0.z) | (a.w ^ y0.w);
-        if (STRIDE > 16) diff |= (b.x ^ y1.x) | (b.y ^ y1.y) | (b.z ^ y1.z) | (b.w ^ y1.w);
-        return diff == 0;
-    };
-    u32 trunc = 0;
-    // A batch is counted in two steps with the request for the batch after next BETWEEN them: `lookup` hashes the batch, reads
-    // the home slots' keys and requests the representatives' rows (always: a record whose home slot is empty or another
-    // value's asks for its own row — no branch around a load); `finish` compares and counts.  Loads return in order: asked
-    // for behind the prefetch, the representatives' rows would arrive behind rows that are two batches away.
-    struct Looked {
-        u32 home[kCfStreamBatch], at[kCfStreamBatch], mine[kCfStreamBatch], k0[kCfStreamBatch], lj[kCfStreamBatch];
-        u32x4c y0[kCfStreamBatch], y1[kCfStreamBatch];
-    };
-    auto lookup = [&](const Rows& r, const u32 base, Looked& k) {
-        u32x4c kq[kCfStreamBatch];
-#pragma unroll
-        for (u32 jj = 0; jj < kCfStreamBatch; ++jj) {
-            const u32 li = base + jj * kCfStreamThreads + t;
-            const u64 h = hash_regs(STRIDE, r.len[jj], r.a[jj], r.b[jj]);
-            k.home[jj] = ((u32)h & (kCfKeysSlots / 4 - 1)) * 4;  // the value's probe sequence starts at a group of four slots
-            k.mine[jj] = ((u32)(h >> 52) << kCfKeysRecBits) | li;
-            kq[jj] = *reinterpret_cast<const u32x4c*>(&s_key[k.home[jj]]);
-        }
-#pragma unroll
-        for (u32 jj = 0; jj < kCfStreamBatch; ++jj) {
-            const u32 li = base + jj * kCfStreamThreads + t;
-            // the first of the four keys with this record's tag (a key's 12 tag bits of an empty slot are all ones, and so may a
-            // record's be: the empty key itself is excluded)
-            const u32 tag = k.mine[jj] >> kCfKeysRecBits;
-            const bool m0 = (kq[jj].x >> kCfKeysRecBits) == tag && kq[jj].x != kCfKeysEmpty;
-            const bool m1 = (kq[jj].y >> kCfKeysRecBits) == tag && kq[jj].y != kCfKeysEmpty;
-            const bool m2 = (kq[jj].z >> kCfKeysRecBits) == tag && kq[jj].z != kCfKeysEmpty;
-            const bool m3 = (kq[jj].w >> kCfKeysRecBits) == tag && kq[jj].w != kCfKeysEmpty;
-            const bool cand = m0 || m1 || m2 || m3;
-            k.at[jj] = k.home[jj] + (m0 ? 0u : m1 ? 1u : m2 ? 2u : 3u);
-            k.k0[jj] = cand ? (m0 ? kq[jj].x : m1 ? kq[jj].y : m2 ? kq[jj].z : kq[jj].w) : kCfKeysEmpty;
-            const u32 rep = cand ? k.k0[jj] & kCfKeysMaxShare : (li < nrec ? li : nrec - 1u);
-            const u64 j = r0 + rep;
-            const u32x4c* const q = reinterpret_cast<const u32x4c*>(c.col + j * STRIDE);
-            k.y0[jj] = q[0];
-            k.y1[jj] = STRIDE > 16 ? q[1] : u32x4c{0, 0, 0, 0};
-            const u32 l = lens[j];
-            k.lj[jj] = c.len ? l : STRIDE;
-        }
-    };
-    auto finish = [&](const Rows& r, const u32 base, const Looked& k) {
-#pragma unroll
-        for (u32 jj = 0; jj < kCfStreamBatch; ++jj) {
-            const u32 li = base + jj * kCfStreamThreads + t;
-            if (li >= nrec) continue;
-            if (r.len[jj] > STRIDE) ++trunc;
-            const u32 home = k.home[jj], at = k.at[jj], mine = k.mine[jj], k0 = k.k0[jj];
-            u32 diff = (k0 == kCfKeysEmpty ? 1u : 0u) | (r.len[jj] ^ k.lj[jj]) | (r.a[jj].x ^ k.y0[jj].x) |
-                       (r.a[jj].y ^ k.y0[jj].y) | (r.a[jj].z ^ k.y0[jj].z) | (r.a[jj].w ^ k.y0[jj].w);
-            if (STRIDE > 16) diff |= (r.b[jj].x ^ k.y1[jj].x) | (r.b[jj].y ^ k.y1[jj].y) | (r.b[jj].z ^ k.y1[jj].z) | (r.b[jj].w ^ k.y1[jj].w);
-            if (diff == 0) {  // one of the first four slots holds this value
-                atomicAdd(&s_count[at], 1u);
-                if (mine < k0) atomicMin(&s_key[at], mine);  // (same tag: the smaller record becomes the representative)
-                continue;
-            }
-            // a new value, one that sits further along, or a second key with the same tag: slot by slot from the group's start
-            bool done = false;
-            const int max_probes = __hip_atomic_load(&s_fill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < kCfKeysSlots * 3 / 4 ? 32 : 4;
-            u32 s = home;
-            for (int p = 0; p < max_probes && !done; ++p, s = (s + 1) & (kCfKeysSlots - 1)) {
-                u32 old = s_key[s];
-                if (old == kCfKeysEmpty) old = atomicCAS(&s_key[s], kCfKeysEmpty, mine);
-                if (old == kCfKeysEmpty) {
-                    atomicAdd(&s_fill, 1u);
-                    atomicAdd(&s_count[s], 1u);
-                    done = true;
-                } else if ((old >> kCfKeysRecBits) == (mine >> kCfKeysRecBits) &&
-                           same_as(r.a[jj], r.b[jj], r.len[jj], old & kCfKeysMaxShare)) {
-                    atomicAdd(&s_count[s], 1u);
-                    if (mine < old) atomicMin(&s_key[s], mine);
-                    done = true;
-                }
-            }
-            if (!done) __hip_atomic_store(&s_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    };
-    Rows n0, n1;
-    request(n0, 0);
-    request(n1, kCfStreamStep);
-    for (u32 base = 0; base < nrec; base += 2 * kCfStreamStep) {
-        if (__hip_atomic_load(&s_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-        {
-            const Rows r = n0;
-            Looked k;
-            lookup(r, base, k);
-            request(n0, base + 2 * kCfStreamStep);
-            finish(r, base, k);
-        }
-        if (base + kCfStreamStep < nrec) {
-            const Rows r = n1;
-            Looked k;
-            lookup(r, base + kCfStreamStep, k);
-            request(n1, base + 3 * kCfStreamStep);
-            finish(r, base + kCfStreamStep, k);
-        }
-    }
-    if (trunc) atomicAdd(&s_trunc, trunc);
-    __syncthreads();
-    if (s_fail) return;  // (the share's flag stays 0: pass 1 counts it)
-    // ---- the table leaves as the share's tuples: the representative is hashed again for the partition and the tuple's hash
-    // bits, the tuples go straight to their places in the share's blocks (up to 12 288 of them: a share's blocks are
-    // contiguous, the run offsets are 16 bits wide) ------------------------------------------------------------------------
-    constexpr u32 kOwn = kCfKeysSlots / kCfStreamThreads;
-    u32 hlo[kOwn], place[kOwn];  // place: partition << 16 | rank within it (ranks < 12 288); all ones = no tuple
-#pragma unroll
-    for (u32 j = 0; j < kOwn; ++j) {
-        const u32 key = s_key[j * kCfStreamThreads + t];
-        place[j] = 0xffffffffu;
-        hlo[j] = 0;
-        if (key != kCfKeysEmpty) {
-            const u64 i = r0 + (key & kCfKeysMaxShare);
-            const u32x4c* const q = reinterpret_cast<const u32x4c*>(c.col + i * STRIDE);
-            const u64 h = hash_regs(STRIDE, c.len ? c.len[i] : STRIDE, q[0], STRIDE > 16 ? q[1] : u32x4c{0, 0, 0, 0});
-            const u32 part = cf_part(h, parts);
-            hlo[j] = (u32)h;
-            place[j] = (part << 16) | atomicAdd(&s_hist[part], 1u);
-        }
-    }
-    __syncthreads();
-    const u32 per = (parts + kCfStreamThreads - 1) / kCfStreamThreads;  // <= 4
-    u32 local = 0;
-    for (u32 k = 0; k < per; ++k) {
-        const u32 bin = t * per + k;
-        if (bin < parts) local += s_hist[bin];
-    }
-    const u32 incl = wave_incl_scan_u32(local);
-    if ((t & 63u) == 63u) s_scan[t >> 6] = incl;
-    __syncthreads();
-    u32 run = incl - local;
-    for (u32 k = 0; k < (t >> 6); ++k) run += s_scan[k];
-    u32 total = 0;
-    for (u32 k = 0; k < kCfStreamThreads / 64; ++k) total += s_scan[k];
-    const u32 share_slabs = slabs - w0 < per_share ? slabs - w0 : per_share;
-    for (u32 k = 0; k < per; ++k) {
-        const u32 bin = t * per + k;
-        if (bin < parts) {
-            const u32 cnt = s_hist[bin];
-            s_hist[bin] = run;
-            unsigned short* const o = offs + (u64)bin * slabs + w0;
-            o[0] = (unsigned short)run;
-            for (u32 q = 1; q < share_slabs; ++q) o[q] = 0;
-            run += cnt;
-        }
-    }
-    for (u32 q = t; q < share_slabs; q += kCfStreamThreads) {
-        offs[(u64)parts * slabs + w0 + q] = (unsigned short)(q == 0 ? total : 0u);
-        const u32 before = q * kCfSlab;
-        const u32 left = s_trunc > before ? s_trunc - before : 0u;
-        offs[(u64)(parts + 1) * slabs + w0 + q] = (unsigned short)(left < kCfSlab ? left : kCfSlab);
-    }
-    __syncthreads();
-    u32* const block = tuples + (u64)w0 * kCfSlab * kCfTupleWords;
-#pragma unroll
-    for (u32 j = 0; j < kOwn; ++j) {
-        if (place[j] != 0xffffffffu) {
-            const u32 slot = j * kCfStreamThreads + t;
-            u32* const q = block + (u64)(s_hist[place[j] >> 16] + (place[j] & 0xffffu)) * kCfTupleWords;
-            q[0] = (u32)r0 + (s_key[slot] & kCfKeysMaxShare);
-            q[1] = s_count[slot];
-            q[2] = hlo[j];
         }
     }
     if (t == 0) share_done[w] = 1;
@@ -1380,7 +1169,8 @@ hipError_t launch_colfreq(const void* d_col, const void* d_len, u64 n_rows, u32 
 #ifdef CSVSIMD_CF_NO_STREAM  // (tuning builds)
     const bool stream_first = false;
 #else
-    const bool stream_first = (stride == 16 || stride == 32) && g.slabs >= 2 * cus && cus <= kCfMaxShares;
+    const bool stream_first = (stride == 16 || stride == 32) && g.slabs >= 2 * cus && cus <= kCfMaxShares &&
+                              (u64)((g.slabs + cus - 1) / cus) * kCfSlab <= kCfStreamMaxShare;  // (a share's records number 20 bits)
 #endif
     const u32 per_share = stream_first ? (g.slabs + cus - 1) / cus : 1u;
     if (stream_first) {
@@ -1391,19 +1181,6 @@ hipError_t launch_colfreq(const void* d_col, const void* d_len, u64 n_rows, u32 
         else
             hipLaunchKernelGGL(colfreq_stream_kernel<16>, dim3(shares), dim3(kCfStreamThreads), 0, stream, c, offs, tuples, g.parts,
                                g.slabs, per_share, status, ticket, share_flags);
-        hipError_t e0 = hipGetLastError();
-        if (e0 != hipSuccess) return e0;
-    }
-    // ... and for the shares it gave up on, the attempt with the larger table of keys (a share's records number 20 bits, and its
-    // 12 288 tuples need a second block behind the first)
-    if (stream_first && per_share >= 2 && (u64)per_share * kCfSlab <= kCfKeysMaxShare) {
-        const u32 shares = (g.slabs + per_share - 1) / per_share;
-        if (stride == 32)
-            hipLaunchKernelGGL(colfreq_stream_keys_kernel<32>, dim3(shares), dim3(kCfStreamThreads), 0, stream, c, offs, tuples,
-                               g.parts, g.slabs, per_share, share_flags);
-        else
-            hipLaunchKernelGGL(colfreq_stream_keys_kernel<16>, dim3(shares), dim3(kCfStreamThreads), 0, stream, c, offs, tuples,
-                               g.parts, g.slabs, per_share, share_flags);
         hipError_t e0 = hipGetLastError();
         if (e0 != hipSuccess) return e0;
     }
