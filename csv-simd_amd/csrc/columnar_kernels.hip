@@ -664,7 +664,7 @@ __global__ __launch_bounds__(kCfThreads1, 4) void colfreq_partition_kernel(const
 // its group (2 % of the values when the table holds 1 000), a second key with the same tag, a row still on its way — goes
 // slot by slot from the group's start; the table takes 1 536 values (half its slots).  The smallest record of a value ends up as its representative (a 32-bit minimum on
 // the key: same tag, smaller record), the tuple's hash bits are recomputed from the row copy when the table leaves.
-// Measured at 32 Mi records x 32 bytes: 100 values 0.50 -> 0.28 ms (the bare stream of this kernel: 0.225; a version that
+// Measured at 32 Mi records x 32 bytes: 100 values 0.50 -> 0.26 ms (0.277 with per-lane row loads, whose bare stream is 0.225; a version that
 // compared against the representative's row in the COLUMN instead of LDS, with 16 384 slots: 2 000 values 0.65 ms, 5 000
 // 1.0, 10 000 2.7 — a gather per record from the L2, whose working set is a share's representatives x 32 CUs).
 static constexpr u32 kCfStreamGroups = 768;
@@ -721,16 +721,36 @@ __global__ __launch_bounds__(kCfStreamThreads) void colfreq_stream_kernel(const 
         u32x4c a[kCfStreamBatch], b[kCfStreamBatch];
         u32 len[kCfStreamBatch];
     };
+    // Rows of 32 bytes are fetched the way colsearch_small_kernel fetches them: a wave's two loads are 16 bytes per lane over the
+    // CONTIGUOUS 2 KiB of its 64 records (a lane fetching its own row asks for 16 bytes every 32: 4.8 instead of 5.2 TB/s), a
+    // lane then holds piece `lane` of records 0..31 and piece `lane` of records 32..63 of the group, neighbours swap one of them
+    // by DPP, and lane l counts record (l >> 1) + 32 * (l & 1) of the group.
+#ifdef CSVSIMD_CF_STREAM_PER_LANE  // (tuning builds)
+    constexpr bool kSwap = false;
+#else
+    constexpr bool kSwap = STRIDE == 32;
+#endif
+    const u32 lane = t & 63u;
+    const u32 mine_in_wave = kSwap ? (lane >> 1) + ((lane & 1u) << 5) : lane;
+    const u32 tt = (t & ~63u) + mine_in_wave;  // this thread's record within a step's run of 1 024
     auto request = [&](Rows& n, u32 base) {
         base = base < nrec ? base : 0u;
 #pragma unroll
         for (u32 jj = 0; jj < kCfStreamBatch; ++jj) {
-            u32 li = base + jj * kCfStreamThreads + t;
+            u32 li = base + jj * kCfStreamThreads + tt;
             li = li < nrec ? li : nrec - 1u;
             const u64 i = r0 + li;
-            const u32x4c* const p0 = reinterpret_cast<const u32x4c*>(c.col + i * STRIDE);
-            n.a[jj] = __builtin_nontemporal_load(p0);
-            n.b[jj] = STRIDE > 16 ? __builtin_nontemporal_load(p0 + 1) : u32x4c{0, 0, 0, 0};
+            if (kSwap) {
+                const u32x4c* const p = reinterpret_cast<const u32x4c*>(c.col + r0 * STRIDE);
+                const u32 last_piece = 2u * nrec - 1u;
+                const u32 q0 = 2u * (base + jj * kCfStreamThreads + (t & ~63u)) + lane, q1 = q0 + 64u;
+                n.a[jj] = __builtin_nontemporal_load(p + (q0 < last_piece ? q0 : last_piece));
+                n.b[jj] = __builtin_nontemporal_load(p + (q1 < last_piece ? q1 : last_piece));
+            } else {
+                const u32x4c* const p0 = reinterpret_cast<const u32x4c*>(c.col + i * STRIDE);
+                n.a[jj] = __builtin_nontemporal_load(p0);
+                n.b[jj] = STRIDE > 16 ? __builtin_nontemporal_load(p0 + 1) : u32x4c{0, 0, 0, 0};
+            }
             const u32 l = __builtin_nontemporal_load(lens + i);
             n.len[jj] = c.len ? l : STRIDE;
         }
@@ -739,17 +759,35 @@ __global__ __launch_bounds__(kCfStreamThreads) void colfreq_stream_kernel(const 
     auto count = [&](const Rows& r, const u32 base) {
         u32 home[kCfStreamBatch], mine[kCfStreamBatch];
         u32x4c kq[kCfStreamBatch];
+        u32x4c A[kCfStreamBatch], B[kCfStreamBatch];  // this thread's rows
+#pragma unroll
+        for (u32 jj = 0; jj < kCfStreamBatch; ++jj) {
+            A[jj] = r.a[jj];
+            B[jj] = r.b[jj];
+            if (kSwap) {
+                // the half my neighbour needs: an even lane gives away its piece of records 32..63, an odd lane its piece of 0..31
+                const bool odd = (lane & 1u) != 0;
+                const u32x4c give = odd ? r.a[jj] : r.b[jj];
+                u32x4c got;
+                got.x = (u32)__builtin_amdgcn_mov_dpp((int)give.x, 0xb1, 0xf, 0xf, true);  // quad_perm [1, 0, 3, 2]
+                got.y = (u32)__builtin_amdgcn_mov_dpp((int)give.y, 0xb1, 0xf, 0xf, true);
+                got.z = (u32)__builtin_amdgcn_mov_dpp((int)give.z, 0xb1, 0xf, 0xf, true);
+                got.w = (u32)__builtin_amdgcn_mov_dpp((int)give.w, 0xb1, 0xf, 0xf, true);
+                A[jj] = odd ? got : r.a[jj];
+                B[jj] = odd ? r.b[jj] : got;
+            }
+        }
 #pragma unroll
         for (u32 jj = 0; jj < kCfStreamBatch; ++jj) {  // the batch's groups of keys are requested together
-            const u32 li = base + jj * kCfStreamThreads + t;
-            const u64 h = hash_regs(STRIDE, r.len[jj], r.a[jj], r.b[jj]);
+            const u32 li = base + jj * kCfStreamThreads + tt;
+            const u64 h = hash_regs(STRIDE, r.len[jj], A[jj], B[jj]);
             home[jj] = (u32)(((u64)(u32)h * kCfStreamGroups) >> 32) * 4;
             mine[jj] = ((u32)(h >> 52) << kCfStreamRecBits) | li;
             kq[jj] = *reinterpret_cast<const u32x4c*>(&s_key[home[jj]]);
         }
 #pragma unroll
         for (u32 jj = 0; jj < kCfStreamBatch; ++jj) {
-            const u32 li = base + jj * kCfStreamThreads + t;
+            const u32 li = base + jj * kCfStreamThreads + tt;
             if (li >= nrec) continue;
             const u32 len = r.len[jj];
             if (len > STRIDE) ++trunc;
@@ -768,8 +806,8 @@ __global__ __launch_bounds__(kCfStreamThreads) void colfreq_stream_kernel(const 
                 const u32 rl0 = __hip_atomic_load(&s_rlen[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 asm volatile("" ::: "memory");
                 const u32x4c b0 = s_rows[at], b1 = STRIDE > 16 ? s_rows[kCfStreamSlots + at] : u32x4c{0, 0, 0, 0};
-                u32 diff = (rl0 ^ (len | 0x80000000u)) | (r.a[jj].x ^ b0.x) | (r.a[jj].y ^ b0.y) | (r.a[jj].z ^ b0.z) | (r.a[jj].w ^ b0.w);
-                if (STRIDE > 16) diff |= (r.b[jj].x ^ b1.x) | (r.b[jj].y ^ b1.y) | (r.b[jj].z ^ b1.z) | (r.b[jj].w ^ b1.w);
+                u32 diff = (rl0 ^ (len | 0x80000000u)) | (A[jj].x ^ b0.x) | (A[jj].y ^ b0.y) | (A[jj].z ^ b0.z) | (A[jj].w ^ b0.w);
+                if (STRIDE > 16) diff |= (B[jj].x ^ b1.x) | (B[jj].y ^ b1.y) | (B[jj].z ^ b1.z) | (B[jj].w ^ b1.w);
                 if (diff == 0) {
                     atomicAdd(&s_count[at], 1u);
                     if (mine[jj] < k0) atomicMin(&s_key[at], mine[jj]);  // (same tag: the smaller record becomes the representative)
@@ -791,8 +829,8 @@ __global__ __launch_bounds__(kCfStreamThreads) void colfreq_stream_kernel(const 
                 if (old == kCfStreamEmpty) {
                     atomicAdd(&s_fill, 1u);
                     atomicAdd(&s_count[s], 1u);
-                    s_rows[s] = r.a[jj];
-                    if (STRIDE > 16) s_rows[kCfStreamSlots + s] = r.b[jj];
+                    s_rows[s] = A[jj];
+                    if (STRIDE > 16) s_rows[kCfStreamSlots + s] = B[jj];
                     __hip_atomic_store(&s_rlen[s], len | 0x80000000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     done = true;
                 } else if ((old >> kCfStreamRecBits) == tag) {
@@ -800,8 +838,8 @@ __global__ __launch_bounds__(kCfStreamThreads) void colfreq_stream_kernel(const 
                     if (rl >> 31) {
                         asm volatile("" ::: "memory");
                         const u32x4c c0 = s_rows[s], c1 = STRIDE > 16 ? s_rows[kCfStreamSlots + s] : u32x4c{0, 0, 0, 0};
-                        eq = (rl & 0x7fffffffu) == len && r.a[jj].x == c0.x && r.a[jj].y == c0.y && r.a[jj].z == c0.z && r.a[jj].w == c0.w &&
-                             (STRIDE <= 16 || (r.b[jj].x == c1.x && r.b[jj].y == c1.y && r.b[jj].z == c1.z && r.b[jj].w == c1.w));
+                        eq = (rl & 0x7fffffffu) == len && A[jj].x == c0.x && A[jj].y == c0.y && A[jj].z == c0.z && A[jj].w == c0.w &&
+                             (STRIDE <= 16 || (B[jj].x == c1.x && B[jj].y == c1.y && B[jj].z == c1.z && B[jj].w == c1.w));
                     } else {
                         eq = rows_equal(c, r0 + li, r0 + (old & kCfStreamMaxShare), len);  // (the slot's copy is not there yet)
                     }
