@@ -1398,9 +1398,11 @@ __global__ __launch_bounds__(256, 2) void colsearch_small_kernel(const ColView c
     //              rows 32..63 — neighbours swap one of them (DPP), the even lanes end up with rows 0..31, the odd lanes with
     //              rows 32..63 (row_of_lane), and the ballot's bits are un-interleaved.  equals / starts-with, which are all
     //              memory: 0.213 ms for 1 GiB = 63 % of 8 TB/s (a lane fetching its own row: 0.230 = 58 %).
-    //   otherwise  a lane fetches its own row (two loads 32 bytes apart from its neighbour's: 4.9 TB/s).  `contains`, which is
-    //              bound by its ~200 VALU instructions per row: the swap, the selects and the bit shuffle cost it more
-    //              (0.29 ms) than the better stream gives (0.265 ms without them) — profiles/r05_consumers_1GiB_*.json.
+    //   otherwise  a lane fetches its own row (two loads 32 bytes apart from its neighbour's: 4.9 TB/s): rows of 16 bytes.  With
+    //              the first version's three-byte filter and one batch in flight `contains` was faster this way (0.265 against
+    //              0.29 ms: the swap, the selects and the bit shuffle cost more than the better stream gave); with the four-byte
+    //              compare and two batches in flight it is 6 % slower (0.302 against 0.286 on one box), so rows of 32 bytes
+    //              take the contiguous loads in every mode (profiles/r05_colsearch_variants.txt).
     constexpr bool kSwap = COALESCED && STRIDE == 32;
     const u32 row_of_lane = kSwap ? (lane >> 1) + ((lane & 1u) << 5) : lane;
     // (no branch around a load: rows past the end are fetched from the last row's address and never looked at, a missing lengths
@@ -1567,11 +1569,8 @@ hipError_t launch_colsearch(const void* d_col, const void* d_len, u64 n_rows, u3
     // (2, 3) 0.230 / 0.340, (2, 2) 0.276 / 0.380, (3, 4) 0.229 / 0.309, (4, 4) 0.220 / 0.295 — fewer, longer streams until the
     // arithmetic of `contains` runs out of waves (profiles/r05_colsearch_variants.txt)
     constexpr u32 kSmallGrid = 256 * CSVSIMD_CS_GRID;
-    if (small && stride == 32 && mode != 2)
+    if (small && stride == 32)  // (every mode: `contains` too is 6 % faster with the contiguous loads once two batches are in flight)
         hipLaunchKernelGGL((colsearch_small_kernel<32, true>), dim3(cgrid_for(n_rows, 256, kSmallGrid)), dim3(256), 0, stream, c,
-                           (const uint8_t*)d_needle, needle_len, mode, (u64*)d_bitmap, (u64*)d_count, (u64*)d_truncated);
-    else if (small && stride == 32)
-        hipLaunchKernelGGL((colsearch_small_kernel<32, false>), dim3(cgrid_for(n_rows, 256, kSmallGrid)), dim3(256), 0, stream, c,
                            (const uint8_t*)d_needle, needle_len, mode, (u64*)d_bitmap, (u64*)d_count, (u64*)d_truncated);
     else if (small)
         hipLaunchKernelGGL((colsearch_small_kernel<16, false>), dim3(cgrid_for(n_rows, 256, kSmallGrid)), dim3(256), 0, stream, c,
