@@ -794,13 +794,29 @@ __global__ __launch_bounds__(kCfStreamThreads) void colfreq_stream_kernel(const 
             // the first of the group's keys with this record's tag (an empty key's tag bits are all ones, and so may a record's
             // be: the empty key itself is excluded)
             const u32 tag = mine[jj] >> kCfStreamRecBits;
-            const bool m0 = (kq[jj].x >> kCfStreamRecBits) == tag && kq[jj].x != kCfStreamEmpty;
-            const bool m1 = (kq[jj].y >> kCfStreamRecBits) == tag && kq[jj].y != kCfStreamEmpty;
-            const bool m2 = (kq[jj].z >> kCfStreamRecBits) == tag && kq[jj].z != kCfStreamEmpty;
-            const bool m3 = (kq[jj].w >> kCfStreamRecBits) == tag && kq[jj].w != kCfStreamEmpty;
+            u32x4c q = kq[jj];
+            u32 g0 = home[jj];
+            bool m0 = (q.x >> kCfStreamRecBits) == tag && q.x != kCfStreamEmpty;
+            bool m1 = (q.y >> kCfStreamRecBits) == tag && q.y != kCfStreamEmpty;
+            bool m2 = (q.z >> kCfStreamRecBits) == tag && q.z != kCfStreamEmpty;
+            bool m3 = (q.w >> kCfStreamRecBits) == tag && q.w != kCfStreamEmpty;
+#ifndef CSVSIMD_CF_STREAM_ONE_GROUP
+            if (!(m0 || m1 || m2 || m3) && q.x != kCfStreamEmpty && q.y != kCfStreamEmpty && q.z != kCfStreamEmpty && q.w != kCfStreamEmpty) {
+                // no key with this tag in a group that is FULL: the value, if the table has it, sits further along — nearly always
+                // in the next group (with 1 000 values in the table 2 % of them sit past their group, and a wave in which one
+                // lane walks slot by slot waits for it: 72 % of the waves did; 1 000 values 0.377 -> 0.302 ms, 1 400: 0.54 ->
+                // 0.39).  An empty slot in the group means the value is not in the table at all (nothing is ever removed).
+                g0 = g0 + 4 < kCfStreamSlots ? g0 + 4 : 0u;
+                q = *reinterpret_cast<const u32x4c*>(&s_key[g0]);
+                m0 = (q.x >> kCfStreamRecBits) == tag && q.x != kCfStreamEmpty;
+                m1 = (q.y >> kCfStreamRecBits) == tag && q.y != kCfStreamEmpty;
+                m2 = (q.z >> kCfStreamRecBits) == tag && q.z != kCfStreamEmpty;
+                m3 = (q.w >> kCfStreamRecBits) == tag && q.w != kCfStreamEmpty;
+            }
+#endif
             if (m0 || m1 || m2 || m3) {
-                const u32 at = home[jj] + (m0 ? 0u : m1 ? 1u : m2 ? 2u : 3u);
-                const u32 k0 = m0 ? kq[jj].x : m1 ? kq[jj].y : m2 ? kq[jj].z : kq[jj].w;
+                const u32 at = g0 + (m0 ? 0u : m1 ? 1u : m2 ? 2u : 3u);
+                const u32 k0 = m0 ? q.x : m1 ? q.y : m2 ? q.z : q.w;
                 // (the row is read BEHIND the flag and a wave's LDS operations execute in order: a flag that is up means the row
                 // read after it is complete)
                 const u32 rl0 = __hip_atomic_load(&s_rlen[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
