@@ -662,7 +662,7 @@ __global__ __launch_bounds__(kCfThreads1, 4) void colfreq_partition_kernel(const
 // of its row.  A value's probe sequence starts at its group: ONE 16-byte LDS read fetches the group's keys, the first with
 // the record's tag names the slot, row and length are compared from LDS.  Anything else — a new value, one that sits past
 // its group (2 % of the values when the table holds 1 000), a second key with the same tag, a row still on its way — goes
-// slot by slot from the group's start; the table takes 1 536 values (half its slots).  The smallest record of a value ends up as its representative (a 32-bit minimum on
+// slot by slot from the group's start; the table takes 2 304 values (three quarters of its slots).  The smallest record of a value ends up as its representative (a 32-bit minimum on
 // the key: same tag, smaller record), the tuple's hash bits are recomputed from the row copy when the table leaves.
 // Measured at 32 Mi records x 32 bytes: 100 values 0.50 -> 0.26 ms (0.277 with per-lane row loads, whose bare stream is 0.225; a version that
 // compared against the representative's row in the COLUMN instead of LDS, with 16 384 slots: 2 000 values 0.65 ms, 5 000
@@ -831,11 +831,16 @@ __global__ __launch_bounds__(kCfStreamThreads) void colfreq_stream_kernel(const 
                 }
             }
             // slot by slot from the group's start
-            // (an empty slot ends the search: the value is new.  New values are taken while the table is less than half full —
-            // probe sequences stay short, and a column of many values gives up within its first few thousand records instead
-            // of at the end of the share, with the whole pass wasted)
+            // (an empty slot ends the search: the value is new.  New values are taken while the table is less than three quarters
+            // full, however long the probe sequence: a share either fits or gives up when its 2 305th value shows up — for a
+            // column of many values within its first few thousand records.  With a limit on the probes instead, a share of 2 000
+            // values gave up at its END: 2.4 ms, the whole pass wasted.  Measured, ms at 32 Mi records: 1 400 values 0.40, 1 800
+            // 0.64, 2 000 0.79, 2 200 0.94, against 1.9-2.0 for the general passes.)
             bool done = false;
-            const bool room = __hip_atomic_load(&s_fill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < kCfStreamSlots / 2;
+#ifndef CSVSIMD_CF_STREAM_ROOM
+#define CSVSIMD_CF_STREAM_ROOM (kCfStreamSlots * 3 / 4)
+#endif
+            const bool room = __hip_atomic_load(&s_fill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < CSVSIMD_CF_STREAM_ROOM;
             u32 s = home[jj];
             for (u32 p = 0; p < kCfStreamSlots && !done; ++p, s = s + 1 < kCfStreamSlots ? s + 1 : 0) {
                 u32 old = s_key[s];

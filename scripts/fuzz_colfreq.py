@@ -23,7 +23,7 @@ def main():
     while time.time() < t_end:
         n = int(rng.integers(4_200_000, 9_000_000))
         stride = int(rng.choice([16, 32]))
-        nvals = int(rng.choice([1, 2, 17, 100, 700, 1400, 1530, 1536, 1545, 1700, 3000, 6000]))
+        nvals = int(rng.choice([1, 2, 17, 100, 700, 1400, 2000, 2290, 2304, 2315, 2500, 3000, 6000]))
         shape = str(rng.choice(["uniform", "skewed", "late", "switch", "distinct"]))
         if shape == "distinct":
             keys = np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)

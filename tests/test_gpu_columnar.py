@@ -229,7 +229,7 @@ def test_columnar_frequency_long_columns_of_few_values(ctx, pkg, torch_cuda, str
             keys = rng.integers(0, 50, size=n).astype(np.uint64)
             keys[split:] = (np.arange(n - split, dtype=np.uint64) + np.uint64(1000)) * np.uint64(0x9E3779B97F4A7C15)
         elif kind == "edge":
-            keys = rng.integers(0, 1500, size=n).astype(np.uint64) * np.uint64(0xD6E8FEB86659FD93)
+            keys = rng.integers(0, 2300, size=n).astype(np.uint64) * np.uint64(0xD6E8FEB86659FD93)   # (a share takes 2 304)
         else:
             keys = rng.integers(0, 20, size=n).astype(np.uint64)
             lens = rng.integers(8, stride + 1, size=n).astype(np.int32)
