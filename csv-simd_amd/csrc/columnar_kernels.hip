@@ -657,18 +657,18 @@ __global__ __launch_bounds__(kCfThreads1, 4) void colfreq_partition_kernel(const
 // workgroup leaves its share "not done" and colfreq_partition_kernel — launched behind this kernel, its workgroups skip
 // finished shares — counts those slabs the general way.  A column of distinct values costs every workgroup one batch before
 // it gives up.
-// The table: 3 072 slots in groups of four.  A slot is a 32-bit key (12 hash bits | the number of a representative record
+// The table: 3 072 slots in groups of four (rows of 16 bytes: 5 120).  A slot is a 32-bit key (12 hash bits | the number of a representative record
 // within the share, 20 bits; all ones = empty), a count, the representative's length (bit 31: its row has arrived) and a copy
 // of its row.  A value's probe sequence starts at its group: ONE 16-byte LDS read fetches the group's keys, the first with
 // the record's tag names the slot, row and length are compared from LDS.  Anything else — a new value, one that sits past
 // its group (2 % of the values when the table holds 1 000), a second key with the same tag, a row still on its way — goes
-// slot by slot from the group's start; the table takes 2 304 values (three quarters of its slots).  The smallest record of a value ends up as its representative (a 32-bit minimum on
+// slot by slot from the group's start; the table takes 2 304 values (three quarters of its slots; 3 840 for rows of 16 bytes).  The smallest record of a value ends up as its representative (a 32-bit minimum on
 // the key: same tag, smaller record), the tuple's hash bits are recomputed from the row copy when the table leaves.
 // Measured at 32 Mi records x 32 bytes: 100 values 0.50 -> 0.26 ms (0.277 with per-lane row loads, whose bare stream is 0.225; a version that
 // compared against the representative's row in the COLUMN instead of LDS, with 16 384 slots: 2 000 values 0.65 ms, 5 000
 // 1.0, 10 000 2.7 — a gather per record from the L2, whose working set is a share's representatives x 32 CUs).
-static constexpr u32 kCfStreamGroups = 768;
-static constexpr u32 kCfStreamSlots = kCfStreamGroups * 4;
+// groups of four slots: 768 for rows of 32 bytes, 1 280 for rows of 16 (a slot is 12 bytes + the row: ~132 and ~140 KiB of LDS)
+template <u32 STRIDE> struct CfStreamTable { static constexpr u32 kGroups = STRIDE > 16 ? 768u : 1280u; };
 static constexpr u32 kCfStreamThreads = 1024;
 #ifndef CSVSIMD_CF_STREAM_BATCH
 #define CSVSIMD_CF_STREAM_BATCH 2
@@ -683,6 +683,8 @@ __global__ __launch_bounds__(kCfStreamThreads) void colfreq_stream_kernel(const 
                                                                         u32* __restrict__ tuples, u32 parts, u32 slabs, u32 per_share,
                                                                         ColFreqStatus* __restrict__ status, u32* __restrict__ ticket,
                                                                         u32* __restrict__ share_done) {
+    constexpr u32 kCfStreamGroups = CfStreamTable<STRIDE>::kGroups, kCfStreamSlots = kCfStreamGroups * 4;
+    constexpr u32 kRowParts = STRIDE > 16 ? 2u : 1u;  // 16-byte pieces of a row
     __shared__ __attribute__((aligned(16))) u32 s_key[kCfStreamSlots];
     __shared__ u32 s_count[kCfStreamSlots];
     __shared__ u32 s_rlen[kCfStreamSlots];
@@ -690,8 +692,9 @@ __global__ __launch_bounds__(kCfStreamThreads) void colfreq_stream_kernel(const 
     __shared__ u32 s_scan[kCfStreamThreads / 64];
     __shared__ u32 s_fill, s_trunc, s_fail;
     // the representatives' rows (bytes 0..15 of slot s in s_rows[s], 16..31 in s_rows[slots + s]); at the end: the tuples
-    __shared__ __attribute__((aligned(16))) u32x4c s_rows[2 * kCfStreamSlots];
-    static_assert(sizeof(u32x4c) * 2 * kCfStreamSlots >= kCfStreamSlots * kCfTupleWords * 4, "the row cache doubles as the tuple staging");
+    __shared__ __attribute__((aligned(16))) u32x4c s_rows[kRowParts * kCfStreamSlots];
+    static_assert(sizeof(u32x4c) * kRowParts * kCfStreamSlots >= kCfStreamSlots * kCfTupleWords * 4, "the row cache doubles as the tuple staging");
+    static_assert(kCfStreamSlots % kCfStreamThreads == 0, "the table leaves as whole slots per thread");
     const u32 t = threadIdx.x, w = blockIdx.x;
     for (u32 k = t; k < kCfStreamSlots; k += kCfStreamThreads) {
         s_key[k] = kCfStreamEmpty;
