@@ -359,10 +359,7 @@ static constexpr u32 kCfRound2 = 6144;       // tuples a pass-2 round may be ask
 #define CSVSIMD_CF_THREADS2 1024
 #endif
 static constexpr u32 kCfThreads2 = CSVSIMD_CF_THREADS2;
-#ifndef CSVSIMD_CF_BATCH2
-#define CSVSIMD_CF_BATCH2 1
-#endif
-static constexpr u32 kCfBatch2 = CSVSIMD_CF_BATCH2;  // tuples a pass-2 thread has in flight (tuning builds: see the loop)
+static constexpr u32 kCfBatch2 = 1;         // tuples a pass-2 thread has in flight (4 and 8 were measured: see the loop)
 static constexpr u32 kCfTupleWords = 3;      // {first record, count, low 32 hash bits}
 static constexpr u32 kCfTickets = 16;        // pass 2's ticket counters, a 128-byte line each
 static constexpr u32 kCfTicketBytes = kCfTickets * 128;
@@ -670,10 +667,7 @@ __global__ __launch_bounds__(kCfThreads1, 4) void colfreq_partition_kernel(const
 // groups of four slots: 768 for rows of 32 bytes, 1 280 for rows of 16 (a slot is 12 bytes + the row: ~132 and ~140 KiB of LDS)
 template <u32 STRIDE> struct CfStreamTable { static constexpr u32 kGroups = STRIDE > 16 ? 768u : 1280u; };
 static constexpr u32 kCfStreamThreads = 1024;
-#ifndef CSVSIMD_CF_STREAM_BATCH
-#define CSVSIMD_CF_STREAM_BATCH 2
-#endif
-static constexpr u32 kCfStreamBatch = CSVSIMD_CF_STREAM_BATCH;  // rows per thread and batch
+static constexpr u32 kCfStreamBatch = 2;  // rows per thread and batch (1 and 3: the same and 2 % slower)
 static constexpr u32 kCfStreamStep = kCfStreamThreads * kCfStreamBatch;  // records per workgroup and step
 static constexpr u32 kCfStreamEmpty = 0xffffffffu;
 static constexpr u32 kCfStreamRecBits = 20;
@@ -728,11 +722,7 @@ __global__ __launch_bounds__(kCfStreamThreads) void colfreq_stream_kernel(const 
     // CONTIGUOUS 2 KiB of its 64 records (a lane fetching its own row asks for 16 bytes every 32: 4.8 instead of 5.2 TB/s), a
     // lane then holds piece `lane` of records 0..31 and piece `lane` of records 32..63 of the group, neighbours swap one of them
     // by DPP, and lane l counts record (l >> 1) + 32 * (l & 1) of the group.
-#ifdef CSVSIMD_CF_STREAM_PER_LANE  // (tuning builds)
-    constexpr bool kSwap = false;
-#else
     constexpr bool kSwap = STRIDE == 32;
-#endif
     const u32 lane = t & 63u;
     const u32 mine_in_wave = kSwap ? (lane >> 1) + ((lane & 1u) << 5) : lane;
     const u32 tt = (t & ~63u) + mine_in_wave;  // this thread's record within a step's run of 1 024
@@ -803,7 +793,6 @@ __global__ __launch_bounds__(kCfStreamThreads) void colfreq_stream_kernel(const 
             bool m1 = (q.y >> kCfStreamRecBits) == tag && q.y != kCfStreamEmpty;
             bool m2 = (q.z >> kCfStreamRecBits) == tag && q.z != kCfStreamEmpty;
             bool m3 = (q.w >> kCfStreamRecBits) == tag && q.w != kCfStreamEmpty;
-#ifndef CSVSIMD_CF_STREAM_ONE_GROUP
             if (!(m0 || m1 || m2 || m3) && q.x != kCfStreamEmpty && q.y != kCfStreamEmpty && q.z != kCfStreamEmpty && q.w != kCfStreamEmpty) {
                 // no key with this tag in a group that is FULL: the value, if the table has it, sits further along — nearly always
                 // in the next group (with 1 000 values in the table 2 % of them sit past their group, and a wave in which one
@@ -816,7 +805,6 @@ __global__ __launch_bounds__(kCfStreamThreads) void colfreq_stream_kernel(const 
                 m2 = (q.z >> kCfStreamRecBits) == tag && q.z != kCfStreamEmpty;
                 m3 = (q.w >> kCfStreamRecBits) == tag && q.w != kCfStreamEmpty;
             }
-#endif
             if (m0 || m1 || m2 || m3) {
                 const u32 at = g0 + (m0 ? 0u : m1 ? 1u : m2 ? 2u : 3u);
                 const u32 k0 = m0 ? q.x : m1 ? q.y : m2 ? q.z : q.w;
@@ -840,10 +828,7 @@ __global__ __launch_bounds__(kCfStreamThreads) void colfreq_stream_kernel(const 
             // values gave up at its END: 2.4 ms, the whole pass wasted.  Measured, ms at 32 Mi records: 1 400 values 0.40, 1 800
             // 0.64, 2 000 0.79, 2 200 0.94, against 1.9-2.0 for the general passes.)
             bool done = false;
-#ifndef CSVSIMD_CF_STREAM_ROOM
-#define CSVSIMD_CF_STREAM_ROOM (kCfStreamSlots * 3 / 4)
-#endif
-            const bool room = __hip_atomic_load(&s_fill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < CSVSIMD_CF_STREAM_ROOM;
+            const bool room = __hip_atomic_load(&s_fill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < kCfStreamSlots * 3 / 4;
             u32 s = home[jj];
             for (u32 p = 0; p < kCfStreamSlots && !done; ++p, s = s + 1 < kCfStreamSlots ? s + 1 : 0) {
                 u32 old = s_key[s];
@@ -1228,12 +1213,8 @@ hipError_t launch_colfreq(const void* d_col, const void* d_len, u64 n_rows, u32 
     u32* const share_flags = (u32*)((char*)d_scratch + g.bytes - kCfShareFlagBytes);
     const u32 cus = (u32)(n_cus > 0 ? n_cus : 256);
     // two rounds of slabs per CU and more (4 Mi records): first the streaming attempt, one workgroup per CU over a share of slabs
-#ifdef CSVSIMD_CF_NO_STREAM  // (tuning builds)
-    const bool stream_first = false;
-#else
     const bool stream_first = (stride == 16 || stride == 32) && g.slabs >= 2 * cus && cus <= kCfMaxShares &&
                               (u64)((g.slabs + cus - 1) / cus) * kCfSlab <= kCfStreamMaxShare;  // (a share's records number 20 bits)
-#endif
     const u32 per_share = stream_first ? (g.slabs + cus - 1) / cus : 1u;
     if (stream_first) {
         const u32 shares = (g.slabs + per_share - 1) / per_share;
@@ -1247,11 +1228,7 @@ hipError_t launch_colfreq(const void* d_col, const void* d_len, u64 n_rows, u32 
         if (e0 != hipSuccess) return e0;
     }
     const u32* const done = stream_first ? share_flags : nullptr;
-#ifdef CSVSIMD_CF_GRID1_SLABS  // (tuning builds)
-    const u32 grid1 = g.slabs;
-#else
     const u32 grid1 = stream_first ? cus : g.slabs;
-#endif
     if (stride <= 32)
         hipLaunchKernelGGL(colfreq_partition_kernel<true>, dim3(grid1), dim3(kCfThreads1), 0, stream, c, offs, tuples, g.parts,
                            g.slabs, status, ticket, done, per_share);
@@ -1435,11 +1412,7 @@ __global__ __launch_bounds__(256, 2) void colsearch_small_kernel(const ColView c
     const u64 last_row = c.n_rows - 1;
     const u32* const lens = c.len ? c.len : reinterpret_cast<const u32*>(c.col);
     auto fetch = [&](u64 wd, u32x4c& va, u32x4c& vb, u32& vlen) {
-#ifdef CSVSIMD_CS_BRANCHY
-        if (wd >= n_words) return;
-#else
         if (wd >= n_words) wd = n_words - 1;
-#endif
         const u64 i0 = wd * 64;
         if (kSwap) {
             const u64 last_piece = c.n_rows * 2 - 1;  // 16-byte pieces of the column
@@ -1551,10 +1524,7 @@ __global__ __launch_bounds__(256, 2) void colsearch_small_kernel(const ColView c
     };
     // TWO batches of rows are in flight per wave while a third is searched: with one, a wave's 2 KiB were requested a
     // search ahead of their use and the column streamed at the rate of (resident waves x 2 KiB) per memory latency.
-#ifndef CSVSIMD_CS_DEPTH
-#define CSVSIMD_CS_DEPTH 2
-#endif
-    constexpr u32 kDepth = CSVSIMD_CS_DEPTH;
+    constexpr u32 kDepth = 2;
     u32x4c va[kDepth], vb[kDepth];
     u32 vlen[kDepth];
 #pragma unroll
@@ -1585,14 +1555,11 @@ hipError_t launch_colsearch(const void* d_col, const void* d_len, u64 n_rows, u3
     // rows of 16 / 32 bytes and a needle that fits the row: the register-resident search.  A persistent-sized grid (4
     // workgroups per CU) whose waves walk the column with two batches of loads in flight each.
     const bool small = (stride == 16 || stride == 32) && needle_len <= stride;
-#ifndef CSVSIMD_CS_GRID
-#define CSVSIMD_CS_GRID 4
-#endif
     // workgroups per CU x 256 CUs.  Measured on one box, 1 GiB of 32-byte rows, equals / contains in ms, (batches in flight,
     // workgroups per CU): (1, 8) 0.236 / 0.297, (1, 6) 0.222 / 0.283, (2, 8) 0.233 / 0.294, (2, 6) 0.224 / 0.285, (2, 4) 0.215 / 0.286,
     // (2, 3) 0.230 / 0.340, (2, 2) 0.276 / 0.380, (3, 4) 0.229 / 0.309, (4, 4) 0.220 / 0.295 — fewer, longer streams until the
     // arithmetic of `contains` runs out of waves (profiles/r05_colsearch_variants.txt)
-    constexpr u32 kSmallGrid = 256 * CSVSIMD_CS_GRID;
+    constexpr u32 kSmallGrid = 256 * 4;
     if (small && stride == 32)  // (every mode: `contains` too is 6 % faster with the contiguous loads once two batches are in flight)
         hipLaunchKernelGGL((colsearch_small_kernel<32, true>), dim3(cgrid_for(n_rows, 256, kSmallGrid)), dim3(256), 0, stream, c,
                            (const uint8_t*)d_needle, needle_len, mode, (u64*)d_bitmap, (u64*)d_count, (u64*)d_truncated);
