@@ -13,10 +13,12 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L > "$OUT/counters_list.txt" 2>&1 || true
 grep -i -E "TCC_EA0?_(RD|WR)REQ|TCC_REQ|TCC_HIT|TCC_MISS|FETCH_SIZE|WRITE_SIZE|SQ_LDS_BANK" "$OUT/counters_list.txt" | cut -c1-160 | sort -u | head -60 > "$OUT/counters_of_interest.txt" || true
+if [ -z "$SKIP_B2B" ]; then
 CMD="python3 $REPO/bench.py --only-back-to-back"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/b2b" -- $CMD > "$OUT/b2b.log" 2>&1
 find "$OUT/b2b" -name "*kernel_trace.csv" -exec cp {} "$OUT/kernel_trace_b2b.csv" \;
 python3 $REPO/scripts/summarise_b2b_trace.py "$OUT/kernel_trace_b2b.csv" > "$OUT/r05_kernel_trace_back_to_back.txt"
+fi
 CMD="python3 $REPO/bench.py --only-consumers-large"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/cl_stats" -- $CMD > "$OUT/cl_stats.log" 2>&1
 find "$OUT/cl_stats" -name "*kernel_stats.csv" -exec cp {} "$OUT/r05_kernel_stats_consumers_1GiB.csv" \;
@@ -37,7 +39,7 @@ for path in glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv")
                 continue
             acc[k.split("(")[0]][r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
 res = {}
-CASES = ("all_distinct", "100_values", "10000_values")   # bench.py consumers_large_leg runs them in this order, 16 calls each
+CASES = ("all_distinct", "100_values", "1000_values", "10000_values")   # bench.py consumers_large_leg runs them in this order, 16 calls each
 for k, c in sorted(acc.items()):
     e = {}
     for name, per in c.items():
@@ -45,8 +47,8 @@ for k, c in sorted(acc.items()):
         vals = [per[d] for d in order]
         sv = sorted(vals)
         e[name] = {"dispatches": len(vals), "median_per_dispatch": sv[len(sv) // 2], "max_per_dispatch": sv[-1]}
-        if "colfreq" in k and len(vals) % 3 == 0:
-            third = len(vals) // 3
+        if "colfreq" in k and len(vals) % len(CASES) == 0:
+            third = len(vals) // len(CASES)
             for ci, case in enumerate(CASES):
                 part = sorted(vals[ci * third:(ci + 1) * third])
                 e[name][case] = part[len(part) // 2]
@@ -69,4 +71,4 @@ find "$OUT" -name "*kernel_trace.csv" -not -name "kernel_trace_b2b.csv" -delete
 find "$OUT" -name "*counter_collection.csv" -delete
 find "$OUT" -name "*agent_info.csv" -delete
 rm -f "$OUT/kernel_trace_b2b.csv"
-cat "$OUT/r05_kernel_trace_back_to_back.txt" | head -60
+if [ -f "$OUT/r05_kernel_trace_back_to_back.txt" ]; then head -60 "$OUT/r05_kernel_trace_back_to_back.txt"; fi
