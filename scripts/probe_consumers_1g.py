@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """dev tool (round 5): the column consumers at a size where a roofline fraction means something — 32 Mi records x 32 bytes
-(1 GiB of column): search (equals / contains), frequency count with 100 / 10 000 / all-distinct values.  Device time by events."""
+(1 GiB of column): search (equals / contains), frequency count with 100 / 10 000 / all-distinct values.  Device time by events.
+usage: probe_consumers_1g.py [records]; PROBE_ONLY=search|freq, PROBE_KINDS=all_distinct,100,1000 (numbers of values),
+PROBE_REPS=30 (search: best of), CSVSIMD_LIB=<variant .so> for A/B runs of tuning builds."""
 import json, os, sys, time
 import numpy as np
 import torch
