@@ -1552,6 +1552,160 @@ __global__ __launch_bounds__(256, 2) void colsearch_small_kernel(const ColView c
     if (trunc) atomicAdd((unsigned long long*)truncated, (unsigned long long)trunc);
 }
 
+// ---- rows of 32 bytes without the swap ---------------------------------------------------------------------------------------
+// The same contiguous fetch (a lane holds piece `lane` of the batch's rows 0..31 — half lane & 1 of row lane >> 1 — and piece
+// `lane` of rows 32..63), but every lane searches the HALVES it fetched: equals / starts-with compare a half with the needle's
+// half (a row matches if both of its lanes say so: the ballot's neighbouring bits and-ed), `contains` looks for windows that
+// START in the lane's half — a first half borrows the first dword of its neighbour's second half for the windows that cross
+// over (one DPP move), a second half is followed by the row's end — and a row has a candidate if either lane has one.  The
+// swap's eight DPP moves and eight selects per row are gone; the arithmetic of these kernels ADDS to their time (a wave asks for
+// its next rows when it has finished with the previous ones).
+__global__ __launch_bounds__(256, 2) void colsearch32_kernel(const ColView c, const uint8_t* __restrict__ needle, u32 m, int mode,
+                                                             u64* __restrict__ bitmap, u64* __restrict__ count,
+                                                             u64* __restrict__ truncated) {
+    constexpr u32 STRIDE = 32;
+    __shared__ u64 s_needle[kColMaxNeedle / 8 + 1];
+    for (u32 k = threadIdx.x; k < kColMaxNeedle / 8 + 1; k += blockDim.x) {
+        u64 w = 0;
+        for (u32 j = 0; j < 8; ++j)
+            if (8 * k + j < m) w |= (u64)needle[8 * k + j] << (8 * j);
+        s_needle[k] = w;
+    }
+    __syncthreads();
+    const u64 n_words = (c.n_rows + 63) / 64;
+    const u32 lane = threadIdx.x & 63u;
+    const u32 half = lane & 1u;
+    // this lane's half of the needle's first 32 bytes and which of its bytes exist; the needle's first four bytes and first
+    // three bytes broadcast (the filters of `contains`)
+    u32 nd[4], nmask[4];
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k) {
+        const u32 kk = 4 * half + k;
+        nd[k] = (u32)(s_needle[kk >> 1] >> (32 * (kk & 1)));
+        nmask[k] = m >= 4 * kk + 4 ? ~0u : (m > 4 * kk ? (1u << (8 * (m - 4 * kk))) - 1u : 0u);
+    }
+    const u32 n4 = (u32)s_needle[0];
+    const u32 b0 = (n4 & 0xffu) * 0x01010101u, b1 = ((n4 >> 8) & 0xffu) * 0x01010101u, b2 = ((n4 >> 16) & 0xffu) * 0x01010101u;
+    u32 hits = 0, trunc = 0;
+    const u64 step = ((u64)gridDim.x * blockDim.x) >> 6;
+    u64 word = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const u64 last_row = c.n_rows - 1, last_piece = c.n_rows * 2 - 1;
+    const u32* const lens = c.len ? c.len : reinterpret_cast<const u32*>(c.col);
+    struct Batch {
+        u32x4c a, b;  // piece `lane` of rows 0..31 and of rows 32..63
+        u32 la, lb;   // those rows' lengths
+    };
+    auto fetch = [&](u64 wd, Batch& v) {  // (no branch around a load: see colsearch_small_kernel)
+        if (wd >= n_words) wd = n_words - 1;
+        const u64 i0 = wd * 64;
+        const u32x4c* const p = reinterpret_cast<const u32x4c*>(c.col);
+        const u64 q0 = i0 * 2 + lane, q1 = q0 + 64;
+        v.a = __builtin_nontemporal_load(p + (q0 < last_piece ? q0 : last_piece));
+        v.b = __builtin_nontemporal_load(p + (q1 < last_piece ? q1 : last_piece));
+        const u64 ra = i0 + (lane >> 1), rb = ra + 32;
+        const u32 la = __builtin_nontemporal_load(lens + (c.len ? (ra < last_row ? ra : last_row) : 0));
+        const u32 lb = __builtin_nontemporal_load(lens + (c.len ? (rb < last_row ? rb : last_row) : 0));
+        v.la = c.len ? la : STRIDE;
+        v.lb = c.len ? lb : STRIDE;
+    };
+    // one half: does it (mode 0 / 1) equal its half of the needle, or (mode 2) hold the start of a window that may be the needle?
+    // Returns the lane's flag; for `contains` with needles of four bytes and more the flag is a CANDIDATE.
+    auto look = [&](const u32x4c v, const u32 nx, const u32 full, const bool valid) -> bool {
+        if (!valid) return false;
+        const u32 n = full < STRIDE ? full : STRIDE;
+        if (mode != 2) {
+            const u32 diff = ((v.x ^ nd[0]) & nmask[0]) | ((v.y ^ nd[1]) & nmask[1]) | ((v.z ^ nd[2]) & nmask[2]) | ((v.w ^ nd[3]) & nmask[3]);
+            return m <= STRIDE && (mode == 0 ? n == m : n >= m) && diff == 0;
+        }
+        if (m == 0) return true;
+        if (n < m) return false;
+        const u32 last = n - m;  // last start position of the row
+        // the dword behind this half: the neighbour's first (a first half), nothing (a second half: the row ends)
+        const u32 d[5] = {v.x, v.y, v.z, v.w, half ? 0u : nx};
+        if (last < 16u * half) return false;  // no window may start in this half
+        if (m >= 4) {
+            u32 best = ~0u;
+#pragma unroll
+            for (u32 k = 0; k < 4; ++k) {
+                const u32x4c r = __builtin_amdgcn_mqsad_u32_u8((u64)d[k] | ((u64)d[k + 1] << 32), n4, u32x4c{0, 0, 0, 0});
+                best = min(best, min(min(r.x, r.y), min(r.z, r.w)));
+            }
+            return best == 0;
+        }
+        const u32 lim = last - 16u * half;  // start positions 0 .. lim of this half
+        const u32 cand = (m == 1 ? prefix_candidates<4, 1>(d, b0, b1, b2) : m == 2 ? prefix_candidates<4, 2>(d, b0, b1, b2)
+                                                                                   : prefix_candidates<4, 3>(d, b0, b1, b2)) &
+                         (lim >= 15u ? 0xffffu : ((2u << lim) - 1u));
+        return cand != 0;
+    };
+    // the needle anywhere in row i?  (the rare row whose half had a candidate: position by position from its cache line)
+    auto verify = [&](const u64 i, const u32 full) -> bool {
+        const u32 n = full < STRIDE ? full : STRIDE;
+        const uint8_t* const row = c.col + i * STRIDE;
+        bool match = false;
+        for (u32 pos = 0; pos + m <= n && !match; ++pos) {
+            bool ok = true;
+            for (u32 q = 0; 8 * q < m && ok; ++q) {
+                const u32 left = m - 8 * q;
+                const u64 mask = left >= 8 ? ~0ull : ((1ull << (8 * left)) - 1ull);
+                ok = ((col_load8(row, pos + 8 * q, STRIDE) ^ s_needle[q]) & mask) == 0;
+            }
+            match = ok;
+        }
+        return match;
+    };
+    auto pack_even = [](u64 x) -> u64 {  // the even bits of x, packed
+        x &= 0x5555555555555555ull;
+        x = (x | (x >> 1)) & 0x3333333333333333ull;
+        x = (x | (x >> 2)) & 0x0f0f0f0f0f0f0f0full;
+        x = (x | (x >> 4)) & 0x00ff00ff00ff00ffull;
+        x = (x | (x >> 8)) & 0x0000ffff0000ffffull;
+        x = (x | (x >> 16)) & 0x00000000ffffffffull;
+        return x;
+    };
+    const bool both = mode != 2;             // a row matches if BOTH halves do (equals / starts-with) or if EITHER does
+    const bool exact = mode != 2 || m <= 3;  // the halves' flags decide; otherwise they name candidates
+    auto search = [&](const u64 wd, const Batch& v) {
+        const u64 ia = wd * 64 + (lane >> 1), ib = ia + 32;
+        // (the neighbour's first dword, fetched while every lane is still active)
+        const u32 nxa = (u32)__builtin_amdgcn_mov_dpp((int)v.a.x, 0xb1, 0xf, 0xf, true);  // quad_perm [1, 0, 3, 2]
+        const u32 nxb = (u32)__builtin_amdgcn_mov_dpp((int)v.b.x, 0xb1, 0xf, 0xf, true);
+        const bool fa = look(v.a, nxa, v.la, ia < c.n_rows), fb = look(v.b, nxb, v.lb, ib < c.n_rows);
+        if (half == 0) trunc += (ia < c.n_rows && v.la > STRIDE ? 1u : 0u) + (ib < c.n_rows && v.lb > STRIDE ? 1u : 0u);
+        u64 xa = __ballot(fa), xb = __ballot(fb);  // bit 2r, 2r + 1: the halves of row r (of row 32 + r)
+        xa = both ? xa & (xa >> 1) : xa | (xa >> 1);
+        xb = both ? xb & (xb >> 1) : xb | (xb >> 1);
+        if (!exact) {
+            // candidates: the even lane of a pair searches its row
+            const bool ma = ((xa >> lane) & 1ull) && half == 0 && verify(ia, v.la);
+            const bool mb = ((xb >> lane) & 1ull) && half == 0 && verify(ib, v.lb);
+            xa = __ballot(ma);
+            xb = __ballot(mb);
+        }
+        const u64 bits = pack_even(xa) | (pack_even(xb) << 32);
+        if (lane == 0) {
+            bitmap[wd] = bits;
+            hits += (u32)__builtin_popcountll(bits);
+        }
+    };
+    constexpr u32 kDepth = 2;  // batches in flight per wave
+    Batch v[kDepth];
+#pragma unroll
+    for (u32 j = 0; j < kDepth; ++j) fetch(word + j * step, v[j]);
+    for (; word < n_words; word += kDepth * step) {
+#pragma unroll
+        for (u32 j = 0; j < kDepth; ++j) {
+            if (word + j * step < n_words) {
+                const Batch cur = v[j];
+                fetch(word + (kDepth + j) * step, v[j]);
+                search(word + j * step, cur);
+            }
+        }
+    }
+    if (lane == 0 && hits) atomicAdd((unsigned long long*)count, (unsigned long long)hits);
+    if (trunc) atomicAdd((unsigned long long*)truncated, (unsigned long long)trunc);
+}
+
 hipError_t launch_colsearch(const void* d_col, const void* d_len, u64 n_rows, u32 stride, const void* d_needle,
                             u32 needle_len, int mode, void* d_bitmap, void* d_count, void* d_truncated, hipStream_t stream) {
     if (n_rows == 0) return hipSuccess;
@@ -1564,7 +1718,13 @@ hipError_t launch_colsearch(const void* d_col, const void* d_len, u64 n_rows, u3
     // (2, 3) 0.230 / 0.340, (2, 2) 0.276 / 0.380, (3, 4) 0.229 / 0.309, (4, 4) 0.220 / 0.295 — fewer, longer streams until the
     // arithmetic of `contains` runs out of waves (profiles/r05_colsearch_variants.txt)
     constexpr u32 kSmallGrid = 256 * 4;
-    if (small && stride == 32)  // (every mode: `contains` too is 6 % faster with the contiguous loads once two batches are in flight)
+    // rows of 32 bytes: halves searched where they were fetched — except `contains` with needles of four bytes and more, which is
+    // faster on whole rows (0.257 / 0.244 against 0.277 / 0.265 ms for 6 / 12 bytes; equals 0.215 -> 0.194-0.204, one-byte
+    // `contains` 0.240 -> 0.221: profiles/r05_colsearch_variants.txt)
+    if (small && stride == 32 && !(mode == 2 && needle_len >= 4))
+        hipLaunchKernelGGL(colsearch32_kernel, dim3(cgrid_for(n_rows, 256, kSmallGrid)), dim3(256), 0, stream, c,
+                           (const uint8_t*)d_needle, needle_len, mode, (u64*)d_bitmap, (u64*)d_count, (u64*)d_truncated);
+    else if (small && stride == 32)  // (`contains` too is 6 % faster with the contiguous loads once two batches are in flight)
         hipLaunchKernelGGL((colsearch_small_kernel<32, true>), dim3(cgrid_for(n_rows, 256, kSmallGrid)), dim3(256), 0, stream, c,
                            (const uint8_t*)d_needle, needle_len, mode, (u64*)d_bitmap, (u64*)d_count, (u64*)d_truncated);
     else if (small)
