@@ -1555,10 +1555,11 @@ __global__ __launch_bounds__(256, 2) void colsearch_small_kernel(const ColView c
 // ---- rows of 32 bytes without the swap ---------------------------------------------------------------------------------------
 // The same contiguous fetch (a lane holds piece `lane` of the batch's rows 0..31 — half lane & 1 of row lane >> 1 — and piece
 // `lane` of rows 32..63), but every lane searches the HALVES it fetched: equals / starts-with compare a half with the needle's
-// half (a row matches if both of its lanes say so: the ballot's neighbouring bits and-ed), `contains` looks for windows that
-// START in the lane's half — a first half borrows the first dword of its neighbour's second half for the windows that cross
-// over (one DPP move), a second half is followed by the row's end — and a row has a candidate if either lane has one.  The
-// swap's eight DPP moves and eight selects per row are gone; the arithmetic of these kernels ADDS to their time (a wave asks for
+// half (a row matches if both of its lanes say so: the ballot's neighbouring bits and-ed), `contains` with needles of up to
+// three bytes looks for the needle STARTING in the lane's half — a first half borrows the first dword of its neighbour's second
+// half for the windows that cross over (one DPP move), a second half is followed by the row's end — and a row matches if either
+// lane found it.  (Longer needles — a filter on four bytes, then the rare exact search — were slower this way, 0.273 against
+// 0.246 ms, and take colsearch_small_kernel<32, true>.)  The swap's eight DPP moves and eight selects per row are gone; the arithmetic of these kernels ADDS to their time (a wave asks for
 // its next rows when it has finished with the previous ones).
 __global__ __launch_bounds__(256, 2) void colsearch32_kernel(const ColView c, const uint8_t* __restrict__ needle, u32 m, int mode,
                                                              u64* __restrict__ bitmap, u64* __restrict__ count,
@@ -1584,7 +1585,7 @@ __global__ __launch_bounds__(256, 2) void colsearch32_kernel(const ColView c, co
         nd[k] = (u32)(s_needle[kk >> 1] >> (32 * (kk & 1)));
         nmask[k] = m >= 4 * kk + 4 ? ~0u : (m > 4 * kk ? (1u << (8 * (m - 4 * kk))) - 1u : 0u);
     }
-    const u32 n4 = (u32)s_needle[0];
+    const u32 n4 = (u32)s_needle[0];  // (needles of up to three bytes: the launch sends longer ones of `contains` elsewhere)
     const u32 b0 = (n4 & 0xffu) * 0x01010101u, b1 = ((n4 >> 8) & 0xffu) * 0x01010101u, b2 = ((n4 >> 16) & 0xffu) * 0x01010101u;
     u32 hits = 0, trunc = 0;
     const u64 step = ((u64)gridDim.x * blockDim.x) >> 6;
@@ -1608,8 +1609,8 @@ __global__ __launch_bounds__(256, 2) void colsearch32_kernel(const ColView c, co
         v.la = c.len ? la : STRIDE;
         v.lb = c.len ? lb : STRIDE;
     };
-    // one half: does it (mode 0 / 1) equal its half of the needle, or (mode 2) hold the start of a window that may be the needle?
-    // Returns the lane's flag; for `contains` with needles of four bytes and more the flag is a CANDIDATE.
+    // one half: does it (mode 0 / 1) equal its half of the needle, or (mode 2, needles of up to three bytes) hold the start of
+    // the needle?
     auto look = [&](const u32x4c v, const u32 nx, const u32 full, const bool valid) -> bool {
         if (!valid) return false;
         const u32 n = full < STRIDE ? full : STRIDE;
@@ -1623,36 +1624,11 @@ __global__ __launch_bounds__(256, 2) void colsearch32_kernel(const ColView c, co
         // the dword behind this half: the neighbour's first (a first half), nothing (a second half: the row ends)
         const u32 d[5] = {v.x, v.y, v.z, v.w, half ? 0u : nx};
         if (last < 16u * half) return false;  // no window may start in this half
-        if (m >= 4) {
-            u32 best = ~0u;
-#pragma unroll
-            for (u32 k = 0; k < 4; ++k) {
-                const u32x4c r = __builtin_amdgcn_mqsad_u32_u8((u64)d[k] | ((u64)d[k + 1] << 32), n4, u32x4c{0, 0, 0, 0});
-                best = min(best, min(min(r.x, r.y), min(r.z, r.w)));
-            }
-            return best == 0;
-        }
         const u32 lim = last - 16u * half;  // start positions 0 .. lim of this half
         const u32 cand = (m == 1 ? prefix_candidates<4, 1>(d, b0, b1, b2) : m == 2 ? prefix_candidates<4, 2>(d, b0, b1, b2)
                                                                                    : prefix_candidates<4, 3>(d, b0, b1, b2)) &
                          (lim >= 15u ? 0xffffu : ((2u << lim) - 1u));
         return cand != 0;
-    };
-    // the needle anywhere in row i?  (the rare row whose half had a candidate: position by position from its cache line)
-    auto verify = [&](const u64 i, const u32 full) -> bool {
-        const u32 n = full < STRIDE ? full : STRIDE;
-        const uint8_t* const row = c.col + i * STRIDE;
-        bool match = false;
-        for (u32 pos = 0; pos + m <= n && !match; ++pos) {
-            bool ok = true;
-            for (u32 q = 0; 8 * q < m && ok; ++q) {
-                const u32 left = m - 8 * q;
-                const u64 mask = left >= 8 ? ~0ull : ((1ull << (8 * left)) - 1ull);
-                ok = ((col_load8(row, pos + 8 * q, STRIDE) ^ s_needle[q]) & mask) == 0;
-            }
-            match = ok;
-        }
-        return match;
     };
     auto pack_even = [](u64 x) -> u64 {  // the even bits of x, packed
         x &= 0x5555555555555555ull;
@@ -1663,8 +1639,7 @@ __global__ __launch_bounds__(256, 2) void colsearch32_kernel(const ColView c, co
         x = (x | (x >> 16)) & 0x00000000ffffffffull;
         return x;
     };
-    const bool both = mode != 2;             // a row matches if BOTH halves do (equals / starts-with) or if EITHER does
-    const bool exact = mode != 2 || m <= 3;  // the halves' flags decide; otherwise they name candidates
+    const bool both = mode != 2;  // a row matches if BOTH halves do (equals / starts-with) or if EITHER does (`contains`)
     auto search = [&](const u64 wd, const Batch& v) {
         const u64 ia = wd * 64 + (lane >> 1), ib = ia + 32;
         // (the neighbour's first dword, fetched while every lane is still active)
@@ -1672,16 +1647,9 @@ __global__ __launch_bounds__(256, 2) void colsearch32_kernel(const ColView c, co
         const u32 nxb = (u32)__builtin_amdgcn_mov_dpp((int)v.b.x, 0xb1, 0xf, 0xf, true);
         const bool fa = look(v.a, nxa, v.la, ia < c.n_rows), fb = look(v.b, nxb, v.lb, ib < c.n_rows);
         if (half == 0) trunc += (ia < c.n_rows && v.la > STRIDE ? 1u : 0u) + (ib < c.n_rows && v.lb > STRIDE ? 1u : 0u);
-        u64 xa = __ballot(fa), xb = __ballot(fb);  // bit 2r, 2r + 1: the halves of row r (of row 32 + r)
+        u64 xa = __ballot(fa), xb = __ballot(fb);  // bits 2r and 2r + 1: the halves of row r (of row 32 + r)
         xa = both ? xa & (xa >> 1) : xa | (xa >> 1);
         xb = both ? xb & (xb >> 1) : xb | (xb >> 1);
-        if (!exact) {
-            // candidates: the even lane of a pair searches its row
-            const bool ma = ((xa >> lane) & 1ull) && half == 0 && verify(ia, v.la);
-            const bool mb = ((xb >> lane) & 1ull) && half == 0 && verify(ib, v.lb);
-            xa = __ballot(ma);
-            xb = __ballot(mb);
-        }
         const u64 bits = pack_even(xa) | (pack_even(xb) << 32);
         if (lane == 0) {
             bitmap[wd] = bits;
