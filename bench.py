@@ -990,6 +990,12 @@ def consumers_large_leg(pkg, device):
         a = alg + int(st.n_distinct) * 16
         freq[label] = {"ms": round(t * 1e3, 4), "distinct": int(st.n_distinct), "algorithmic_bytes": a,
                        "GBps_algorithmic": round(a / t / 1e9, 1), "frac": round(a / t / 1e9 / HBM_PEAK_GBPS, 4), "verified": bool(good)}
+    freq["note"] = ("three launches on the caller's stream, asynchronous: colfreq_stream_kernel first (one workgroup per CU keeps one LDS "
+                    "table — 3 072 slots with copies of the rows — over its whole share of the column; 100 and 1 000 values end "
+                    "there), then the general passes for the shares it gave up on (more than 2 304 values per share: the 10 000-value "
+                    "and the all-distinct column, whose attempt ends within the first batch): slabs of 8 192 records -> tuples "
+                    "partitioned by hash -> partitions merged in LDS, bytes compared everywhere; ms = device time per call "
+                    "(events around 5 back-to-back calls, best of 3); algorithmic bytes = the column read + 16 B per distinct value")
     out["frequency_count"] = freq
     del ent, scratch
     bm = torch.zeros((nrec + 63) // 64 + 1, dtype=torch.int64, device=device)
@@ -1018,6 +1024,10 @@ def consumers_large_leg(pkg, device):
     bits = bm[: (1 << 20) // 64].cpu().numpy().view(np.uint64)
     want_bits = np.packbits(m.cpu().numpy(), bitorder="little").view(np.uint64)
     ok = ok and int(m.sum()) == hits and bool(np.array_equal(bits, want_bits))
+    search["note"] = ("rows of 32 bytes in registers, contiguous wave loads (a lane holds half rows), two batches in flight: equals / "
+                      "starts-with / needles of up to three bytes search the halves where they are (colsearch32_kernel), longer needles "
+                      "swap halves into whole rows and filter with v_mqsad_u32_u8 (colsearch_small_kernel); ms = wall time of one "
+                      "synchronous call (launch, kernel, the count's copy), best of 7; algorithmic bytes = the column")
     out["search"] = search
     del col, bm, sl, m
     torch.cuda.empty_cache()
