@@ -118,10 +118,11 @@ struct csvsimd_ctx {
     uint32_t max_blocks = 0;
     int n_cus = 0;
     csvsimd_shard_result* d_result = nullptr;  // for the synchronous entry points
-    void* d_small = nullptr;                   // 8 KiB: [0, 16) match / truncation counters, [64, 328) search needle, [512, 544)
+    void* d_small = nullptr;                   // 8 KiB: [0, 16) match / truncation counters, [16, 24) the columnar search's packed word (zero between calls), [64, 328) search needle, [512, 544)
                                                // status of the synchronous frequency count, [1024, 5120) field list of
                                                // csvsimd_chunk_to_columns_device
     void* h_small = nullptr;                   // 256 B pinned: where the synchronous consumers' few result words land
+    uint64_t search_seq = 0;                   // calls of the columnar search (the number its kernel publishes)
     // host-buffer path (csvsimd_stage1_index): kSlots-slot pipeline; every slot is allocated when a call first needs it
     static constexpr uint64_t kChunk = 32ull << 20;  // bytes per slot
     static constexpr int kSlots = 4;
@@ -222,7 +223,9 @@ int csvsimd_ctx_create(int device, csvsimd_ctx** out) {
     ctx->max_blocks = (uint32_t)(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256) * (uint32_t)per_cu;
     HIP_TRY(hipMalloc((void**)&ctx->d_result, sizeof(csvsimd_shard_result)));
     HIP_TRY(hipMalloc(&ctx->d_small, 8192));
+    HIP_TRY(hipMemset(ctx->d_small, 0, 8192));  // (the columnar search's words and arrival counter start, and are left, at zero)
     HIP_TRY(hipHostMalloc(&ctx->h_small, 256, hipHostMallocDefault));
+    memset(ctx->h_small, 0, 256);
     *out = ctx.release();
     const int rc = csvsimd_ctx_reserve(*out, 1ull << 30);
     if (rc != CSVSIMD_OK) {
@@ -2201,15 +2204,24 @@ int csvsimd_columnar_search_device(csvsimd_ctx* ctx, const void* d_col, const vo
     if (n_records == 0) return CSVSIMD_OK;
     WITH_DEVICE_OF(ctx);
     hipStream_t s = (hipStream_t)hip_stream;
-    uint64_t h[2] = {0, 0};  // matches, records longer than the stride
-    HIP_TRY(hipMemsetAsync(ctx->d_small, 0, 16, s));
-    if (needle_len) HIP_TRY(hipMemcpyAsync((char*)ctx->d_small + 64, needle, needle_len, hipMemcpyHostToDevice, s));
-    HIP_TRY(csvsimd::launch_colsearch(d_col, d_len, n_records, stride, (char*)ctx->d_small + 64, needle_len, mode, d_bitmap,
-                                      ctx->d_small, (char*)ctx->d_small + 8, s));
-    HIP_TRY(hipMemcpyAsync(h, ctx->d_small, 16, hipMemcpyDeviceToHost, s));
+    // One launch and the wait (round 5; before: a memset, the needle's copy from pageable memory, the launch, a 16-byte copy back
+    // and the wait — ~25 us around the kernel): the needle rides in the kernel's arguments, the kernel's last workgroup writes
+    // one word — this call's number, "a record was longer than the stride", the matches — to pinned memory and leaves its
+    // device word at zero.
+    volatile uint64_t* const rec = reinterpret_cast<volatile uint64_t*>((char*)ctx->h_small + 192);
+    void* rec_dev = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&rec_dev, (void*)rec, 0));
+    const uint64_t seq = (++ctx->search_seq) & 0xffffu;
+    HIP_TRY(csvsimd::launch_colsearch(d_col, d_len, n_records, stride, needle, needle_len, mode, d_bitmap, (char*)ctx->d_small + 16,
+                                      rec_dev, seq, s));
     HIP_TRY(hipStreamSynchronize(s));
-    *n_matches = h[0];
-    return h[1] ? CSVSIMD_ERR_TAPE_CAPACITY : CSVSIMD_OK;  // truncated records: the match is only known for their first `stride` bytes
+    const uint64_t w = *rec;
+    if ((w >> 48) != seq) {
+        g_last_error = "columnar search: the result was not published";
+        return CSVSIMD_ERR_INTERNAL;
+    }
+    *n_matches = w & ((1ull << 47) - 1);
+    return ((w >> 47) & 1) ? CSVSIMD_ERR_TAPE_CAPACITY : CSVSIMD_OK;  // truncated records: the match is only known for their first `stride` bytes
 }
 
 int csvsimd_trim_spans_device(const void* dbytes, void* d_begin, void* d_end, uint64_t n_records, uint32_t flags,

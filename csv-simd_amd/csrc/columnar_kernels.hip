@@ -21,6 +21,7 @@
 //   colsearch_kernel    equals / starts-with / contains over a column of the columnar copy.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "stage1_kernels.h"
 
@@ -1268,15 +1269,48 @@ __device__ __forceinline__ u64 col_load8(const uint8_t* row, u32 at, u32 stride)
     return v;
 }
 
-__global__ __launch_bounds__(256) void colsearch_kernel(const ColView c, const uint8_t* __restrict__ needle, u32 m, int mode,
-                                                        u64* __restrict__ bitmap, u64* __restrict__ count,
-                                                        u64* __restrict__ truncated) {
+// The needle travels in the kernel's arguments and the result comes back through pinned host memory (round 5): the synchronous
+// call used to be a memset, a copy of the needle from pageable memory, the launch, a 16-byte copy back and a wait — ~25 us
+// around a 190-us kernel at 1 GiB, and most of the call at 73 MB.  Now it is the launch and the wait.  Every workgroup adds ONE
+// 64-bit word to a device word — its matches (36 bits), whether it saw a record longer than the stride (a count of such
+// workgroups, 14 bits) and an arrival (14 bits) — so the workgroup whose addition returns "all others have arrived" holds the
+// totals in that one return value: no fence, no second trip.  It stores them, with the call's number, as one word in pinned host
+// memory and zeroes the device word for the next call.  (A version in which every thread fenced before its workgroup's arrival
+// — release at agent scope = a write-back of the L2 — cost 170 us per call.)
+struct ColNeedle {
+    u64 w[kColMaxNeedle / 8];  // the needle's bytes, little endian, zero padded
+};
+struct ColSearchOut {
+    u64* acc;    // device: the packed word (zero between calls)
+    u64* h_pub;  // pinned host memory (device address): seq << 48 | truncated << 47 | matches
+    u64 seq;
+};
+static constexpr u32 kCsHitBits = 36, kCsTruncBits = 14;  // + 14 bits of arrivals (at most 8 192 workgroups)
+__device__ __forceinline__ void colsearch_finish(const ColSearchOut o, u32* s_acc, u32 lane, u32 hits, u32 trunc) {
+    if (lane == 0 && hits) atomicAdd(&s_acc[0], hits);
+    if (trunc) atomicAdd(&s_acc[1], trunc);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const u64 mine = (1ull << (kCsHitBits + kCsTruncBits)) | ((u64)(s_acc[1] ? 1u : 0u) << kCsHitBits) | (u64)s_acc[0];
+        const u64 old = atomicAdd((unsigned long long*)o.acc, (unsigned long long)mine);
+        if ((old >> (kCsHitBits + kCsTruncBits)) == gridDim.x - 1) {  // the last to arrive: old + mine = everybody's
+            const u64 total = old + mine;
+            const u64 matches = total & ((1ull << kCsHitBits) - 1), tr = (total >> kCsHitBits) & ((1ull << kCsTruncBits) - 1);
+            __hip_atomic_store(o.acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(o.h_pub, (o.seq << 48) | ((u64)(tr ? 1u : 0u) << 47) | matches, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void colsearch_kernel(const ColView c, const ColNeedle needle, u32 m, int mode,
+                                                        u64* __restrict__ bitmap, const ColSearchOut out) {
     __shared__ u64 s_needle[kColMaxNeedle / 8 + 1];
-    for (u32 k = threadIdx.x; k < kColMaxNeedle / 8 + 1; k += blockDim.x) {
-        u64 w = 0;
-        for (u32 j = 0; j < 8; ++j)
-            if (8 * k + j < m) w |= (u64)needle[8 * k + j] << (8 * j);
-        s_needle[k] = w;
+    __shared__ u32 s_acc[2];  // the workgroup's matches and records longer than the stride
+    if (threadIdx.x == 0) {  // (constant indices: the words come straight from the argument segment; indexed by the thread
+                             // the compiler would copy the struct to scratch memory first)
+#pragma unroll
+        for (u32 k = 0; k < kColMaxNeedle / 8; ++k) s_needle[k] = needle.w[k];
+        s_needle[kColMaxNeedle / 8] = 0;
+        s_acc[0] = s_acc[1] = 0;
     }
     __syncthreads();
     const u64 n_words = (c.n_rows + 63) / 64;
@@ -1331,8 +1365,7 @@ __global__ __launch_bounds__(256) void colsearch_kernel(const ColView c, const u
             hits += (u32)__builtin_popcountll(bits);
         }
     }
-    if (lane == 0 && hits) atomicAdd((unsigned long long*)count, (unsigned long long)hits);
-    if (trunc) atomicAdd((unsigned long long*)truncated, (unsigned long long)trunc);
+    colsearch_finish(out, s_acc, lane, hits, trunc);
 }
 
 // ---- rows of 16 or 32 bytes (round 5) ----------------------------------------------------------------------------------------
@@ -1367,17 +1400,18 @@ __device__ __forceinline__ u32 prefix_candidates(const u32 (&d)[D + 1], u32 b0, 
     return c;
 }
 template <u32 STRIDE, bool COALESCED>
-__global__ __launch_bounds__(256, 2) void colsearch_small_kernel(const ColView c, const uint8_t* __restrict__ needle, u32 m, int mode,
-                                                                 u64* __restrict__ bitmap, u64* __restrict__ count,
-                                                                 u64* __restrict__ truncated) {
+__global__ __launch_bounds__(256, 2) void colsearch_small_kernel(const ColView c, const ColNeedle needle, u32 m, int mode,
+                                                                 u64* __restrict__ bitmap, const ColSearchOut out) {
     static_assert(STRIDE == 16 || STRIDE == 32, "rows that fit one or two 16-byte loads");
     constexpr u32 D = STRIDE / 4;  // dwords per row
     __shared__ u64 s_needle[kColMaxNeedle / 8 + 1];
-    for (u32 k = threadIdx.x; k < kColMaxNeedle / 8 + 1; k += blockDim.x) {
-        u64 w = 0;
-        for (u32 j = 0; j < 8; ++j)
-            if (8 * k + j < m) w |= (u64)needle[8 * k + j] << (8 * j);
-        s_needle[k] = w;
+    __shared__ u32 s_acc[2];  // the workgroup's matches and records longer than the stride
+    if (threadIdx.x == 0) {  // (constant indices: the words come straight from the argument segment; indexed by the thread
+                             // the compiler would copy the struct to scratch memory first)
+#pragma unroll
+        for (u32 k = 0; k < kColMaxNeedle / 8; ++k) s_needle[k] = needle.w[k];
+        s_needle[kColMaxNeedle / 8] = 0;
+        s_acc[0] = s_acc[1] = 0;
     }
     __syncthreads();
     const u64 n_words = (c.n_rows + 63) / 64;
@@ -1548,8 +1582,7 @@ __global__ __launch_bounds__(256, 2) void colsearch_small_kernel(const ColView c
             }
         }
     }
-    if (lane == 0 && hits) atomicAdd((unsigned long long*)count, (unsigned long long)hits);
-    if (trunc) atomicAdd((unsigned long long*)truncated, (unsigned long long)trunc);
+    colsearch_finish(out, s_acc, lane, hits, trunc);
 }
 
 // ---- rows of 32 bytes without the swap ---------------------------------------------------------------------------------------
@@ -1561,16 +1594,17 @@ __global__ __launch_bounds__(256, 2) void colsearch_small_kernel(const ColView c
 // lane found it.  (Longer needles — a filter on four bytes, then the rare exact search — were slower this way, 0.273 against
 // 0.246 ms, and take colsearch_small_kernel<32, true>.)  The swap's eight DPP moves and eight selects per row are gone; the arithmetic of these kernels ADDS to their time (a wave asks for
 // its next rows when it has finished with the previous ones).
-__global__ __launch_bounds__(256, 2) void colsearch32_kernel(const ColView c, const uint8_t* __restrict__ needle, u32 m, int mode,
-                                                             u64* __restrict__ bitmap, u64* __restrict__ count,
-                                                             u64* __restrict__ truncated) {
+__global__ __launch_bounds__(256, 2) void colsearch32_kernel(const ColView c, const ColNeedle needle, u32 m, int mode,
+                                                             u64* __restrict__ bitmap, const ColSearchOut out) {
     constexpr u32 STRIDE = 32;
     __shared__ u64 s_needle[kColMaxNeedle / 8 + 1];
-    for (u32 k = threadIdx.x; k < kColMaxNeedle / 8 + 1; k += blockDim.x) {
-        u64 w = 0;
-        for (u32 j = 0; j < 8; ++j)
-            if (8 * k + j < m) w |= (u64)needle[8 * k + j] << (8 * j);
-        s_needle[k] = w;
+    __shared__ u32 s_acc[2];  // the workgroup's matches and records longer than the stride
+    if (threadIdx.x == 0) {  // (constant indices: the words come straight from the argument segment; indexed by the thread
+                             // the compiler would copy the struct to scratch memory first)
+#pragma unroll
+        for (u32 k = 0; k < kColMaxNeedle / 8; ++k) s_needle[k] = needle.w[k];
+        s_needle[kColMaxNeedle / 8] = 0;
+        s_acc[0] = s_acc[1] = 0;
     }
     __syncthreads();
     const u64 n_words = (c.n_rows + 63) / 64;
@@ -1670,14 +1704,17 @@ __global__ __launch_bounds__(256, 2) void colsearch32_kernel(const ColView c, co
             }
         }
     }
-    if (lane == 0 && hits) atomicAdd((unsigned long long*)count, (unsigned long long)hits);
-    if (trunc) atomicAdd((unsigned long long*)truncated, (unsigned long long)trunc);
+    colsearch_finish(out, s_acc, lane, hits, trunc);
 }
 
-hipError_t launch_colsearch(const void* d_col, const void* d_len, u64 n_rows, u32 stride, const void* d_needle,
-                            u32 needle_len, int mode, void* d_bitmap, void* d_count, void* d_truncated, hipStream_t stream) {
-    if (n_rows == 0) return hipSuccess;
+hipError_t launch_colsearch(const void* d_col, const void* d_len, u64 n_rows, u32 stride, const void* needle_host,
+                            u32 needle_len, int mode, void* d_bitmap, void* d_acc, void* h_pub_dev, u64 seq, hipStream_t stream) {
+    if (n_rows == 0 || needle_len > kColMaxNeedle) return n_rows == 0 ? hipSuccess : hipErrorInvalidValue;
     const ColView c = {(const uint8_t*)d_col, (const u32*)d_len, n_rows, stride};
+    ColNeedle nd;
+    memset(&nd, 0, sizeof nd);
+    if (needle_len) memcpy(&nd, needle_host, needle_len);  // (little endian host: byte k of the needle = byte k of the words)
+    const ColSearchOut out = {(u64*)d_acc, (u64*)h_pub_dev, seq & 0xffffu};
     // rows of 16 / 32 bytes and a needle that fits the row: the register-resident search.  A persistent-sized grid (4
     // workgroups per CU) whose waves walk the column with two batches of loads in flight each.
     const bool small = (stride == 16 || stride == 32) && needle_len <= stride;
@@ -1691,16 +1728,16 @@ hipError_t launch_colsearch(const void* d_col, const void* d_len, u64 n_rows, u3
     // `contains` 0.240 -> 0.221: profiles/r05_colsearch_variants.txt)
     if (small && stride == 32 && !(mode == 2 && needle_len >= 4))
         hipLaunchKernelGGL(colsearch32_kernel, dim3(cgrid_for(n_rows, 256, kSmallGrid)), dim3(256), 0, stream, c,
-                           (const uint8_t*)d_needle, needle_len, mode, (u64*)d_bitmap, (u64*)d_count, (u64*)d_truncated);
+                           nd, needle_len, mode, (u64*)d_bitmap, out);
     else if (small && stride == 32)  // (`contains` too is 6 % faster with the contiguous loads once two batches are in flight)
         hipLaunchKernelGGL((colsearch_small_kernel<32, true>), dim3(cgrid_for(n_rows, 256, kSmallGrid)), dim3(256), 0, stream, c,
-                           (const uint8_t*)d_needle, needle_len, mode, (u64*)d_bitmap, (u64*)d_count, (u64*)d_truncated);
+                           nd, needle_len, mode, (u64*)d_bitmap, out);
     else if (small)
         hipLaunchKernelGGL((colsearch_small_kernel<16, false>), dim3(cgrid_for(n_rows, 256, kSmallGrid)), dim3(256), 0, stream, c,
-                           (const uint8_t*)d_needle, needle_len, mode, (u64*)d_bitmap, (u64*)d_count, (u64*)d_truncated);
+                           nd, needle_len, mode, (u64*)d_bitmap, out);
     else
     hipLaunchKernelGGL(colsearch_kernel, dim3(cgrid_for(n_rows, 256, 8192)), dim3(256), 0, stream, c,
-                       (const uint8_t*)d_needle, needle_len, mode, (u64*)d_bitmap, (u64*)d_count, (u64*)d_truncated);
+                       nd, needle_len, mode, (u64*)d_bitmap, out);
     return hipGetLastError();
 }
 

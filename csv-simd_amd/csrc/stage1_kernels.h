@@ -149,8 +149,10 @@ struct FreqWideOut {
 hipError_t launch_colfreq(const void* d_col, const void* d_len, uint64_t n_rows, uint32_t stride, uint64_t first_record,
                           void* d_scratch, void* d_entries, uint64_t entries_cap, void* d_status, int n_cus, hipStream_t stream,
                           const FreqWideOut* wide = nullptr);
-hipError_t launch_colsearch(const void* d_col, const void* d_len, uint64_t n_rows, uint32_t stride, const void* d_needle,
-                            uint32_t needle_len, int mode, void* d_bitmap, void* d_count, void* d_truncated,
+// (the needle is HOST memory: it travels in the kernel's arguments; the last workgroup to arrive writes seq << 48 | truncated << 47 |
+// matches to the pinned word at h_pub_dev — its device address — and leaves the device word d_acc at zero, as it found it)
+hipError_t launch_colsearch(const void* d_col, const void* d_len, uint64_t n_rows, uint32_t stride, const void* needle_host,
+                            uint32_t needle_len, int mode, void* d_bitmap, void* d_acc, void* h_pub_dev, uint64_t seq,
                             hipStream_t stream);
 // text_kernels.hip
 hipError_t launch_utf8_validate(const void* dbuf, uint64_t len, void* d_result, int n_cus, hipStream_t stream);
