@@ -2202,6 +2202,7 @@ int csvsimd_columnar_search_device(csvsimd_ctx* ctx, const void* d_col, const vo
         return CSVSIMD_ERR_INVALID_ARG;
     *n_matches = 0;
     if (n_records == 0) return CSVSIMD_OK;
+    if (n_records >> 36) return CSVSIMD_ERR_INVALID_ARG;  // (the kernel's packed result word counts matches in 36 bits)
     WITH_DEVICE_OF(ctx);
     hipStream_t s = (hipStream_t)hip_stream;
     // One launch and the wait (round 5; before: a memset, the needle's copy from pageable memory, the launch, a 16-byte copy back

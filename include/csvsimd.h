@@ -528,7 +528,9 @@ int csvsimd_columnar_frequency_device(csvsimd_ctx* ctx, const void* d_col, const
                                       void* d_entries, uint64_t entries_cap, csvsimd_colfreq_status* status,
                                       void* hip_stream);
 /* csvsimd_column_search_device on a column of the columnar copy: bit i of d_bitmap = record i matches; same modes and
- * definitions.  CSVSIMD_ERR_TAPE_CAPACITY (bitmap and *n_matches still written) if some record is longer than the stride. */
+ * definitions.  CSVSIMD_ERR_TAPE_CAPACITY (bitmap and *n_matches still written) if some record is longer than the stride.
+ * The call is one launch and a wait on hip_stream (the needle — host memory, up to 256 bytes — travels in the kernel's arguments,
+ * the counts come back through pinned memory); n_records < 2^36 (CSVSIMD_ERR_INVALID_ARG above). */
 int csvsimd_columnar_search_device(csvsimd_ctx* ctx, const void* d_col, const void* d_len, uint64_t n_records,
                                    uint32_t stride, const void* needle, uint32_t needle_len, int mode, void* d_bitmap,
                                    uint64_t* n_matches, void* hip_stream);
