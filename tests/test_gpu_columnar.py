@@ -385,3 +385,7 @@ def test_columnar_search_on_16_and_32_byte_rows(ctx, pkg, torch_cuda, stride):
             got_n = pkg.columnar_search_device(ctx, col.data_ptr(), 0, n, stride, needle, mode, bm.data_ptr())
             bits = np.unpackbits(bm.cpu().numpy().view(np.uint8), bitorder="little")[:n].astype(bool)
             assert got_n == int(want.sum()) and np.array_equal(bits, want), (stride, needle, mode, "fixed width")
+    # the packed result word counts matches in 36 bits: more records than that per call are refused before anything runs
+    with pytest.raises(pkg.StructureError) as e:
+        pkg.columnar_search_device(ctx, col.data_ptr(), 0, 1 << 36, stride, b"abc", pkg.SEARCH_CONTAINS, bm.data_ptr())
+    assert e.value.code == pkg.ERR_INVALID_ARG
