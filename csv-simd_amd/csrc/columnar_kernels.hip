@@ -655,16 +655,18 @@ __global__ __launch_bounds__(kCfThreads1, 4) void colfreq_partition_kernel(const
 // workgroup leaves its share "not done" and colfreq_partition_kernel — launched behind this kernel, its workgroups skip
 // finished shares — counts those slabs the general way.  A column of distinct values costs every workgroup one batch before
 // it gives up.
-// The table: 3 072 slots in groups of four (rows of 16 bytes: 5 120).  A slot is a 32-bit key (12 hash bits | the number of a representative record
-// within the share, 20 bits; all ones = empty), a count, the representative's length (bit 31: its row has arrived) and a copy
-// of its row.  A value's probe sequence starts at its group: ONE 16-byte LDS read fetches the group's keys, the first with
-// the record's tag names the slot, row and length are compared from LDS.  Anything else — a new value, one that sits past
-// its group (2 % of the values when the table holds 1 000), a second key with the same tag, a row still on its way — goes
-// slot by slot from the group's start; the table takes 2 304 values (three quarters of its slots; 3 840 for rows of 16 bytes).  The smallest record of a value ends up as its representative (a 32-bit minimum on
-// the key: same tag, smaller record), the tuple's hash bits are recomputed from the row copy when the table leaves.
-// Measured at 32 Mi records x 32 bytes: 100 values 0.50 -> 0.26 ms (0.277 with per-lane row loads, whose bare stream is 0.225; a version that
-// compared against the representative's row in the COLUMN instead of LDS, with 16 384 slots: 2 000 values 0.65 ms, 5 000
-// 1.0, 10 000 2.7 — a gather per record from the L2, whose working set is a share's representatives x 32 CUs).
+// The table: 3 072 slots in groups of four (rows of 16 bytes: 5 120).  A slot is a 32-bit key (12 hash bits | the number of a
+// representative record within the share, 20 bits; all ones = empty), a count, the representative's length (bit 31: its row
+// has arrived) and a copy of its row.  A value's probe sequence starts at its group: ONE 16-byte LDS read fetches the group's
+// keys (the next group's too if the first is full of other tags), the first with the record's tag names the slot, row and
+// length are compared from LDS.  Anything else — a new value, one that sits further along, a second key with the same tag, a
+// row still on its way — goes slot by slot from the group's start; the table takes 2 304 values (three quarters of its slots;
+// 3 840 for rows of 16 bytes).  The smallest record of a value ends up as its representative (a 32-bit minimum on the key:
+// same tag, smaller record), the tuple's hash bits are recomputed from the row copy when the table leaves.
+// Measured at 32 Mi records x 32 bytes: 100 values 0.50 -> 0.24 ms, 1 000 values 0.29, 2 000 0.79 (general passes: 1.9-2.2); the
+// kernel's bare stream — no hash, no table — is 0.225 ms with per-lane row loads.  A version that compared against the
+// representative's row in the COLUMN instead of LDS, with 16 384 slots: 2 000 values 0.65 ms, 5 000 1.0, 10 000 2.7 — a gather
+// per record from the L2, whose working set is a share's representatives x 32 CUs (profiles/r05_colfreq_stream_variants.txt).
 // groups of four slots: 768 for rows of 32 bytes, 1 280 for rows of 16 (a slot is 12 bytes + the row: ~132 and ~140 KiB of LDS)
 template <u32 STRIDE> struct CfStreamTable { static constexpr u32 kGroups = STRIDE > 16 ? 768u : 1280u; };
 static constexpr u32 kCfStreamThreads = 1024;
